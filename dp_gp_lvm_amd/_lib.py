@@ -1,0 +1,70 @@
+"""
+ctypes binding of libdpgp_hip.so (the C ABI declared in include/dpgp.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  If the shared object has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C dp_gp_lvm_amd/csrc``) every operator raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdpgp_hip.so')
+
+FLAG_NOISE, FLAG_JITTER = 1, 2
+ALGO = {'auto': 0, 'mfma': 0, 'plain': 1}
+PREC = {'f32': 0, 'mixed': 1, 'f64': 2}
+
+_vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+
+# name -> (restype, argtypes); one entry per symbol declared in include/dpgp.h
+SIGNATURES = {
+    'dpgp_version': (_i, []),
+    'dpgp_psi1T_y_workspace_bytes': (_sz, [_i, _i, _i]),
+    'dpgp_psi2_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'dpgp_potrf_workspace_bytes': (_sz, [_i, _i, _i]),
+    'dpgp_trsm_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'dpgp_elbo_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'dpgp_elbo_fhat': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp, _sz,
+                            _vp]),
+}
+for _t in ('f32', 'f64'):
+    SIGNATURES.update({
+        'dpgp_ard_rbf_gram_' + _t: (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp]),
+        'dpgp_ard_rbf_diag_' + _t: (_i, [_i, _i, _vp, _vp, _i, _d, _vp, _vp]),
+        'dpgp_psi0_' + _t: (_i, [_i, _i, _vp, _vp, _vp]),
+        'dpgp_psi1_' + _t: (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+        'dpgp_psi1T_y_' + _t: (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+        'dpgp_psi2_' + _t: (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+        'dpgp_potrf_batched_' + _t: (_i, [_i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
+        'dpgp_trsm_batched_' + _t: (_i, [_i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
+        'dpgp_kl_qx_' + _t: (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    })
+
+_lib = None
+
+
+class DpgpLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises loudly when it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DpgpLibraryMissing(
+                'libdpgp_hip.so is not built: run `make -C %s` (hipcc, gfx950). dp_gp_lvm_amd has no CPU fallback.'
+                % os.path.join(_HERE, 'csrc'))
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        if rc == -100:
+            raise RuntimeError('%s: HIP kernel launch failed' % name)
+        raise ValueError('%s: bad argument #%d' % (name, -rc))

@@ -1,0 +1,68 @@
+// Shared device helpers for libdpgp_hip (gfx950 / CDNA4 only: 64-wide wavefronts, MFMA 16x16x4 f32/f64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/dpgp.h"
+
+#define DPGP_WAVE 64
+#define DPGP_TB 16            // MFMA tile edge (v_mfma_*_16x16x4_*)
+#define DPGP_LOG2E 1.4426950408889634074
+#define DPGP_LOG_2PI 1.8378770664093454835606594728112
+
+static inline int dpgp_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int dpgp_round_up(int a, int b) { return dpgp_ceil_div(a, b) * b; }
+static inline size_t dpgp_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+#define DPGP_LAUNCH_CHECK()                                 \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return DPGP_ERR_LAUNCH; \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// One 16x16x4 matrix-core step D = A(16x4) * B(4x16) + C for one wavefront.
+//   A operand: lane l holds A[i = l & 15][k = l >> 4];  B operand: lane l holds B[k = l >> 4][j = l & 15].
+//   C/D: 4 values per lane, column j = l & 15, row given by Mfma<T>::row(l, r)   (f32 and f64 differ!).
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return ((lane >> 4) << 2) + r; }
+};
+template <> struct Mfma<double> {
+    typedef f64x4 acc_t;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + (r << 2); }
+};
+
+// base-2 exponential: fp32 -> the bare v_exp_f32 (results below 2^-126 flush to 0, which is what a sum of such terms
+// next to O(1) terms needs); fp64 -> device-library exp2.
+__device__ __forceinline__ float dpgp_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ double dpgp_exp2(double x) { return exp2(x); }
+__device__ __forceinline__ float dpgp_log(float x) { return logf(x); }
+__device__ __forceinline__ double dpgp_log(double x) { return log(x); }
+
+// Wavefront (64 lanes) sum.
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Workgroup sum through LDS (scratch: >= blockDim.x/64 elements). Result valid in every thread.
+template <typename T> __device__ __forceinline__ T block_sum(T v, T *scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    T t = 0;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}

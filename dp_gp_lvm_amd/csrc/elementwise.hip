@@ -1,0 +1,479 @@
+// ARD-RBF gram / diag / psi0 / psi1 / Psi1^T y / KL kernels (HBM- or exp-bound, no matrix cores needed).
+// Reference semantics: /root/reference/src/kernels/rbf_kernel.py:58-161, src/models/expressions/gp_expressions.py:10-24.
+#include "internal.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1  gram: out[b, i, j] = alpha_b exp(-1/2 sum_q gamma_bq (x0_iq - x1_jq)^2)  (+ noise/jitter on the diagonal)
+//   one 256-thread workgroup per 64x64 output tile; both input tiles are staged through LDS pre-scaled by
+//   sqrt(gamma_b) (so the inner loop is sub+fma per q); each thread owns a 4x4 patch whose rows are written as one
+//   16-byte (fp32) / 32-byte (fp64) store -> 256 B contiguous per 16 lanes.
+// ---------------------------------------------------------------------------------------------------------------
+#define GRAM_T 64
+template <typename TIN, typename T>
+__global__ __launch_bounds__(256) void gram_kernel(int N0, int N1, int Q, const TIN *__restrict__ x0,
+                                                   const TIN *__restrict__ x1, const TIN *__restrict__ gamma,
+                                                   const TIN *__restrict__ alpha, const TIN *__restrict__ beta,
+                                                   int flags, T jitter, T *__restrict__ out, int ld_out,
+                                                   size_t batch_stride, int symmetric) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *xs = reinterpret_cast<T *>(smem_raw);          // [64][Q+1]
+    T *zs = xs + GRAM_T * (Q + 1);                     // [64][Q+1]
+    const int b = blockIdx.z, i0 = blockIdx.y * GRAM_T, j0 = blockIdx.x * GRAM_T;
+    const int t = threadIdx.x;
+    const TIN *g = gamma + (size_t)b * Q;
+    for (int e = t; e < GRAM_T * Q; e += 256) {
+        int r = e / Q, q = e - r * Q;
+        T sg = sqrt((T)g[q]);
+        xs[r * (Q + 1) + q] = (i0 + r < N0) ? sg * (T)x0[(size_t)(i0 + r) * Q + q] : (T)0;
+        zs[r * (Q + 1) + q] = (j0 + r < N1) ? sg * (T)x1[(size_t)(j0 + r) * Q + q] : (T)0;
+    }
+    __syncthreads();
+    const int ty = t >> 4, tx = t & 15;
+    T acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+    for (int q = 0; q < Q; ++q) {
+        T a[4], c_[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = xs[(ty * 4 + r) * (Q + 1) + q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) c_[c] = zs[(tx * 4 + c) * (Q + 1) + q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                T d = a[r] - c_[c];
+                acc[r][c] = fma(d, d, acc[r][c]);
+            }
+    }
+    const T al = (T)alpha[b];
+    T diag_add = 0;
+    if (symmetric) {
+        if (flags & DPGP_FLAG_NOISE) diag_add += (T)1 / (T)beta[b];
+        if (flags & DPGP_FLAG_JITTER) diag_add += jitter;
+    }
+    const T scale = (T)(-0.5 * DPGP_LOG2E);
+    T *ob = out + (size_t)b * batch_stride;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int i = i0 + ty * 4 + r;
+        if (i >= N0) continue;
+        T v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int j = j0 + tx * 4 + c;
+            v[c] = al * dpgp_exp2(scale * acc[r][c]);
+            if (symmetric && i == j) v[c] += diag_add;
+        }
+        int j = j0 + tx * 4;
+        T *p = ob + (size_t)i * ld_out + j;
+        if (j + 3 < N1 && ((ld_out & 3) == 0)) {
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            vec4 vv = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<vec4 *>(p) = vv;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (j + c < N1) p[c] = v[c];
+        }
+    }
+}
+
+template <typename TIN, typename T>
+int launch_gram(int B, int N0, int N1, int Q, const TIN *x0, const TIN *x1, const TIN *gamma, const TIN *alpha,
+                const TIN *beta, int flags, double jitter, T *out, int ld_out, size_t batch_stride, hipStream_t st) {
+    const int sym = (x1 == nullptr);
+    if (sym) { x1 = x0; N1 = N0; }
+    dim3 grid(dpgp_ceil_div(N1, GRAM_T), dpgp_ceil_div(N0, GRAM_T), B);
+    size_t lds = sizeof(T) * 2 * GRAM_T * (Q + 1);
+    hipLaunchKernelGGL((gram_kernel<TIN, T>), grid, dim3(256), lds, st, N0, N1, Q, x0, x1, gamma, alpha, beta, flags,
+                       (T)jitter, out, ld_out, batch_stride, sym);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+template int launch_gram<float, float>(int, int, int, int, const float *, const float *, const float *, const float *,
+                                       const float *, int, double, float *, int, size_t, hipStream_t);
+template int launch_gram<double, double>(int, int, int, int, const double *, const double *, const double *,
+                                         const double *, const double *, int, double, double *, int, size_t,
+                                         hipStream_t);
+template int launch_gram<double, float>(int, int, int, int, const double *, const double *, const double *,
+                                        const double *, const double *, int, double, float *, int, size_t,
+                                        hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// diag / psi0: trivial broadcasts (rbf_kernel.py:96-132)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void diag_kernel(int B, int N, const T *alpha, const T *beta, int flags, T jitter, T *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    int b = (int)(i / N);
+    T v = alpha[b];
+    if (flags & DPGP_FLAG_NOISE) v += (T)1 / beta[b];
+    if (flags & DPGP_FLAG_JITTER) v += jitter;
+    out[i] = v;
+}
+template <typename T> __global__ void psi0_kernel(int B, int N, const T *alpha, T *out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = alpha[b] * (T)N;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2  psi1 materialised: out[b,n,m] = alpha_b exp(-1/2 sum_q( g (mu_nq - z_mq)^2 / (g s_nq + 1) + log(g s_nq + 1) ))
+//   workgroup = (b, 32 rows n); per-row factors w = g/(g s+1) and c = -1/2 sum log(g s+1) are computed once into LDS;
+//   z is staged through LDS in chunks of 64 rows; thread = (row, 4 consecutive m) -> 16-byte stores.
+// ---------------------------------------------------------------------------------------------------------------
+#define PSI1_NT 32
+template <typename T>
+__global__ __launch_bounds__(256) void psi1_kernel(int N, int M, int Q, const T *__restrict__ z,
+                                                   const T *__restrict__ mu, const T *__restrict__ s,
+                                                   const T *__restrict__ gamma, const T *__restrict__ alpha,
+                                                   T *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *w = reinterpret_cast<T *>(smem_raw);   // [32][Q]
+    T *mus = w + PSI1_NT * Q;                  // [32][Q]
+    T *cn = mus + PSI1_NT * Q;                 // [32]
+    T *zs = cn + PSI1_NT;                      // [64][Q+1]
+    const int b = blockIdx.y, n0 = blockIdx.x * PSI1_NT, t = threadIdx.x;
+    const T *g = gamma + (size_t)b * Q;
+    for (int e = t; e < PSI1_NT * Q; e += 256) {
+        int r = e / Q, q = e - r * Q, n = n0 + r;
+        T sv = n < N ? s[(size_t)n * Q + q] : (T)1, mv = n < N ? mu[(size_t)n * Q + q] : (T)0;
+        T den = g[q] * sv + (T)1;
+        w[e] = g[q] / den;
+        mus[e] = mv;
+    }
+    if (t < PSI1_NT) {
+        int n = n0 + t;
+        T a = 0;
+        for (int q = 0; q < Q; ++q) a += dpgp_log(g[q] * (n < N ? s[(size_t)n * Q + q] : (T)1) + (T)1);
+        cn[t] = (T)(-0.5 * DPGP_LOG2E) * a;
+    }
+    const T al = alpha[b];
+    const int r = t >> 3, c8 = t & 7;   // 32 rows x 8 threads; each thread 2 groups of 4 consecutive m per 64-chunk
+    const int n = n0 + r;
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        __syncthreads();
+        for (int e = t; e < 64 * Q; e += 256) {
+            int rr = e / Q, q = e - rr * Q;
+            zs[rr * (Q + 1) + q] = (m0 + rr < M) ? z[(size_t)(m0 + rr) * Q + q] : (T)0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int mb = (h * 8 + c8) * 4;
+            T acc[4] = {0, 0, 0, 0};
+            for (int q = 0; q < Q; ++q) {
+                T wq = w[r * Q + q], mq = mus[r * Q + q];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    T d = mq - zs[(mb + c) * (Q + 1) + q];
+                    acc[c] = fma(wq * d, d, acc[c]);
+                }
+            }
+            if (n < N) {
+                T *p = out + ((size_t)b * N + n) * M + m0 + mb;
+                T v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = al * dpgp_exp2((T)(-0.5 * DPGP_LOG2E) * acc[c] + cn[r]);
+                if (m0 + mb + 3 < M && ((M & 3) == 0)) {
+                    typedef T vec4 __attribute__((ext_vector_type(4)));
+                    vec4 vv = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<vec4 *>(p) = vv;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (m0 + mb + c < M) p[c] = v[c];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2f  Psi1^T y (fused reduction over n, Psi1 never written):  part[ns][b][m] = alpha_b sum_{n in chunk} y_nb psi1[b,n,m]
+//   grid (ns, ceil(M/128), B), 256 threads = 4 waves; a wave takes every 4th n of the tile, a lane owns m = lane and
+//   m = lane + 64 of the 128-chunk with their z rows in registers; per-n factors go through LDS.
+// ---------------------------------------------------------------------------------------------------------------
+#define P1Y_NT 32
+template <typename TIN, typename T>
+__global__ __launch_bounds__(256) void psi1T_y_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                                      const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                                      const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
+                                                      const TIN *__restrict__ y, int ldy, double *__restrict__ part,
+                                                      int n_per_split) {
+    __shared__ T w[P1Y_NT][DPGP_MAX_Q + 2];
+    __shared__ T mus[P1Y_NT][DPGP_MAX_Q + 2];
+    __shared__ T cn[P1Y_NT], yn[P1Y_NT];
+    __shared__ double red[4][128];
+    const int b = blockIdx.z, mc = blockIdx.y * 128, sp = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const TIN *g = gamma + (size_t)b * Q;
+    T zr[2][DPGP_MAX_Q];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int m = mc + lane + 64 * h;
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q) zr[h][q] = (q < Q && m < M) ? (T)z[(size_t)m * Q + q] : (T)0;
+    }
+    double acc[2] = {0.0, 0.0};
+    const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    for (int n0 = nbeg; n0 < nend; n0 += P1Y_NT) {
+        __syncthreads();
+        for (int e = t; e < P1Y_NT * Q; e += 256) {
+            int r = e / Q, q = e - r * Q, n = n0 + r;
+            bool ok = n < nend;
+            T sv = ok ? (T)s[(size_t)n * Q + q] : (T)1;
+            T den = (T)g[q] * sv + (T)1;
+            w[r][q] = (T)(-0.5 * DPGP_LOG2E) * (T)g[q] / den;
+            mus[r][q] = ok ? (T)mu[(size_t)n * Q + q] : (T)0;
+        }
+        if (t < P1Y_NT) {
+            int n = n0 + t;
+            bool ok = n < nend;
+            T a = 0;
+            for (int q = 0; q < Q; ++q) a += dpgp_log((T)g[q] * (ok ? (T)s[(size_t)n * Q + q] : (T)1) + (T)1);
+            cn[t] = (T)(-0.5 * DPGP_LOG2E) * a;
+            yn[t] = ok ? (T)y[(size_t)n * ldy + b] : (T)0;
+        }
+        __syncthreads();
+        T tacc[2] = {0, 0};
+        for (int r = wv; r < P1Y_NT; r += 4) {
+            T e0 = cn[r], e1 = cn[r];
+#pragma unroll
+            for (int q = 0; q < DPGP_MAX_Q; ++q) {
+                if (q < Q) {
+                    T wq = w[r][q], mq = mus[r][q];
+                    T d0 = mq - zr[0][q], d1 = mq - zr[1][q];
+                    e0 = fma(wq * d0, d0, e0);
+                    e1 = fma(wq * d1, d1, e1);
+                }
+            }
+            tacc[0] = fma(yn[r], dpgp_exp2(e0), tacc[0]);
+            tacc[1] = fma(yn[r], dpgp_exp2(e1), tacc[1]);
+        }
+        acc[0] += (double)tacc[0];
+        acc[1] += (double)tacc[1];
+    }
+    __syncthreads();
+    red[wv][lane] = acc[0];
+    red[wv][lane + 64] = acc[1];
+    __syncthreads();
+    if (t < 128 && mc + t < M) {
+        double v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        part[((size_t)sp * B + b) * M + mc + t] = (double)alpha[b] * v;
+    }
+}
+
+int psi1T_y_nsplit(int B, int N, int M) {
+    int wgs = B * dpgp_ceil_div(M, 128);
+    int ns = dpgp_ceil_div(1024, wgs);          // aim for >= ~4 workgroups per CU
+    int max_ns = dpgp_ceil_div(N, 4 * P1Y_NT);
+    if (ns > max_ns) ns = max_ns;
+    return ns < 1 ? 1 : ns;
+}
+
+template <typename TIN, typename T>
+int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                           const TIN *alpha, const TIN *y, int ldy, double *part, int ns, hipStream_t st) {
+    int nper = dpgp_round_up(dpgp_ceil_div(N, ns), P1Y_NT);
+    dim3 grid(ns, dpgp_ceil_div(M, 128), B);
+    hipLaunchKernelGGL((psi1T_y_kernel<TIN, T>), grid, dim3(256), 0, st, N, M, Q, B, z, mu, s, gamma, alpha, y, ldy,
+                       part, nper);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+template int launch_psi1T_y_partial<float, float>(int, int, int, int, const float *, const float *, const float *,
+                                                  const float *, const float *, const float *, int, double *, int,
+                                                  hipStream_t);
+template int launch_psi1T_y_partial<double, double>(int, int, int, int, const double *, const double *, const double *,
+                                                    const double *, const double *, const double *, int, double *, int,
+                                                    hipStream_t);
+template int launch_psi1T_y_partial<double, float>(int, int, int, int, const double *, const double *, const double *,
+                                                   const double *, const double *, const double *, int, double *, int,
+                                                   hipStream_t);
+
+template <typename T>
+__global__ void sum_slabs_kernel(size_t n, int ns, const double *__restrict__ part, T *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0;
+    for (int k = 0; k < ns; ++k) a += part[(size_t)k * n + i];
+    out[i] = (T)a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// KL(q(X) || N(0,I)) (gp_expressions.py:18-23) and, in the same launch, y_d^T y_d for the data-fit term
+// (dp_gp_lvm.py:143-144; the reference forms the whole [D,D] product and takes its diagonal).
+//   block 0            : KL  -> kl_out[0]
+//   blocks 1 .. 1+D/64 : yy[d] for 64 consecutive d (coalesced along d, 4 waves stride over n)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__restrict__ mu,
+                                                    const TIN *__restrict__ s, double *__restrict__ kl_out, int D,
+                                                    const TIN *__restrict__ y, int ldy, double *__restrict__ yy_out) {
+    __shared__ double scratch[4][64];
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (kl_out == nullptr) return;
+        double a = 0.0;
+        size_t tot = (size_t)N * Q;
+        for (size_t i = t; i < tot; i += 256) {
+            double m = (double)mu[i], v = (double)s[i];
+            a += m * m + v - log(v);
+        }
+        a = block_sum(a, &scratch[0][0]);
+        if (t == 0) kl_out[0] = 0.5 * (a - (double)N * (double)Q);
+        return;
+    }
+    const int d = (blockIdx.x - 1) * 64 + (t & 63), wv = t >> 6;
+    double a = 0.0;
+    if (d < D)
+        for (int n = wv; n < N; n += 4) {
+            double v = (double)y[(size_t)n * ldy + d];
+            a += v * v;
+        }
+    scratch[wv][t & 63] = a;
+    __syncthreads();
+    if (t < 64 && d < D) yy_out[d] = scratch[0][t] + scratch[1][t] + scratch[2][t] + scratch[3][t];
+}
+
+template <typename TIN>
+int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
+                 double *yy_out, hipStream_t st) {
+    int blocks = 1 + (yy_out ? dpgp_ceil_div(D, 64) : 0);
+    hipLaunchKernelGGL((kl_yy_kernel<TIN>), dim3(blocks), dim3(256), 0, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+template int launch_kl_yy<float>(int, int, const float *, const float *, double *, int, const float *, int, double *,
+                                 hipStream_t);
+template int launch_kl_yy<double>(int, int, const double *, const double *, double *, int, const double *, int,
+                                  double *, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+#define CHECK_ARG(cond, idx) \
+    do {                     \
+        if (!(cond)) return -(idx); \
+    } while (0)
+
+template <typename T>
+static int gram_api(int B, int N0, int N1, int Q, const T *x0, const T *x1, const T *gamma, const T *alpha,
+                    const T *beta, int flags, double jitter, T *out, void *stream) {
+    CHECK_ARG(B > 0, 1); CHECK_ARG(N0 > 0, 2); CHECK_ARG(x1 == nullptr || N1 > 0, 3);
+    CHECK_ARG(Q > 0 && Q <= DPGP_MAX_Q, 4); CHECK_ARG(x0, 5); CHECK_ARG(gamma, 7); CHECK_ARG(alpha, 8);
+    CHECK_ARG(beta || !(flags & DPGP_FLAG_NOISE), 9); CHECK_ARG(out, 12);
+    int n1 = x1 ? N1 : N0;
+    return launch_gram<T, T>(B, N0, n1, Q, x0, x1, gamma, alpha, beta, flags, jitter, out, n1, (size_t)N0 * n1,
+                             (hipStream_t)stream);
+}
+extern "C" int dpgp_ard_rbf_gram_f32(int B, int N0, int N1, int Q, const float *x0, const float *x1, const float *gamma,
+                                     const float *alpha, const float *beta, int flags, double jitter, float *out,
+                                     void *stream) {
+    return gram_api<float>(B, N0, N1, Q, x0, x1, gamma, alpha, beta, flags, jitter, out, stream);
+}
+extern "C" int dpgp_ard_rbf_gram_f64(int B, int N0, int N1, int Q, const double *x0, const double *x1,
+                                     const double *gamma, const double *alpha, const double *beta, int flags,
+                                     double jitter, double *out, void *stream) {
+    return gram_api<double>(B, N0, N1, Q, x0, x1, gamma, alpha, beta, flags, jitter, out, stream);
+}
+
+template <typename T>
+static int diag_api(int B, int N, const T *alpha, const T *beta, int flags, double jitter, T *out, void *stream) {
+    CHECK_ARG(B > 0, 1); CHECK_ARG(N > 0, 2); CHECK_ARG(alpha, 3); CHECK_ARG(beta || !(flags & DPGP_FLAG_NOISE), 4);
+    CHECK_ARG(out, 7);
+    size_t tot = (size_t)B * N;
+    hipLaunchKernelGGL((diag_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
+                       alpha, beta, flags, (T)jitter, out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+extern "C" int dpgp_ard_rbf_diag_f32(int B, int N, const float *alpha, const float *beta, int flags, double jitter,
+                                     float *out, void *stream) {
+    return diag_api<float>(B, N, alpha, beta, flags, jitter, out, stream);
+}
+extern "C" int dpgp_ard_rbf_diag_f64(int B, int N, const double *alpha, const double *beta, int flags, double jitter,
+                                     double *out, void *stream) {
+    return diag_api<double>(B, N, alpha, beta, flags, jitter, out, stream);
+}
+
+template <typename T> static int psi0_api(int B, int N, const T *alpha, T *out, void *stream) {
+    CHECK_ARG(B > 0, 1); CHECK_ARG(N > 0, 2); CHECK_ARG(alpha, 3); CHECK_ARG(out, 4);
+    hipLaunchKernelGGL((psi0_kernel<T>), dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, N, alpha, out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+extern "C" int dpgp_psi0_f32(int B, int N, const float *alpha, float *out, void *stream) {
+    return psi0_api<float>(B, N, alpha, out, stream);
+}
+extern "C" int dpgp_psi0_f64(int B, int N, const double *alpha, double *out, void *stream) {
+    return psi0_api<double>(B, N, alpha, out, stream);
+}
+
+template <typename T>
+static int psi1_api(int B, int N, int M, int Q, const T *z, const T *mu, const T *s, const T *gamma, const T *alpha,
+                    T *out, void *stream) {
+    CHECK_ARG(B > 0, 1); CHECK_ARG(N > 0, 2); CHECK_ARG(M > 0, 3); CHECK_ARG(Q > 0 && Q <= DPGP_MAX_Q, 4);
+    CHECK_ARG(z, 5); CHECK_ARG(mu, 6); CHECK_ARG(s, 7); CHECK_ARG(gamma, 8); CHECK_ARG(alpha, 9); CHECK_ARG(out, 10);
+    size_t lds = sizeof(T) * (2 * PSI1_NT * Q + PSI1_NT + 64 * (Q + 1));
+    hipLaunchKernelGGL((psi1_kernel<T>), dim3(dpgp_ceil_div(N, PSI1_NT), B), dim3(256), lds, (hipStream_t)stream, N, M,
+                       Q, z, mu, s, gamma, alpha, out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+extern "C" int dpgp_psi1_f32(int B, int N, int M, int Q, const float *z, const float *mu, const float *s,
+                             const float *gamma, const float *alpha, float *out, void *stream) {
+    return psi1_api<float>(B, N, M, Q, z, mu, s, gamma, alpha, out, stream);
+}
+extern "C" int dpgp_psi1_f64(int B, int N, int M, int Q, const double *z, const double *mu, const double *s,
+                             const double *gamma, const double *alpha, double *out, void *stream) {
+    return psi1_api<double>(B, N, M, Q, z, mu, s, gamma, alpha, out, stream);
+}
+
+extern "C" size_t dpgp_psi1T_y_workspace_bytes(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return dpgp_align256(sizeof(double) * (size_t)psi1T_y_nsplit(B, N, M) * B * M);
+}
+template <typename T>
+static int psi1T_y_api(int B, int N, int M, int Q, const T *z, const T *mu, const T *s, const T *gamma, const T *alpha,
+                       const T *y, int ldy, T *out, void *ws, size_t ws_bytes, void *stream) {
+    CHECK_ARG(B > 0, 1); CHECK_ARG(N > 0, 2); CHECK_ARG(M > 0, 3); CHECK_ARG(Q > 0 && Q <= DPGP_MAX_Q, 4);
+    CHECK_ARG(z, 5); CHECK_ARG(mu, 6); CHECK_ARG(s, 7); CHECK_ARG(gamma, 8); CHECK_ARG(alpha, 9); CHECK_ARG(y, 10);
+    CHECK_ARG(ldy >= B, 11); CHECK_ARG(out, 12); CHECK_ARG(ws, 13);
+    CHECK_ARG(ws_bytes >= dpgp_psi1T_y_workspace_bytes(B, N, M), 14);
+    int ns = psi1T_y_nsplit(B, N, M);
+    int rc = launch_psi1T_y_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, (double *)ws, ns,
+                                          (hipStream_t)stream);
+    if (rc) return rc;
+    size_t tot = (size_t)B * M;
+    hipLaunchKernelGGL((sum_slabs_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       tot, ns, (const double *)ws, out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+extern "C" int dpgp_psi1T_y_f32(int B, int N, int M, int Q, const float *z, const float *mu, const float *s,
+                                const float *gamma, const float *alpha, const float *y, int ldy, float *out, void *ws,
+                                size_t ws_bytes, void *stream) {
+    return psi1T_y_api<float>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, out, ws, ws_bytes, stream);
+}
+extern "C" int dpgp_psi1T_y_f64(int B, int N, int M, int Q, const double *z, const double *mu, const double *s,
+                                const double *gamma, const double *alpha, const double *y, int ldy, double *out,
+                                void *ws, size_t ws_bytes, void *stream) {
+    return psi1T_y_api<double>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, out, ws, ws_bytes, stream);
+}
+
+template <typename T> static int kl_api(int N, int Q, const T *mu, const T *s, double *out, void *stream) {
+    CHECK_ARG(N > 0, 1); CHECK_ARG(Q > 0, 2); CHECK_ARG(mu, 3); CHECK_ARG(s, 4); CHECK_ARG(out, 5);
+    return launch_kl_yy<T>(N, Q, mu, s, out, 0, nullptr, 0, nullptr, (hipStream_t)stream);
+}
+extern "C" int dpgp_kl_qx_f32(int N, int Q, const float *mu, const float *s, double *out, void *stream) {
+    return kl_api<float>(N, Q, mu, s, out, stream);
+}
+extern "C" int dpgp_kl_qx_f64(int N, int Q, const double *mu, const double *s, double *out, void *stream) {
+    return kl_api<double>(N, Q, mu, s, out, stream);
+}
+extern "C" int dpgp_version(void) { return 100; }

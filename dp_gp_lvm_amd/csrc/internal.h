@@ -1,0 +1,37 @@
+// Internal launch functions shared between the translation units of libdpgp_hip (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+// ---- elementwise.hip -------------------------------------------------------------------------------------------
+// gram with explicit output leading dimension / batch stride so the fused ELBO can write straight into its padded
+// Cholesky workspace.  x1 == nullptr: symmetric case, noise/jitter flags honoured.
+template <typename TIN, typename T>
+int launch_gram(int B, int N0, int N1, int Q, const TIN *x0, const TIN *x1, const TIN *gamma, const TIN *alpha,
+                const TIN *beta, int flags, double jitter, T *out, int ld_out, size_t batch_stride, hipStream_t st);
+
+// partial Psi1^T y slabs: part[ns][B][M] (fp64), ns = psi1T_y_nsplit(B, N, M)
+int psi1T_y_nsplit(int B, int N, int M);
+template <typename TIN, typename T>
+int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                           const TIN *alpha, const TIN *y, int ldy, double *part, int ns, hipStream_t st);
+
+template <typename TIN>
+int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
+                 double *yy_out, hipStream_t st);
+
+// ---- psi2.hip --------------------------------------------------------------------------------------------------
+// partial Psi2 slabs: part[ns][B][Mp][Mp] (type T), Mp = round_up(M,16); only the lower block-triangle (16x16 tiles,
+// J <= I) is written; entries with row/col >= M are zero.  ns = psi2_nsplit(B, N, M).
+int psi2_nsplit(int B, int N, int M);
+template <typename TIN, typename T>
+int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                        const TIN *alpha, T *part, int ns, int algo, hipStream_t st);
+
+// ---- linalg.hip ------------------------------------------------------------------------------------------------
+// per-d workspace of the fused Cholesky chain, in elements of TL
+size_t la_chain_ws_elems(int M);
+template <typename TP, typename TL>
+int launch_la_chain(int D, int N, int M, TL *kuu_ws /* gram already written, see linalg.hip */, const TP *psi2_part,
+                    int ns2, const double *v_part, int ns1, const double *alpha, const double *beta,
+                    const double *yy, double *terms, int *info, TL *ws, int algo, hipStream_t st);
+int launch_sum_terms(int D, const double *terms, double *sums, hipStream_t st);

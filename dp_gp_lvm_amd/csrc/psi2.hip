@@ -1,0 +1,418 @@
+// K3  psi2 statistic, streamed over n on the matrix cores.
+// Reference: /root/reference/src/kernels/rbf_kernel.py:164-199 (materialises [B,N,M,M,Q]; here nothing larger than the
+// [B,M,M] result ever exists).
+//
+// Algebra (per batch entry b; den = 2 g s_n + 1, w = g/den, everything in log2 units, z centred by its column mean c):
+//   log2 psi2[n,m,m'] = 2 log2 alpha + beta_mm' + P[n,m] + P[n,m'] + sum_q X[n,q] z_mq z_m'q
+//     X[n,q]   = -1/2 w_nq log2e
+//     P[n,m]   = log2e * sum_q ( 1/2 w_nq (mu_nq-c_q)^2 - 1/4 log den_nq - 1/4 w_nq (z_mq - 2 (mu_nq-c_q))^2 )
+//     beta_mm' = -1/4 log2e sum_q g_q (z_mq - z_m'q)^2                 (n-independent: applied once, at the end)
+//   so for every n the [m,m'] block of exponents is ONE small GEMM  E_n = A_n B_n  with K = Q+2:
+//     A_n[m, 0:Q] = X[n,:] * z[m,:],  A_n[m,Q] = P[n,m],  A_n[m,Q+1] = 1
+//     B_n[0:Q,m'] = z[m',:]^T,        B_n[Q,m'] = 1,      B_n[Q+1,m'] = P[n,m']
+//   evaluated with v_mfma_{f32,f64}_16x16x4; then psi2[m,m'] += exp2(E_n[m,m']) element-wise in registers.
+//   (identical to the reference formula: tests/test_psi2.py checks against the literal oracle)
+//
+// Decomposition: workgroup = (patch of the lower triangle, b, n-split); patch = PT x PT tiles of 16x16 (64x64 fp32,
+// 32x32 fp64); the 4 waves of a workgroup work on the SAME patch and split the n of every 32-row tile 4 ways
+// (identical work per wave, z operands shared), their accumulators are summed through LDS at the end.
+// Output: partial slabs part[split][b][Mp][Mp], lower block-triangle of 16x16 tiles only.
+#include "internal.h"
+
+#define PSI2_NT 32   // n per LDS tile
+
+__device__ __forceinline__ void patch_from_index(int p, int &pi, int &pj) {
+    int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+    while ((i + 1) * (i + 2) / 2 <= p) ++i;
+    while (i * (i + 1) / 2 > p) --i;
+    pi = i;
+    pj = p - i * (i + 1) / 2;
+}
+
+// DIAG is a compile-time property of the patch (pi == pj: only tiles J <= I are computed) so that the MFMA / exp
+// sequences are straight-line code.  (With a run-time `diag` predicate around each MFMA, hipcc 7.2 shuffled the
+// accumulators through AGPRs and overwrote a SrcC register of an in-flight v_mfma_f32_16x16x4_f32 with
+// v_accvgpr_write_b32 with no wait states in between: one register of one tile came out wrong on the GPU.)
+template <typename TIN, typename T, int KS, int PT, bool DIAG>
+__device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                           const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                           const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
+                                           T *__restrict__ part, int Mp, int n_per_split, int pi, int pj,
+                                           unsigned char *smem_raw) {
+    constexpr int PS = 16 * PT;        // patch edge
+    constexpr int KP = 4 * KS;         // padded K
+    constexpr int PLD = 2 * PS + 4;    // row stride of the P tile (breaks the power-of-two stride)
+    typedef typename Mfma<T>::acc_t acc_t;
+    T *zs = reinterpret_cast<T *>(smem_raw);        // [2*PS][KP+1] centred z rows: m-block then m'-block (0 beyond Q / M)
+    T *xa = zs + 2 * PS * (KP + 1);                  // [NT][KP]     X[n,k] (0 for k >= Q)
+    T *pm = xa + PSI2_NT * KP;                       // [NT][PLD]    P[n, m-block | m'-block]
+    T *w4 = pm + PSI2_NT * PLD;                      // [NT][Q]      1/4 w log2e
+    T *tm = w4 + PSI2_NT * DPGP_MAX_Q;               // [NT][Q]      2 (mu - c)
+    T *cn = tm + PSI2_NT * DPGP_MAX_Q;               // [NT][Q]      (1/2 w (mu-c)^2 - 1/4 log den) log2e
+    T *zc = cn + PSI2_NT * DPGP_MAX_Q;               // [Q]          column means of z
+    T *gq = zc + DPGP_MAX_Q + 2;                     // [Q]          gamma_b
+    // the cross-wave reduction at the end reuses the buffer from `xa` on: 4 waves * PT tiles * 4 regs * 64 lanes
+
+    const int b = blockIdx.y, sp = blockIdx.z;
+    constexpr bool diag = DIAG;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
+    const int m_base = pi * PS, mp_base = pj * PS;
+
+    // ---- prologue: gamma_b, z column means, centred z rows of both blocks -----------------------------------
+    if (t < Q) {
+        gq[t] = (T)gamma[(size_t)b * Q + t];
+        double a = 0.0;
+        for (int m = 0; m < M; ++m) a += (double)z[(size_t)m * Q + t];
+        zc[t] = (T)(a / (double)M);
+    }
+    __syncthreads();
+    for (int e = t; e < 2 * PS * (KP + 1); e += 256) {
+        int r = e / (KP + 1), k = e - r * (KP + 1);
+        int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
+        zs[e] = (k < Q && m < M) ? (T)z[(size_t)m * Q + k] - zc[k] : (T)0;
+    }
+    for (int e = t; e < PSI2_NT * KP; e += 256) xa[e] = (T)0;
+    __syncthreads();
+
+    // ---- per-lane constant MFMA operands ---------------------------------------------------------------------
+    // A side (rows m of tile I): z value for k < Q, else 0;  B side (cols m' of tile J): z value for k < Q, 1 for k == Q.
+    T zA[PT][KS], zB[PT][KS];
+    T cPa[KS], c1a[KS], cPb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + kk;
+        cPa[ks] = (k == Q) ? (T)1 : (T)0;
+        c1a[ks] = (k == Q + 1) ? (T)1 : (T)0;
+        cPb[ks] = (k == Q + 1) ? (T)1 : (T)0;
+#pragma unroll
+        for (int I = 0; I < PT; ++I) {
+            zA[I][ks] = zs[(16 * I + li) * (KP + 1) + k];                    // already 0 for k >= Q
+            zB[I][ks] = (k == Q) ? (T)1 : zs[(PS + 16 * I + li) * (KP + 1) + k];
+        }
+    }
+
+    acc_t acc[PT][PT];
+#pragma unroll
+    for (int I = 0; I < PT; ++I)
+#pragma unroll
+        for (int J = 0; J < PT; ++J) acc[I][J] = (acc_t){0, 0, 0, 0};
+
+    const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    const int pcols = diag ? PS : 2 * PS;
+    const int pb_off = diag ? 0 : PS;
+
+    for (int n0 = nbeg; n0 < nend; n0 += PSI2_NT) {
+        __syncthreads();   // previous tile's readers are done with xa/pm/w4/tm/cn
+        // phase 1: per-(n,q) factors
+        for (int e = t; e < PSI2_NT * Q; e += 256) {
+            const int r = e / Q, q = e - r * Q, n = n0 + r;
+            if (n < nend) {
+                const T g = gq[q];
+                const T sv = (T)s[(size_t)n * Q + q];
+                const T mc = (T)mu[(size_t)n * Q + q] - zc[q];
+                const T den = (T)2 * g * sv + (T)1;
+                const T w = g / den;
+                xa[r * KP + q] = (T)(-0.5 * DPGP_LOG2E) * w;
+                w4[r * DPGP_MAX_Q + q] = (T)(0.25 * DPGP_LOG2E) * w;
+                tm[r * DPGP_MAX_Q + q] = (T)2 * mc;
+                cn[r * DPGP_MAX_Q + q] = (T)DPGP_LOG2E * ((T)0.5 * w * mc * mc - (T)0.25 * dpgp_log(den));
+            } else {   // rows past the end of this split contribute exp2(-huge) = 0
+                xa[r * KP + q] = (T)0;
+                w4[r * DPGP_MAX_Q + q] = (T)0;
+                tm[r * DPGP_MAX_Q + q] = (T)0;
+                cn[r * DPGP_MAX_Q + q] = (T)-1.0e30;
+            }
+        }
+        __syncthreads();
+        // phase 2: P[n, m] for the rows of both blocks
+        for (int e = t; e < PSI2_NT * pcols; e += 256) {
+            const int r = e / pcols, c = e - r * pcols;
+            const T *zr = zs + c * (KP + 1);
+            T p = 0;
+            for (int q = 0; q < Q; ++q) {
+                const T d = zr[q] - tm[r * DPGP_MAX_Q + q];
+                p += cn[r * DPGP_MAX_Q + q] - w4[r * DPGP_MAX_Q + q] * d * d;
+            }
+            pm[r * PLD + c] = p;
+        }
+        __syncthreads();
+        // phase 3: each wave takes every 4th n of the tile
+        for (int r = wv; r < PSI2_NT; r += 4) {
+            T a[PT][KS], bq[PT][KS];
+            T xk[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xk[ks] = xa[r * KP + 4 * ks + kk];
+            T pa[PT], pb[PT];
+#pragma unroll
+            for (int I = 0; I < PT; ++I) {
+                pa[I] = pm[r * PLD + 16 * I + li];
+                pb[I] = pm[r * PLD + pb_off + 16 * I + li];
+            }
+#pragma unroll
+            for (int I = 0; I < PT; ++I)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks < KS - 2) {          // k < Q for certain: pure z steps
+                        a[I][ks] = zA[I][ks] * xk[ks];
+                        bq[I][ks] = zB[I][ks];
+                    } else {
+                        a[I][ks] = fma(zA[I][ks], xk[ks], fma(cPa[ks], pa[I], c1a[ks]));
+                        bq[I][ks] = fma(cPb[ks], pb[I], zB[I][ks]);
+                    }
+                }
+#pragma unroll
+            for (int I = 0; I < PT; ++I) {
+                acc_t c[PT];
+#pragma unroll
+                for (int J = 0; J < PT; ++J) c[J] = (acc_t){0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int J = 0; J < PT; ++J)
+                        if (!(diag && J > I)) c[J] = Mfma<T>::mma(a[I][ks], bq[J][ks], c[J]);
+#pragma unroll
+                for (int J = 0; J < PT; ++J)
+                    if (!(diag && J > I)) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[I][J][v] += dpgp_exp2(c[J][v]);
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue: sum the 4 waves' accumulators through LDS, apply alpha^2 exp2(beta_mm'), store the lower tiles ----
+    T *red = xa;   // [4 waves][PT][4][64]
+    const T al = (T)alpha[b];
+    const T al2 = al * al;
+    T *out = part + ((size_t)sp * B + b) * (size_t)Mp * Mp;
+#pragma unroll
+    for (int I = 0; I < PT; ++I) {
+        __syncthreads();
+#pragma unroll
+        for (int J = 0; J < PT; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[((wv * PT + J) * 4 + v) * 64 + lane] = acc[I][J][v];
+        __syncthreads();
+        for (int e = t; e < PT * 256; e += 256) {
+            const int J = e >> 8, v = (e >> 6) & 3, l = e & 63;
+            if (diag && J > I) continue;
+            T sum = 0;
+#pragma unroll
+            for (int w_ = 0; w_ < 4; ++w_) sum += red[((w_ * PT + J) * 4 + v) * 64 + l];
+            const int row = 16 * I + Mfma<T>::row(l, v), col = 16 * J + (l & 15);
+            const int m = m_base + row, mp = mp_base + col;
+            if (m < Mp && mp < Mp) {
+                T val = 0;
+                if (m < M && mp < M) {
+                    const T *z1 = zs + row * (KP + 1), *z2 = zs + (PS + col) * (KP + 1);
+                    T bsum = 0;
+                    for (int q = 0; q < Q; ++q) {
+                        const T d = z1[q] - z2[q];
+                        bsum += gq[q] * d * d;
+                    }
+                    val = al2 * sum * dpgp_exp2((T)(-0.25 * DPGP_LOG2E) * bsum);
+                }
+                out[(size_t)m * Mp + mp] = val;
+            }
+        }
+    }
+}
+
+template <typename TIN, typename T, int KS, int PT>
+__global__ __launch_bounds__(256) void psi2_mfma_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                                        const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                                        const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
+                                                        T *__restrict__ part, int Mp, int n_per_split) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    int pi, pj;
+    patch_from_index(blockIdx.x, pi, pj);
+    if (pi == pj)
+        psi2_patch<TIN, T, KS, PT, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, pi, pj, smem_raw);
+    else
+        psi2_patch<TIN, T, KS, PT, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, pi, pj, smem_raw);
+}
+
+// Plain-VALU variant (cross-check of the matrix-core kernel): thread per (m, m') of the lower block-triangle, literal
+// reference formula rbf_kernel.py:189-199 with the per-(n,q) factors staged through LDS.  Writes slab 0 only.
+template <typename TIN, typename T>
+__global__ __launch_bounds__(256) void psi2_plain_kernel(int N, int M, int Q, const TIN *__restrict__ z,
+                                                         const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                                         const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
+                                                         T *__restrict__ part, int Mp) {
+    __shared__ T w[PSI2_NT][DPGP_MAX_Q], mm[PSI2_NT][DPGP_MAX_Q], hl[PSI2_NT];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int e = blockIdx.x * 256 + t;
+    const int m = e / Mp, mp = e - m * Mp;
+    const bool active = (m < Mp) && ((mp >> 4) <= (m >> 4));
+    const bool real = active && m < M && mp < M;
+    T zb[DPGP_MAX_Q], t1 = 0;
+    const TIN *g = gamma + (size_t)b * Q;
+    for (int q = 0; q < Q; ++q) {
+        T z1 = real ? (T)z[(size_t)m * Q + q] : (T)0, z2 = real ? (T)z[(size_t)mp * Q + q] : (T)0;
+        zb[q] = (T)0.5 * (z1 + z2);
+        t1 += (T)0.25 * (T)g[q] * (z1 - z2) * (z1 - z2);
+    }
+    T acc = 0;
+    for (int n0 = 0; n0 < N; n0 += PSI2_NT) {
+        __syncthreads();
+        for (int i = t; i < PSI2_NT * Q; i += 256) {
+            int r = i / Q, q = i - r * Q, n = n0 + r;
+            T sv = n < N ? (T)s[(size_t)n * Q + q] : (T)1;
+            w[r][q] = (T)g[q] / ((T)2 * (T)g[q] * sv + (T)1);
+            mm[r][q] = n < N ? (T)mu[(size_t)n * Q + q] : (T)0;
+        }
+        if (t < PSI2_NT) {
+            int n = n0 + t;
+            T a = 0;
+            for (int q = 0; q < Q; ++q) a += dpgp_log((T)2 * (T)g[q] * (n < N ? (T)s[(size_t)n * Q + q] : (T)1) + (T)1);
+            hl[t] = (T)0.5 * a;
+        }
+        __syncthreads();
+        const int nn = min(PSI2_NT, N - n0);
+        for (int r = 0; r < nn; ++r) {
+            T ex = hl[r] + t1;
+            for (int q = 0; q < Q; ++q) {
+                T d = mm[r][q] - zb[q];
+                ex += w[r][q] * d * d;
+            }
+            acc += dpgp_exp2((T)(-DPGP_LOG2E) * ex);
+        }
+    }
+    if (active) {
+        T al = (T)alpha[b];
+        part[(size_t)b * Mp * Mp + (size_t)m * Mp + mp] = real ? al * al * acc : (T)0;
+    }
+}
+
+// slabs -> dense symmetric [B,M,M]
+template <typename T>
+__global__ void psi2_finish_kernel(int B, int M, int Mp, int ns, const T *__restrict__ part, T *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * M * M) return;
+    int b = (int)(i / ((size_t)M * M));
+    int r = (int)(i - (size_t)b * M * M);
+    int m = r / M, mp = r - m * M;
+    const int a = m > mp ? m : mp, c = m > mp ? mp : m;   // element-wise lower triangle: exactly symmetric output
+    double acc = 0.0;
+    for (int k = 0; k < ns; ++k) acc += (double)part[((size_t)k * B + b) * (size_t)Mp * Mp + (size_t)a * Mp + c];
+    out[i] = (T)acc;
+}
+
+template <typename T> struct Psi2Cfg;
+template <> struct Psi2Cfg<float> { static constexpr int PT = 4; };
+template <> struct Psi2Cfg<double> { static constexpr int PT = 2; };
+
+template <typename T> static size_t psi2_lds_bytes(int KS) {
+    constexpr int PT = Psi2Cfg<T>::PT, PS = 16 * PT, PLD = 2 * PS + 4;
+    const int KP = 4 * KS;
+    size_t fill = (size_t)2 * PS * (KP + 1) + (size_t)PSI2_NT * KP + (size_t)PSI2_NT * PLD +
+                  3 * (size_t)PSI2_NT * DPGP_MAX_Q + 2 * (DPGP_MAX_Q + 2);
+    size_t red = (size_t)2 * PS * (KP + 1) + (size_t)4 * PT * 4 * 64;
+    return sizeof(T) * (fill > red ? fill : red);
+}
+
+int psi2_nsplit(int B, int N, int M) {
+    // enough workgroups for >= 2 per CU (512); never fewer than 4 LDS tiles of n per split
+    int np64 = dpgp_ceil_div(M, 64);
+    int wgs = B * np64 * (np64 + 1) / 2;
+    int ns = dpgp_ceil_div(512, wgs);
+    int max_ns = dpgp_ceil_div(N, 4 * PSI2_NT);
+    if (ns > max_ns) ns = max_ns;
+    return ns < 1 ? 1 : ns;
+}
+
+template <typename TIN, typename T, int KS>
+static int launch_psi2_ks(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                          const TIN *alpha, T *part, int ns, hipStream_t st) {
+    constexpr int PT = Psi2Cfg<T>::PT, PS = 16 * PT;
+    const int Mp = dpgp_round_up(M, 16);
+    const int nps = dpgp_ceil_div(Mp, PS);
+    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
+    dim3 grid(nps * (nps + 1) / 2, B, ns);
+    size_t lds = psi2_lds_bytes<T>(KS);
+    auto kern = psi2_mfma_kernel<TIN, T, KS, PT>;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
+template <typename TIN, typename T>
+int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                        const TIN *alpha, T *part, int ns, int algo, hipStream_t st) {
+    const int Mp = dpgp_round_up(M, 16);
+    if (algo == DPGP_ALGO_PLAIN) {
+        // slabs 1.. are expected to exist by the consumer: zero them, slab 0 carries the result
+        if (ns > 1 && hipMemsetAsync(part + (size_t)B * Mp * Mp, 0, sizeof(T) * (size_t)(ns - 1) * B * Mp * Mp, st) !=
+                          hipSuccess)
+            return DPGP_ERR_LAUNCH;
+        dim3 grid(dpgp_ceil_div(Mp * Mp, 256), B);
+        hipLaunchKernelGGL((psi2_plain_kernel<TIN, T>), grid, dim3(256), 0, st, N, M, Q, z, mu, s, gamma, alpha, part,
+                           Mp);
+        DPGP_LAUNCH_CHECK();
+        return DPGP_OK;
+    }
+    const int KS = dpgp_ceil_div(Q + 2, 4);
+    switch (KS) {
+#define CASE(k) \
+    case k: return launch_psi2_ks<TIN, T, k>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, st);
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    return -4;
+}
+template int launch_psi2_partial<float, float>(int, int, int, int, const float *, const float *, const float *,
+                                               const float *, const float *, float *, int, int, hipStream_t);
+template int launch_psi2_partial<double, double>(int, int, int, int, const double *, const double *, const double *,
+                                                 const double *, const double *, double *, int, int, hipStream_t);
+template int launch_psi2_partial<double, float>(int, int, int, int, const double *, const double *, const double *,
+                                                const double *, const double *, float *, int, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t dpgp_psi2_workspace_bytes(int B, int N, int M, int Q, int elem_size) {
+    if (B <= 0 || N <= 0 || M <= 0 || Q <= 0) return 0;
+    int Mp = dpgp_round_up(M, 16);
+    return dpgp_align256((size_t)elem_size * psi2_nsplit(B, N, M) * B * Mp * Mp);
+}
+
+template <typename T>
+static int psi2_api(int B, int N, int M, int Q, const T *z, const T *mu, const T *s, const T *gamma, const T *alpha,
+                    T *out, void *ws, size_t ws_bytes, int algo, void *stream) {
+    if (B <= 0) return -1;
+    if (N <= 0) return -2;
+    if (M <= 0) return -3;
+    if (Q <= 0 || Q > DPGP_MAX_Q) return -4;
+    if (!z) return -5;
+    if (!mu) return -6;
+    if (!s) return -7;
+    if (!gamma) return -8;
+    if (!alpha) return -9;
+    if (!out) return -10;
+    if (!ws) return -11;
+    if (ws_bytes < dpgp_psi2_workspace_bytes(B, N, M, Q, sizeof(T))) return -12;
+    if (algo != DPGP_ALGO_AUTO && algo != DPGP_ALGO_PLAIN) return -13;
+    const int ns = psi2_nsplit(B, N, M), Mp = dpgp_round_up(M, 16);
+    int rc = launch_psi2_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, (T *)ws, ns, algo, (hipStream_t)stream);
+    if (rc) return rc;
+    size_t tot = (size_t)B * M * M;
+    hipLaunchKernelGGL((psi2_finish_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       B, M, Mp, ns, (const T *)ws, out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+extern "C" int dpgp_psi2_f32(int B, int N, int M, int Q, const float *z, const float *mu, const float *s,
+                             const float *gamma, const float *alpha, float *out, void *ws, size_t ws_bytes, int algo,
+                             void *stream) {
+    return psi2_api<float>(B, N, M, Q, z, mu, s, gamma, alpha, out, ws, ws_bytes, algo, stream);
+}
+extern "C" int dpgp_psi2_f64(int B, int N, int M, int Q, const double *z, const double *mu, const double *s,
+                             const double *gamma, const double *alpha, double *out, void *ws, size_t ws_bytes, int algo,
+                             void *stream) {
+    return psi2_api<double>(B, N, M, Q, z, mu, s, gamma, alpha, out, ws, ws_bytes, algo, stream);
+}

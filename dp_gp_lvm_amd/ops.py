@@ -1,0 +1,226 @@
+"""
+Torch-tensor front-end of the C ABI (include/dpgp.h).  PyTorch is plumbing here: device memory, the current HIP stream
+and (in models/) torch.distributed.  Every function takes CUDA (ROCm) tensors, enqueues HIP kernels on the current
+stream and returns device tensors; nothing here computes on the host and there is no fallback.
+"""
+import torch
+
+from . import _lib
+
+_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _prep(t, dtype, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('%s must live on the GPU: dp_gp_lvm_amd runs its operators in HIP only' % name)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _dtype_of(*ts):
+    dt = ts[0].dtype
+    if dt not in _SUFFIX:
+        raise TypeError('expected float32 or float64 tensors, got %s' % dt)
+    return dt
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _hyp(gamma, alpha, beta, dt):
+    gamma = _prep(gamma, dt, 'gamma')
+    assert gamma.dim() == 2, 'gamma must be [B x Q]'
+    b = gamma.shape[0]
+    alpha = _prep(alpha, dt, 'alpha').reshape(-1)
+    assert alpha.numel() == b, 'alpha must be [B x 1]'
+    if beta is not None:
+        beta = _prep(beta, dt, 'beta').reshape(-1)
+        assert beta.numel() == b, 'beta must be [B x 1]'
+    return gamma, alpha, beta, b
+
+
+def ard_rbf_gram(x0, x1, gamma, alpha, beta, include_noise=False, include_jitter=False, jitter=1e-8):
+    """Kernel.covariance_matrix -> [B,N0,N1]  (reference: src/kernels/rbf_kernel.py:58-93)."""
+    dt = _dtype_of(x0)
+    x0 = _prep(x0, dt, 'input_0')
+    gamma, alpha, beta, b = _hyp(gamma, alpha, beta, dt)
+    q = gamma.shape[1]
+    assert x0.dim() == 2 and x0.shape[1] == q, 'input_0 must be [N0 x Q]'
+    n0 = x0.shape[0]
+    n1 = n0
+    x1p = None
+    if x1 is not None:
+        x1 = _prep(x1, dt, 'input_1')
+        assert x1.dim() == 2 and x1.shape[1] == q, 'input_1 must be [N1 x Q]'
+        n1, x1p = x1.shape[0], x1.data_ptr()
+    out = torch.empty((b, n0, n1), dtype=dt, device=x0.device)
+    flags = (_lib.FLAG_NOISE if include_noise else 0) | (_lib.FLAG_JITTER if include_jitter else 0)
+    name = 'dpgp_ard_rbf_gram_' + _SUFFIX[dt]
+    _lib.check(getattr(_lib.lib(), name)(b, n0, n1, q, x0.data_ptr(), x1p, gamma.data_ptr(), alpha.data_ptr(),
+                                         beta.data_ptr(), flags, float(jitter), out.data_ptr(), _stream()), name)
+    return out
+
+
+def ard_rbf_diag(n, alpha, beta, include_noise=False, include_jitter=False, jitter=1e-8):
+    """Kernel.covariance_diag -> [B,N]  (rbf_kernel.py:96-116)."""
+    dt = _dtype_of(alpha)
+    alpha = _prep(alpha, dt, 'alpha').reshape(-1)
+    beta = _prep(beta, dt, 'beta').reshape(-1)
+    b = alpha.numel()
+    out = torch.empty((b, int(n)), dtype=dt, device=alpha.device)
+    flags = (_lib.FLAG_NOISE if include_noise else 0) | (_lib.FLAG_JITTER if include_jitter else 0)
+    name = 'dpgp_ard_rbf_diag_' + _SUFFIX[dt]
+    _lib.check(getattr(_lib.lib(), name)(b, int(n), alpha.data_ptr(), beta.data_ptr(), flags, float(jitter),
+                                         out.data_ptr(), _stream()), name)
+    return out
+
+
+def psi0(n, alpha):
+    """Kernel.psi_0 -> [B,1]  (rbf_kernel.py:119-132)."""
+    dt = _dtype_of(alpha)
+    alpha = _prep(alpha, dt, 'alpha').reshape(-1)
+    out = torch.empty((alpha.numel(), 1), dtype=dt, device=alpha.device)
+    name = 'dpgp_psi0_' + _SUFFIX[dt]
+    _lib.check(getattr(_lib.lib(), name)(alpha.numel(), int(n), alpha.data_ptr(), out.data_ptr(), _stream()), name)
+    return out
+
+
+def _zms(z, mu, s, gamma, alpha):
+    dt = _dtype_of(mu)
+    z, mu, s = _prep(z, dt, 'inducing_input'), _prep(mu, dt, 'latent_input_mean'), _prep(s, dt, 'latent variance')
+    gamma, alpha, _, b = _hyp(gamma, alpha, None, dt)
+    q = gamma.shape[1]
+    assert z.dim() == 2 and z.shape[1] == q, 'inducing_input must be [M x Q]'
+    assert mu.dim() == 2 and mu.shape[1] == q, 'latent_input_mean must be [N x Q]'
+    assert s.shape == mu.shape, 'latent variances must be [N x Q]'
+    return dt, z, mu, s, gamma, alpha, b, mu.shape[0], z.shape[0], q
+
+
+def psi1(z, mu, s, gamma, alpha):
+    """Kernel.psi_1 -> [B,N,M]  (rbf_kernel.py:135-161)."""
+    dt, z, mu, s, gamma, alpha, b, n, m, q = _zms(z, mu, s, gamma, alpha)
+    out = torch.empty((b, n, m), dtype=dt, device=mu.device)
+    name = 'dpgp_psi1_' + _SUFFIX[dt]
+    _lib.check(getattr(_lib.lib(), name)(b, n, m, q, z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(),
+                                         alpha.data_ptr(), out.data_ptr(), _stream()), name)
+    return out
+
+
+def psi1T_y(z, mu, s, gamma, alpha, y):
+    """Psi1_b^T y_b -> [B,M] without materialising Psi1 (dp_gp_lvm.py:132-145)."""
+    dt, z, mu, s, gamma, alpha, b, n, m, q = _zms(z, mu, s, gamma, alpha)
+    y = _prep(y, dt, 'y')
+    assert y.shape == (n, b), 'y must be [N x B]'
+    out = torch.empty((b, m), dtype=dt, device=mu.device)
+    l = _lib.lib()
+    wsb = l.dpgp_psi1T_y_workspace_bytes(b, n, m)
+    ws = _ws(wsb, mu.device)
+    name = 'dpgp_psi1T_y_' + _SUFFIX[dt]
+    _lib.check(getattr(l, name)(b, n, m, q, z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(),
+                                alpha.data_ptr(), y.data_ptr(), y.stride(0), out.data_ptr(), ws.data_ptr(), wsb,
+                                _stream()), name)
+    return out
+
+
+def psi2(z, mu, s, gamma, alpha, algo='auto'):
+    """Kernel.psi_2 -> [B,M,M]  (rbf_kernel.py:164-199), streamed over n on the matrix cores."""
+    dt, z, mu, s, gamma, alpha, b, n, m, q = _zms(z, mu, s, gamma, alpha)
+    out = torch.empty((b, m, m), dtype=dt, device=mu.device)
+    l = _lib.lib()
+    wsb = l.dpgp_psi2_workspace_bytes(b, n, m, q, out.element_size())
+    ws = _ws(wsb, mu.device)
+    name = 'dpgp_psi2_' + _SUFFIX[dt]
+    _lib.check(getattr(l, name)(b, n, m, q, z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(),
+                                alpha.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, _lib.ALGO[algo], _stream()), name)
+    return out
+
+
+def potrf_batched(a, algo='auto'):
+    """tf.cholesky on [B,M,M] -> (L [B,M,M] lower, info [B] int32)  (dp_gp_lvm.py:116,127)."""
+    dt = _dtype_of(a)
+    assert a.dim() == 3 and a.shape[1] == a.shape[2], 'a must be [B x M x M]'
+    l_ = _prep(a, dt, 'a').clone()
+    b, m = l_.shape[0], l_.shape[1]
+    info = torch.empty(b, dtype=torch.int32, device=a.device)
+    l = _lib.lib()
+    wsb = l.dpgp_potrf_workspace_bytes(b, m, l_.element_size())
+    ws = _ws(wsb, a.device)
+    name = 'dpgp_potrf_batched_' + _SUFFIX[dt]
+    _lib.check(getattr(l, name)(b, m, l_.data_ptr(), info.data_ptr(), ws.data_ptr(), wsb, _lib.ALGO[algo], _stream()),
+               name)
+    return l_, info
+
+
+def trsm_batched(l_, rhs, algo='auto'):
+    """tf.matrix_triangular_solve(l, rhs, lower=True) on [B,M,M], [B,M,K] -> [B,M,K]  (dp_gp_lvm.py:118-121)."""
+    dt = _dtype_of(l_)
+    l_ = _prep(l_, dt, 'l')
+    x = _prep(rhs, dt, 'rhs').clone()
+    assert l_.dim() == 3 and x.dim() == 3 and l_.shape[0] == x.shape[0] and l_.shape[1] == l_.shape[2] == x.shape[1]
+    b, m, k = x.shape
+    l = _lib.lib()
+    wsb = l.dpgp_trsm_workspace_bytes(b, m, k, x.element_size())
+    ws = _ws(wsb, x.device)
+    name = 'dpgp_trsm_batched_' + _SUFFIX[dt]
+    _lib.check(getattr(l, name)(b, m, k, l_.data_ptr(), x.data_ptr(), ws.data_ptr(), wsb, _lib.ALGO[algo], _stream()),
+               name)
+    return x
+
+
+def kl_qx(mu, s):
+    """calculate_kl_divergence_standard_prior -> 0-d fp64 tensor  (gp_expressions.py:10-24)."""
+    dt = _dtype_of(mu)
+    mu, s = _prep(mu, dt, 'x_mean'), _prep(s, dt, 'x_var')
+    assert mu.shape == s.shape and mu.dim() == 2
+    out = torch.empty(1, dtype=torch.float64, device=mu.device)
+    name = 'dpgp_kl_qx_' + _SUFFIX[dt]
+    _lib.check(getattr(_lib.lib(), name)(mu.shape[0], mu.shape[1], mu.data_ptr(), s.data_ptr(), out.data_ptr(),
+                                         _stream()), name)
+    return out[0]
+
+
+class ElboWorkspace:
+    """Caller-owned scratch + outputs of the fused ELBO for one (D,N,M,Q,prec): allocate once, evaluate many times."""
+
+    def __init__(self, d, n, m, q, prec='mixed', device='cuda'):
+        self.shape, self.prec = (d, n, m, q), prec
+        l = _lib.lib()
+        self.nbytes = l.dpgp_elbo_workspace_bytes(d, n, m, q, _lib.PREC[prec])
+        self.ws = _ws(self.nbytes, device)
+        self.terms = torch.empty((d, 5), dtype=torch.float64, device=device)
+        self.sums = torch.empty(2, dtype=torch.float64, device=device)
+        self.info = torch.empty(d, dtype=torch.int32, device=device)
+
+
+def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None):
+    """
+    The fused per-output ELBO reduction of dp_gp_lvm.py:108-148 for the D output dims in ``y`` [N,D] (a column slice of
+    the full data when D is sharded over GPUs).  All inputs fp64 device tensors.
+    Returns (terms [D,5], sums [2] = (f_hat, KL), info [D]) — device tensors, no host synchronisation.
+    """
+    f64 = torch.float64
+    z, mu, s = _prep(z, f64, 'z'), _prep(mu, f64, 'mu'), _prep(s, f64, 's')
+    gamma, alpha, beta, d = _hyp(gamma, alpha, beta, f64)
+    if not y.is_cuda:
+        raise RuntimeError('y must live on the GPU')
+    if y.dtype != f64 or y.stride(1) != 1:
+        y = y.to(f64).contiguous()
+    n, m, q = mu.shape[0], z.shape[0], z.shape[1]
+    assert y.shape == (n, d), 'y must be [N x D]'
+    assert mu.shape == (n, q) and s.shape == (n, q) and gamma.shape == (d, q)
+    w = workspace if workspace is not None else ElboWorkspace(d, n, m, q, prec, y.device)
+    assert w.shape == (d, n, m, q) and w.prec == prec, 'workspace was sized for another problem'
+    _lib.check(_lib.lib().dpgp_elbo_fhat(d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(),
+                                         s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(),
+                                         float(jitter), _lib.PREC[prec], _lib.ALGO[algo], w.terms.data_ptr(),
+                                         w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes, _stream()),
+               'dpgp_elbo_fhat')
+    return w.terms, w.sums, w.info

@@ -1,0 +1,125 @@
+/*
+ * dpgp.h — C ABI of libdpgp_hip.so: the DP-GP-LVM variational-ELBO inner loop on AMD MI355X (gfx950), hand-written HIP.
+ *
+ * The reference (AndrewRLawrence/dp_gp_lvm) has no FFI: its boundary for this path is the Python operator API
+ *   k_ard_rbf / Kernel.covariance_matrix | covariance_diag | psi_0 | psi_1 | psi_2   (src/kernels/rbf_kernel.py:26-203,
+ *                                                                                     src/kernels/interfaces/kernel.py:204-280)
+ *   dp_gp_lvm(...).objective                                                          (src/models/dp_gp_lvm.py:100-154)
+ * which dispatches to TensorFlow 1.15 ops (tf.matmul / tf.exp / tf.cholesky / tf.matrix_triangular_solve ...).
+ * These entry points are what a binding of that API would call instead of TensorFlow; dp_gp_lvm_amd/ binds them with
+ * ctypes (dp_gp_lvm_amd/_lib.py), INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (e.g. torch's allocator); row-major, contiguous, leading batch
+ *    dimension; the library keeps no global state and allocates nothing: scratch is a caller-provided workspace whose
+ *    size comes from the matching *_workspace_bytes() query (a pure host function, callable without a GPU);
+ *  - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it and returns (graph-capturable);
+ *  - return value: DPGP_OK (0), or -(1-based index of the first bad argument), or DPGP_ERR_LAUNCH (-100) if the HIP
+ *    launch itself failed.  A non-positive-definite matrix is never an abort: it is reported LAPACK-style in the
+ *    caller-provided device array info[B] (0 = ok, j>0 = leading minor j not positive; for the fused ELBO, M + j
+ *    refers to the second factorisation);
+ *  - suffix _f32 / _f64 is the arithmetic AND storage type of the call;  `s` is always the DIAGONAL [N,Q] of q(X)'s
+ *    covariance (the reference API takes [N,Q,Q] and reads only its diagonal: rbf_kernel.py:151,182);
+ *  - B = kernel batch (= D output dims in dp_gp_lvm), N observations, M inducing points, Q latent dims (Q <= 30).
+ */
+#ifndef DPGP_H
+#define DPGP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPGP_OK 0
+#define DPGP_ERR_LAUNCH (-100)
+#define DPGP_FLAG_NOISE 1  /* include_noise  (only honoured when x1 == NULL: rbf_kernel.py:80)  */
+#define DPGP_FLAG_JITTER 2 /* include_jitter (only honoured when x1 == NULL: rbf_kernel.py:86)  */
+#define DPGP_MAX_Q 30
+
+/* algorithm selectors for the calls that have a matrix-core and a plain-VALU implementation */
+#define DPGP_ALGO_AUTO 0  /* MFMA kernels (the product path)                                   */
+#define DPGP_ALGO_PLAIN 1 /* straightforward one-thread-per-element HIP kernels (cross-check)  */
+
+/* precision modes of the fused ELBO */
+#define DPGP_PREC_F32 0   /* psi-statistics fp32, Cholesky chain fp32                          */
+#define DPGP_PREC_MIXED 1 /* psi-statistics fp32 (MFMA), Cholesky chain + reductions fp64      */
+#define DPGP_PREC_F64 2   /* everything fp64                                                   */
+
+int dpgp_version(void);
+
+/* ---- Kernel.covariance_matrix (rbf_kernel.py:58-93): out[B,N0,N1] = alpha_b exp(-1/2 sum_q gamma_bq (x0_iq-x1_jq)^2)
+ *      x1 == NULL means input_1 is None: N1 is ignored (= N0) and noise/jitter flags apply on the diagonal.          */
+int dpgp_ard_rbf_gram_f32(int B, int N0, int N1, int Q, const float *x0, const float *x1, const float *gamma,
+                          const float *alpha, const float *beta, int flags, double jitter, float *out, void *stream);
+int dpgp_ard_rbf_gram_f64(int B, int N0, int N1, int Q, const double *x0, const double *x1, const double *gamma,
+                          const double *alpha, const double *beta, int flags, double jitter, double *out, void *stream);
+
+/* ---- Kernel.covariance_diag (rbf_kernel.py:96-116): out[B,N] = alpha_b (+1/beta_b) (+jitter) */
+int dpgp_ard_rbf_diag_f32(int B, int N, const float *alpha, const float *beta, int flags, double jitter, float *out,
+                          void *stream);
+int dpgp_ard_rbf_diag_f64(int B, int N, const double *alpha, const double *beta, int flags, double jitter, double *out,
+                          void *stream);
+
+/* ---- Kernel.psi_0 (rbf_kernel.py:119-132): out[B] = alpha_b * N */
+int dpgp_psi0_f32(int B, int N, const float *alpha, float *out, void *stream);
+int dpgp_psi0_f64(int B, int N, const double *alpha, double *out, void *stream);
+
+/* ---- Kernel.psi_1 (rbf_kernel.py:135-161): out[B,N,M] */
+int dpgp_psi1_f32(int B, int N, int M, int Q, const float *z, const float *mu, const float *s, const float *gamma,
+                  const float *alpha, float *out, void *stream);
+int dpgp_psi1_f64(int B, int N, int M, int Q, const double *z, const double *mu, const double *s, const double *gamma,
+                  const double *alpha, double *out, void *stream);
+
+/* ---- Psi1_b^T y_b without materialising Psi1 (replaces the two [D,M,N] solves + [D,N,N] product of
+ *      dp_gp_lvm.py:132-136,145): y is [N, ldy] with column b used for batch entry b; out[B,M].
+ *      ws: dpgp_psi1T_y_workspace_bytes(B,N,M).                                                                   */
+size_t dpgp_psi1T_y_workspace_bytes(int B, int N, int M);
+int dpgp_psi1T_y_f32(int B, int N, int M, int Q, const float *z, const float *mu, const float *s, const float *gamma,
+                     const float *alpha, const float *y, int ldy, float *out, void *ws, size_t ws_bytes, void *stream);
+int dpgp_psi1T_y_f64(int B, int N, int M, int Q, const double *z, const double *mu, const double *s,
+                     const double *gamma, const double *alpha, const double *y, int ldy, double *out, void *ws,
+                     size_t ws_bytes, void *stream);
+
+/* ---- Kernel.psi_2 (rbf_kernel.py:164-199): out[B,M,M], streamed over n (no [B,N,M,M,Q] temporary).
+ *      ws: dpgp_psi2_workspace_bytes(B,N,M,Q,elem_size).                                                           */
+size_t dpgp_psi2_workspace_bytes(int B, int N, int M, int Q, int elem_size);
+int dpgp_psi2_f32(int B, int N, int M, int Q, const float *z, const float *mu, const float *s, const float *gamma,
+                  const float *alpha, float *out, void *ws, size_t ws_bytes, int algo, void *stream);
+int dpgp_psi2_f64(int B, int N, int M, int Q, const double *z, const double *mu, const double *s, const double *gamma,
+                  const double *alpha, double *out, void *ws, size_t ws_bytes, int algo, void *stream);
+
+/* ---- tf.cholesky (dp_gp_lvm.py:116,127): in-place lower Cholesky of a[B,M,M] (upper triangle zeroed), info[B].
+ *      ws: dpgp_potrf_workspace_bytes(B,M,elem_size).                                                              */
+size_t dpgp_potrf_workspace_bytes(int B, int M, int elem_size);
+int dpgp_potrf_batched_f32(int B, int M, float *a, int *info, void *ws, size_t ws_bytes, int algo, void *stream);
+int dpgp_potrf_batched_f64(int B, int M, double *a, int *info, void *ws, size_t ws_bytes, int algo, void *stream);
+
+/* ---- tf.matrix_triangular_solve(lower=True) (dp_gp_lvm.py:118-121,132-133): rhs[B,M,K] <- l[B,M,M]^-1 rhs.
+ *      ws: dpgp_trsm_workspace_bytes(B,M,K,elem_size).                                                             */
+size_t dpgp_trsm_workspace_bytes(int B, int M, int K, int elem_size);
+int dpgp_trsm_batched_f32(int B, int M, int K, const float *l, float *rhs, void *ws, size_t ws_bytes, int algo,
+                          void *stream);
+int dpgp_trsm_batched_f64(int B, int M, int K, const double *l, double *rhs, void *ws, size_t ws_bytes, int algo,
+                          void *stream);
+
+/* ---- calculate_kl_divergence_standard_prior (gp_expressions.py:10-24): out[1] (fp64) */
+int dpgp_kl_qx_f32(int N, int Q, const float *mu, const float *s, double *out, void *stream);
+int dpgp_kl_qx_f64(int N, int Q, const double *mu, const double *s, double *out, void *stream);
+
+/* ---- the fused per-output ELBO reduction, dp_gp_lvm.py:108-145, for D output dims resident on this GPU.
+ *   inputs (all fp64 device arrays; they are rounded to fp32 on the fly where `prec` says so):
+ *     y[N,ldy] (column d = output d), z[M,Q], mu[N,Q], s[N,Q], gamma[D,Q], alpha[D], beta[D]
+ *   outputs (fp64): terms[D,5] = { N/2 (log beta - log 2pi), -sum log diag L_A, beta/2 (tr(L^-1 Psi2 L^-T) - alpha N),
+ *                                  -beta/2 y'y, beta^2/2 |L_A^-1 L^-1 Psi1' y|^2 }   (f_hat = sum of all entries)
+ *                   sums[2]    = { f_hat, KL(q(X)||p(X)) }
+ *                   info[D]    (see top of file)
+ *   ws: dpgp_elbo_workspace_bytes(D,N,M,Q,prec).  algo: DPGP_ALGO_*.                                               */
+size_t dpgp_elbo_workspace_bytes(int D, int N, int M, int Q, int prec);
+int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                   const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
+                   int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
+                   void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPGP_H */

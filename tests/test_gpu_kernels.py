@@ -1,0 +1,150 @@
+"""
+GPU parity tests of the kernel operators (through the C ABI, via dp_gp_lvm_amd.ops) against the golden vectors the
+reference's own source produced (tests/golden/kernel_b1.npz = TestRbfKernel inputs, kernel_b7.npz = TestRbfBatchKernel;
+/root/reference/test/unittests/kernel_unittests.py:150-829) and against the CPU oracle on seeded inputs.
+
+Tolerances (stated per north star, fp64 reference -> fp32 kernels):
+  fp64 kernels : rtol 1e-10 on every entry (atol 1e-13 * max|ref| for entries that underflow relative precision)
+  fp32 kernels : rtol 2e-5 on gram / psi1 entries, 1e-4 on psi2 entries (atol 1e-6 * max|ref|)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from dp_gp_lvm_amd import ops
+from oracle import dpgp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float64: dict(rtol=1e-10, atol_rel=1e-13), torch.float32: dict(rtol=2e-5, atol_rel=1e-6)}
+TOL_PSI2 = {torch.float64: dict(rtol=1e-10, atol_rel=1e-13), torch.float32: dict(rtol=1e-4, atol_rel=1e-6)}
+
+
+def close(got, ref, tol, what=''):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    np.testing.assert_allclose(got, ref, rtol=tol['rtol'], atol=tol['atol_rel'] * np.max(np.abs(ref)), err_msg=what)
+
+
+def T(a, dt, dev):
+    return torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+
+
+@pytest.mark.parametrize('fixture', ['kernel_b1', 'kernel_b7'])
+@pytest.mark.parametrize('dt', [torch.float64, torch.float32])
+def test_covariance_matrix_all_variants(dev, fixture, dt):
+    g = golden(fixture)
+    gam, al, be = T(g['gamma'], dt, dev), T(g['alpha'], dt, dev), T(g['beta'], dt, dev)
+    combos = {'xx': ('x0', None), 'x01': ('x0', 'x1'), 'x10': ('x1', 'x0'), 'uu_same': ('x_u', 'x_u'),
+              'uu': ('x_u', None)}
+    for tag, (a, c) in combos.items():
+        for noise in (0, 1):
+            for jit in (0, 1):
+                out = ops.ard_rbf_gram(T(g[a], dt, dev), None if c is None else T(g[c], dt, dev), gam, al, be,
+                                       include_noise=bool(noise), include_jitter=bool(jit))
+                close(out, g['gram_%s_n%d_j%d' % (tag, noise, jit)], TOL[dt], 'gram %s n%d j%d' % (tag, noise, jit))
+
+
+@pytest.mark.parametrize('fixture', ['kernel_b1', 'kernel_b7'])
+@pytest.mark.parametrize('dt', [torch.float64, torch.float32])
+def test_diag_psi0_psi1(dev, fixture, dt):
+    g = golden(fixture)
+    gam, al, be = T(g['gamma'], dt, dev), T(g['alpha'], dt, dev), T(g['beta'], dt, dev)
+    n = g['x0'].shape[0]
+    for noise in (0, 1):
+        for jit in (0, 1):
+            close(ops.ard_rbf_diag(n, al, be, bool(noise), bool(jit)), g['diag_n%d_j%d' % (noise, jit)], TOL[dt], 'diag')
+    close(ops.psi0(g['x_mean'].shape[0], al), g['psi_0'], TOL[dt], 'psi0')
+    p1 = ops.psi1(T(g['x_u'], dt, dev), T(g['x_mean'], dt, dev), T(g['x_var'], dt, dev), gam, al)
+    close(p1, g['psi_1'], TOL[dt], 'psi1')
+
+
+@pytest.mark.parametrize('fixture', ['kernel_b1', 'kernel_b7'])
+@pytest.mark.parametrize('dt', [torch.float64, torch.float32])
+@pytest.mark.parametrize('algo', ['auto', 'plain'])
+def test_psi2_golden(dev, fixture, dt, algo):
+    g = golden(fixture)
+    p2 = ops.psi2(T(g['x_u'], dt, dev), T(g['x_mean'], dt, dev), T(g['x_var'], dt, dev), T(g['gamma'], dt, dev),
+                  T(g['alpha'], dt, dev), algo=algo)
+    close(p2, g['psi_2'], TOL_PSI2[dt], 'psi2 ' + algo)
+    assert torch.equal(p2, p2.transpose(1, 2)), 'psi2 must be exactly symmetric'
+
+
+@pytest.mark.parametrize('shape', [(3, 37, 5, 1), (2, 300, 33, 3), (5, 257, 64, 10), (2, 500, 100, 20), (1, 130, 130, 30),
+                                   (3, 1000, 128, 10)])
+@pytest.mark.parametrize('dt', [torch.float64, torch.float32])
+def test_psi_statistics_vs_oracle_ragged(dev, shape, dt):
+    """Ragged shapes (M, N not multiples of the tiles; Q from 1 to the maximum 30) against the NumPy oracle."""
+    b, n, m, q = shape
+    rng = np.random.default_rng(sum(shape))
+    z, mu = rng.standard_normal((m, q)), rng.standard_normal((n, q))
+    s = np.exp(0.5 * rng.standard_normal((n, q)))
+    gam, al = np.exp(0.3 * rng.standard_normal((b, q))), np.exp(0.3 * rng.standard_normal((b, 1)))
+    y = rng.standard_normal((n, b))
+    args = [T(a, dt, dev) for a in (z, mu, s, gam, al)]
+    close(ops.psi2(*args), orc.psi2(z, mu, s, gam, al), TOL_PSI2[dt], 'psi2')
+    close(ops.psi1(*args), orc.psi1(z, mu, s, gam, al), TOL[dt], 'psi1')
+    tol = dict(TOL[dt])
+    if dt == torch.float32:
+        tol['atol_rel'] = 2e-5      # a signed sum over n of fp32 terms
+    close(ops.psi1T_y(*args, T(y, dt, dev)), orc.psi1T_y(z, mu, s, gam, al, y), tol, 'psi1T_y')
+
+
+@pytest.mark.parametrize('dt', [torch.float64, torch.float32])
+def test_psi2_far_from_origin_is_translation_invariant(dev, dt):
+    """q(X) and Z far from the origin: the kernel centres its coordinates, so fp32 accuracy must not degrade."""
+    rng = np.random.default_rng(5)
+    b, n, m, q = 2, 400, 48, 6
+    z, mu = rng.standard_normal((m, q)), rng.standard_normal((n, q))
+    s = np.exp(0.5 * rng.standard_normal((n, q)))
+    gam, al = np.exp(0.3 * rng.standard_normal((b, q))), np.ones((b, 1))
+    ref = orc.psi2(z, mu, s, gam, al)
+    shift = 50.0
+    got = ops.psi2(T(z + shift, dt, dev), T(mu + shift, dt, dev), T(s, dt, dev), T(gam, dt, dev), T(al, dt, dev))
+    tol = dict(TOL_PSI2[dt])
+    if dt == torch.float32:
+        tol['rtol'] = 2e-3      # the inputs themselves lose 3 digits when stored as fp32 at offset 50
+    close(got, ref, tol, 'shifted psi2')
+
+
+@pytest.mark.parametrize('m', [1, 7, 16, 20, 25, 64, 100, 128, 130])
+@pytest.mark.parametrize('dt', [torch.float64, torch.float32])
+@pytest.mark.parametrize('algo', ['auto', 'plain'])
+def test_potrf_trsm(dev, m, dt, algo):
+    rng = np.random.default_rng(m)
+    b, k = 3, 9
+    a = rng.standard_normal((b, m, m + 3))
+    a = a @ a.transpose(0, 2, 1) + 0.5 * m * np.eye(m)
+    rhs = rng.standard_normal((b, m, k))
+    l_ref = np.linalg.cholesky(a)
+    tol = dict(rtol=1e-11, atol_rel=1e-13) if dt == torch.float64 else dict(rtol=2e-4, atol_rel=2e-6)
+    l, info = ops.potrf_batched(T(a, dt, dev), algo=algo)
+    assert int(info.abs().max()) == 0
+    close(l, l_ref, tol, 'potrf')
+    x = ops.trsm_batched(T(l_ref, dt, dev), T(rhs, dt, dev), algo=algo)
+    x_ref = np.stack([np.linalg.solve(l_ref[i], rhs[i]) for i in range(b)])
+    close(x, x_ref, tol, 'trsm')
+
+
+@pytest.mark.parametrize('algo', ['auto', 'plain'])
+def test_potrf_reports_non_positive_definite(dev, algo):
+    a = np.eye(40)[None].repeat(2, axis=0)
+    a[1, 17, 17] = -1.0
+    l, info = ops.potrf_batched(T(a, torch.float64, dev), algo=algo)
+    assert info.tolist() == [0, 18]
+
+
+def test_kl(dev):
+    g = golden('dpgplvm_50_10_25_3_T8')
+    for dt in (torch.float64, torch.float32):
+        got = float(ops.kl_qx(T(g['mu'], dt, dev), T(g['s'], dt, dev)))
+        np.testing.assert_allclose(got, float(g['kl']), rtol=1e-12 if dt == torch.float64 else 1e-6)
+
+
+def test_operators_refuse_cpu_tensors():
+    x = torch.zeros(4, 2, dtype=torch.float64)
+    with pytest.raises(RuntimeError):
+        ops.ard_rbf_gram(x, None, torch.ones(1, 2, dtype=torch.float64), torch.ones(1, 1, dtype=torch.float64),
+                         torch.ones(1, 1, dtype=torch.float64))
