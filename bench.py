@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""
+Benchmark of the DP-GP-LVM objective (ELBO) evaluation — BASELINE.json metric "ELBO evals/sec (N=2000,D=512,M=128,Q=10)".
+
+One step = one evaluation of dp_gp_lvm(...).objective (reference: src/models/dp_gp_lvm.py:100-154) from device-resident
+raw parameters to the scalar objective in device memory: parameter transforms + soft-assignment mixing + DP objective +
+hyper-prior (dpgp_model_prepare), K_uu, Psi1^T y, Psi2, both Choleskys + solves + the five f_hat terms, KL
+(dpgp_elbo_fhat), the packed 2-scalar all-reduce when D is sharded over GPUs (RCCL), and dpgp_model_finalize.
+Steps are enqueued back to back and the host synchronises once at the end of the timed region (what a training loop
+does: the reference reads the objective only every 100 iterations, test/synthetic_data_hard_test.py:143-155); every
+step's objective is kept on the device and checked after timing.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--prec mixed] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `value` is whole-job evaluations/s (D=512 is a fixed total: strong scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (spec), gfx950
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', type=int, default=3, help='BASELINE.json config index (SURVEY.md 8d): 2,3,4,5')
+    ap.add_argument('--prec', default='mixed', choices=['mixed', 'f32', 'f64'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-dims', type=int, default=0, help='output dims in the bounded CPU sample (0 = auto)')
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, p, shape, dims):
+    """The C restatement of the reference algorithm (oracle/dpgp_oracle.c, fast build, OpenMP over output dims) timed on
+    this box's host cores on a bounded sample: `dims` of the D output dims (every dim costs the same), 3 repetitions."""
+    from oracle.c_oracle import COracle
+    n, d, m, q = shape
+    orc = COracle(fast=True)
+    cores = orc.max_threads
+    dims = min(d, dims if dims > 0 else max(2 * cores, 16))
+    sel = np.linspace(0, d - 1, dims).astype(int)
+    args = (np.ascontiguousarray(p['y'][:, sel]), p['z'], p['mu'], p['s'], p['gamma'][sel], p['alpha'][sel], p['beta'][sel])
+    orc.fhat_terms(*args, nthreads=cores)                    # warm-up (page in, spin up the OpenMP pool)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        orc.fhat_terms(*args, nthreads=cores)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return dict(value=1.0 / (t * d / dims), unit='ELBO evals/s', cores=int(cores), kind='port',
+                sample='%d of %d output dims of config %d, all of N=%d M=%d Q=%d, fp64 C/OpenMP port of the reference '
+                       'formulas (oracle/dpgp_oracle.c), median of 3 runs of %.2f s, scaled by D/dims'
+                       % (dims, d, cfg, n, m, q, t))
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from dp_gp_lvm_amd import _lib
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    from dp_gp_lvm_amd.utils.synthetic import make_problem, CONFIGS
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (a.gpus, world, a.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    group = None
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)      # nccl == RCCL on ROCm
+        group = dist.group.WORLD
+
+    shape = CONFIGS[a.config]
+    n, d, m, q = shape
+    p = make_problem(a.config)
+    t = p['phi'].shape[1]
+    model = dp_gp_lvm(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=t,
+                      alpha_prior_params=np.array([p['s1'], p['s2']]), device=dev, precision=a.prec,
+                      process_group=group,
+                      initial_values=dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']),
+                                          gamma_atoms=p['gamma_atoms'], alpha_atoms=p['alpha_atoms'],
+                                          beta_atoms=p['beta_atoms'], gamma_1=p['g1'], gamma_2=p['g2'],
+                                          w_1=p['w1'], w_2=p['w2']))
+    lib = _lib.lib()
+    d_lo, d_hi = model.shard
+    objs = torch.zeros(a.steps, dtype=torch.float64, device=dev)
+    ev = [(lib.dpgp_event_create(), lib.dpgp_event_create()) for _ in range(a.steps)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        model.evaluate_()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = model.evaluate_(events=ev[i])
+        objs[i:i + 1].copy_(out[0:1])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    psi2_ms = float(np.mean([lib.dpgp_event_elapsed_ms(e0, e1) for e0, e1 in ev]))
+    for e0, e1 in ev:
+        lib.dpgp_event_destroy(e0)
+        lib.dpgp_event_destroy(e1)
+    objs = objs.cpu().numpy()
+    terms, info = model.per_dimension_terms
+    assert np.isfinite(objs).all() and np.all(objs == objs[0]), 'objective is not finite / not reproducible'
+    assert int(info.abs().max().item()) == 0, 'a Cholesky factorisation failed'
+
+    if rank == 0:
+        d_loc = d_hi - d_lo
+        # algorithmic work of the dominant kernel (psi2) per launch: SURVEY.md 8(d): per output dim N*M(M+1)/2 exps and
+        # (4Q+2) flops per exponent on the symmetric half; one launch processes d_loc output dims.
+        exps = d_loc * n * m * (m + 1) // 2
+        flops = exps * (4 * q + 2)
+        achieved = flops / (psi2_ms * 1e-3) / 1e12
+        res = {
+            'metric': 'ELBO evals/sec (N=%d,D=%d,M=%d,Q=%d)' % (n, d, m, q),
+            'value': a.steps / elapsed, 'unit': 'ELBO evals/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': {'mixed': 'f32 (psi-statistics, MFMA) + f64 (Cholesky chain)', 'f32': 'f32',
+                                           'f64': 'f64'}[a.prec],
+            'data': 'synthetic (SURVEY.md 8d recipe, seed %d)' % (1000 + a.config),
+            'config': {'workload': 'BASELINE config %d: dp_gp_lvm objective, N=%d D=%d M=%d Q=%d T=%d' % (a.config, n, d, m, q, t),
+                       'parallelism': 'D sharded over %d GPU(s), %d output dims per GPU' % (world, d_loc),
+                       'precision': a.prec},
+            'objective': float(objs[0]),
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None, 'kernel': 'psi2_mfma_kernel',
+                         'kernel_ms': psi2_ms, 'exp_per_s': exps / (psi2_ms * 1e-3),
+                         'executed_mfma_tflops': exps * 2 * (q + 2) / (psi2_ms * 1e-3) / 1e12},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline(a.config, p, shape, a.cpu_dims)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -19,6 +19,7 @@ _vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size
 # name -> (restype, argtypes); one entry per symbol declared in include/dpgp.h
 SIGNATURES = {
     'dpgp_version': (_i, []),
+    'dpgp_last_hip_error': (ctypes.c_char_p, []),
     'dpgp_psi1T_y_workspace_bytes': (_sz, [_i, _i, _i]),
     'dpgp_psi2_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'dpgp_potrf_workspace_bytes': (_sz, [_i, _i, _i]),
@@ -26,6 +27,14 @@ SIGNATURES = {
     'dpgp_elbo_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'dpgp_elbo_fhat': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp, _sz,
                             _vp]),
+    'dpgp_elbo_fhat_timed': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp,
+                                  _sz, _vp, _vp, _vp]),
+    'dpgp_event_create': (_vp, []),
+    'dpgp_event_destroy': (None, [_vp]),
+    'dpgp_event_elapsed_ms': (ctypes.c_float, [_vp, _vp]),
+    'dpgp_model_prepare': (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp]),
+    'dpgp_model_finalize': (_i, [_vp, _vp, _vp, _vp, _vp]),
 }
 for _t in ('f32', 'f64'):
     SIGNATURES.update({
@@ -55,6 +64,9 @@ def lib():
             raise DpgpLibraryMissing(
                 'libdpgp_hip.so is not built: run `make -C %s` (hipcc, gfx950). dp_gp_lvm_amd has no CPU fallback.'
                 % os.path.join(_HERE, 'csrc'))
+        # torch ships its own libamdhip64 (same soname as /opt/rocm's): it must be the one already mapped when this
+        # library's NEEDED entry is resolved, otherwise the process ends up with two HIP runtimes and no device.
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError here = header/library mismatch
@@ -66,5 +78,5 @@ def lib():
 def check(rc, name):
     if rc != 0:
         if rc == -100:
-            raise RuntimeError('%s: HIP kernel launch failed' % name)
+            raise RuntimeError('%s: HIP kernel launch failed: %s' % (name, lib().dpgp_last_hip_error().decode()))
         raise ValueError('%s: bad argument #%d' % (name, -rc))

@@ -14,9 +14,20 @@ static inline int dpgp_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int dpgp_round_up(int a, int b) { return dpgp_ceil_div(a, b) * b; }
 static inline size_t dpgp_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-#define DPGP_LAUNCH_CHECK()                                 \
-    do {                                                    \
-        if (hipGetLastError() != hipSuccess) return DPGP_ERR_LAUNCH; \
+// hipGetLastError() is sticky across unrelated runtime calls of the process (torch's own included): clear it first.
+#define DPGP_PRELAUNCH() (void)hipGetLastError()
+// The last HIP error seen by a launch check of this thread (diagnostics only; see dpgp_last_hip_error()).
+inline hipError_t &dpgp_last_error_slot() {
+    static thread_local hipError_t e = hipSuccess;
+    return e;
+}
+#define DPGP_LAUNCH_CHECK()                              \
+    do {                                                 \
+        hipError_t e_ = hipGetLastError();               \
+        if (e_ != hipSuccess) {                          \
+            dpgp_last_error_slot() = e_;                 \
+            return DPGP_ERR_LAUNCH;                      \
+        }                                                \
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -37,7 +37,7 @@ template <typename TP, typename TL>
 static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                     const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                     int algo, double *terms, double *sums, int *info, unsigned char *ws, const ElboLayout &L,
-                    hipStream_t st) {
+                    hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     double *yy = reinterpret_cast<double *>(ws + L.off_yy);
     double *vpart = reinterpret_cast<double *>(ws + L.off_v);
     TP *p2 = reinterpret_cast<TP *>(ws + L.off_p2);
@@ -49,17 +49,20 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
         return rc;
     if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, st)))
         return rc;
+    if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st))) return rc;
+    if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     if ((rc = launch_la_chain<TP, TL>(D, N, M, la, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, terms, info, la, algo,
                                       st)))
         return rc;
     return launch_sum_terms(D, terms, sums, st);
 }
 
-extern "C" int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
-                              const double *s, const double *gamma, const double *alpha, const double *beta,
-                              double jitter, int prec, int algo, double *terms, double *sums, int *info, void *ws,
-                              size_t ws_bytes, void *stream) {
+extern "C" int dpgp_elbo_fhat_timed(int D, int N, int M, int Q, const double *y, int ldy, const double *z,
+                                    const double *mu, const double *s, const double *gamma, const double *alpha,
+                                    const double *beta, double jitter, int prec, int algo, double *terms, double *sums,
+                                    int *info, void *ws, size_t ws_bytes, void *stream, void *ev_psi2_begin,
+                                    void *ev_psi2_end) {
     if (D <= 0) return -1;
     if (N <= 0) return -2;
     if (M <= 0 || M > N) return -3;
@@ -86,12 +89,196 @@ extern "C" int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int l
     switch (prec) {
     case DPGP_PREC_F32:
         return elbo_run<float, float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, algo, terms, sums, info,
-                                      w, L, st);
+                                      w, L, st, (hipEvent_t)ev_psi2_begin, (hipEvent_t)ev_psi2_end);
     case DPGP_PREC_MIXED:
         return elbo_run<float, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, algo, terms, sums,
-                                       info, w, L, st);
+                                       info, w, L, st, (hipEvent_t)ev_psi2_begin, (hipEvent_t)ev_psi2_end);
     default:
         return elbo_run<double, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, algo, terms, sums,
-                                        info, w, L, st);
+                                        info, w, L, st, (hipEvent_t)ev_psi2_begin, (hipEvent_t)ev_psi2_end);
     }
 }
+
+extern "C" int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                              const double *s, const double *gamma, const double *alpha, const double *beta,
+                              double jitter, int prec, int algo, double *terms, double *sums, int *info, void *ws,
+                              size_t ws_bytes, void *stream) {
+    return dpgp_elbo_fhat_timed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, prec, algo, terms, sums, info,
+                                ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+// HIP events for callers that have no HIP runtime binding of their own (bench.py times the psi2 kernel with these).
+extern "C" void *dpgp_event_create(void) {
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? (void *)e : nullptr;
+}
+extern "C" void dpgp_event_destroy(void *e) {
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+}
+extern "C" float dpgp_event_elapsed_ms(void *a, void *b) {
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Model-level glue of dp_gp_lvm(...).objective that is O(D T + N Q): variational-parameter transforms, soft-assignment
+// mixing (dp_gp_lvm.py:100-102), the DP objective (dirichlet_process.py:39-88) and the hyper-prior on the atoms
+// (dp_gp_lvm.py:96-98), so that one objective evaluation is a fixed handful of launches with no host arithmetic.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double softplus_d(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))); }
+
+// digamma for x > 0: recurrence up to x >= 10, then the asymptotic series (error < 1e-15 there)
+__device__ double digamma_d(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    const double t = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 + f * (-1.0 / 132.0 +
+                     f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+    return r + log(x) - 0.5 / x + t;
+}
+
+#define PREP_MAX_T 64
+__global__ __launch_bounds__(256) void model_prepare_kernel(
+    int D, int T, int Q, int N, int d_offset, int mask_size, const double *__restrict__ logits,
+    const double *__restrict__ gat_raw, const double *__restrict__ aat_raw, const double *__restrict__ bat_raw,
+    const double *__restrict__ s_raw, const double *__restrict__ g1_raw, const double *__restrict__ g2_raw,
+    const double *__restrict__ w_raw, double s1, double s2, int add_constants, double *__restrict__ gamma,
+    double *__restrict__ alpha, double *__restrict__ beta, double *__restrict__ s_out, double *__restrict__ phi_out,
+    double *__restrict__ scal) {
+    const int t = threadIdx.x;
+    if (blockIdx.x > 0) {   // q(X) variances: s = softplus(raw)   (dp_gp_lvm.py:67-69, utils/types.py:40-57)
+        const size_t tot = (size_t)N * Q;
+        for (size_t i = (size_t)(blockIdx.x - 1) * 256 + t; i < tot; i += (size_t)(gridDim.x - 1) * 256)
+            s_out[i] = softplus_d(s_raw[i]);
+        return;
+    }
+    __shared__ double gat[PREP_MAX_T * DPGP_MAX_Q], aat[PREP_MAX_T], bat[PREP_MAX_T];
+    __shared__ double c1[PREP_MAX_T], c2[PREP_MAX_T];   // psi(g1)-psi(g1+g2), psi(g2)-psi(g1+g2)
+    __shared__ double scratch[8];
+    double hyper = 0.0, consts = 0.0;
+    for (int i = t; i < T * Q; i += 256) {
+        const double v = softplus_d(gat_raw[i]);
+        gat[i] = v;
+        const double lx = log(v);
+        hyper += -lx - 0.5 * (DPGP_LOG_2PI + lx * lx);        // log_normal.log_pdf (log_normal.py:34-39)
+    }
+    if (t < T) {
+        const double a = softplus_d(aat_raw[t]), b = softplus_d(bat_raw[t]);
+        aat[t] = a;
+        bat[t] = b;
+        const double la = log(a), lb = log(b);
+        hyper += -la - 0.5 * (DPGP_LOG_2PI + la * la) - lb - 0.5 * (DPGP_LOG_2PI + lb * lb);
+    }
+    const double w1 = softplus_d(w_raw[0]), w2 = softplus_d(w_raw[1]);
+    if (t < T - 1) {
+        const double g1 = softplus_d(g1_raw[t]), g2 = softplus_d(g2_raw[t]);
+        const double p1 = digamma_d(g1), p2 = digamma_d(g2), p12 = digamma_d(g1 + g2);
+        c1[t] = p1 - p12;
+        c2[t] = p2 - p12;
+        // D-independent pieces, per stick t: part of E[log p(V|alpha)] and the Beta entropy
+        consts += (w1 / w2 - 1.0) * (p2 - p12) +
+                  (lgamma(g1) + lgamma(g2) - lgamma(g1 + g2) - (g1 - 1.0) * p1 - (g2 - 1.0) * p2 + (g1 + g2 - 2.0) * p12);
+    }
+    if (t == 0) {
+        const double pw = digamma_d(w1), lw2 = log(w2);
+        consts += (T - 1.0) * (pw - lw2)                                                       // rest of E[log p(V|alpha)]
+                  + s1 * log(s2) - lgamma(s1) + (s1 - 1.0) * (pw - lw2) - s2 * (w1 / w2)       // E[log p(alpha)]
+                  + w1 - lw2 + lgamma(w1) + (1.0 - w1) * pw;                                   // Gamma entropy
+    }
+    __syncthreads();
+    // per output dim: phi = softmax(logits row), mixing, entropy of q(Z) and E[log p(Z|V)]
+    double dsum = 0.0;
+    for (int d = t; d < D; d += 256) {
+        const double *lr = logits + (size_t)((d_offset + d) / mask_size) * T;
+        double mx = lr[0];
+        for (int k = 1; k < T; ++k) mx = fmax(mx, lr[k]);
+        double z = 0.0;
+        for (int k = 0; k < T; ++k) z += exp(lr[k] - mx);
+        const double lz = log(z);
+        double al = 0.0, be = 0.0, ent = 0.0, ev = 0.0, tail = 0.0;
+        for (int k = T - 1; k >= 0; --k) {
+            const double lp = lr[k] - mx - lz, p = exp(lp);
+            if (phi_out) phi_out[(size_t)d * T + k] = p;
+            al += p * aat[k];
+            be += p * bat[k];
+            ent -= p * lp;
+            if (k < T - 1) ev += p * c1[k] + tail * c2[k];     // tail = sum_{j>k} phi_dj  (exclusive reverse cumsum)
+            tail += p;
+        }
+        alpha[d] = al;
+        beta[d] = be;
+        for (int q = 0; q < Q; ++q) {
+            double g = 0.0;
+            for (int k = 0; k < T; ++k) g += exp(lr[k] - mx - lz) * gat[k * Q + q];
+            gamma[(size_t)d * Q + q] = g;
+        }
+        dsum += ev + ent;
+    }
+    dsum = block_sum(dsum, scratch);
+    hyper = block_sum(hyper, scratch);
+    consts = block_sum(consts, scratch);
+    if (t == 0) {
+        scal[0] = -(dsum + (add_constants ? consts : 0.0));   // this rank's share of the DP objective (= -ELBO_DP)
+        scal[1] = hyper;                                       // hyper-prior log-likelihood of the atoms (replicated)
+    }
+}
+
+// objective = DP objective - (f_hat - KL) - hyper-prior   (dp_gp_lvm.py:151-154); red = {sum f_hat, sum dp share}
+__global__ void model_finalize_kernel(const double *__restrict__ red, const double *__restrict__ kl,
+                                      const double *__restrict__ hyper, double *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = red[1] - (red[0] - kl[0]) - hyper[0];
+        out[1] = red[0];
+        out[2] = kl[0];
+        out[3] = red[1];
+        out[4] = hyper[0];
+    }
+}
+
+extern "C" int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
+                                  const double *gamma_atoms_raw, const double *alpha_atoms_raw,
+                                  const double *beta_atoms_raw, const double *s_raw, const double *g1_raw,
+                                  const double *g2_raw, const double *w_raw, double s1, double s2, int add_constants,
+                                  double *gamma, double *alpha, double *beta, double *s, double *phi, double *scal,
+                                  void *stream) {
+    if (D <= 0) return -1;
+    if (T <= 0 || T > PREP_MAX_T) return -2;
+    if (Q <= 0 || Q > DPGP_MAX_Q) return -3;
+    if (N <= 0) return -4;
+    if (d_offset < 0) return -5;
+    if (mask_size <= 0) return -6;
+    if (!logits) return -7;
+    if (!gamma_atoms_raw) return -8;
+    if (!alpha_atoms_raw) return -9;
+    if (!beta_atoms_raw) return -10;
+    if (!s_raw) return -11;
+    if (T > 1 && (!g1_raw || !g2_raw)) return -12;
+    if (!w_raw) return -14;
+    if (!(s1 > 0.0)) return -15;
+    if (!(s2 > 0.0)) return -16;
+    if (!gamma) return -18;
+    if (!alpha) return -19;
+    if (!beta) return -20;
+    if (!s) return -21;
+    if (!scal) return -23;
+    int sblocks = dpgp_ceil_div(N * Q, 256 * 4);
+    if (sblocks > 512) sblocks = 512;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_prepare_kernel, dim3(1 + sblocks), dim3(256), 0, (hipStream_t)stream, D, T, Q, N, d_offset,
+                       mask_size, logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw, g1_raw, g2_raw, w_raw,
+                       s1, s2, add_constants, gamma, alpha, beta, s, phi, scal);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
+extern "C" int dpgp_model_finalize(const double *red, const double *kl, const double *hyper, double *out, void *stream) {
+    if (!red) return -1;
+    if (!kl) return -2;
+    if (!hyper) return -3;
+    if (!out) return -4;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, red, kl, hyper, out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
+extern "C" const char *dpgp_last_hip_error(void) { return hipGetErrorString(dpgp_last_error_slot()); }

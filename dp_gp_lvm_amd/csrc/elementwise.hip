@@ -88,7 +88,7 @@ int launch_gram(int B, int N0, int N1, int Q, const TIN *x0, const TIN *x1, cons
     if (sym) { x1 = x0; N1 = N0; }
     dim3 grid(dpgp_ceil_div(N1, GRAM_T), dpgp_ceil_div(N0, GRAM_T), B);
     size_t lds = sizeof(T) * 2 * GRAM_T * (Q + 1);
-    hipLaunchKernelGGL((gram_kernel<TIN, T>), grid, dim3(256), lds, st, N0, N1, Q, x0, x1, gamma, alpha, beta, flags,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((gram_kernel<TIN, T>), grid, dim3(256), lds, st, N0, N1, Q, x0, x1, gamma, alpha, beta, flags,
                        (T)jitter, out, ld_out, batch_stride, sym);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
@@ -280,7 +280,7 @@ int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *
                            const TIN *alpha, const TIN *y, int ldy, double *part, int ns, hipStream_t st) {
     int nper = dpgp_round_up(dpgp_ceil_div(N, ns), P1Y_NT);
     dim3 grid(ns, dpgp_ceil_div(M, 128), B);
-    hipLaunchKernelGGL((psi1T_y_kernel<TIN, T>), grid, dim3(256), 0, st, N, M, Q, B, z, mu, s, gamma, alpha, y, ldy,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1T_y_kernel<TIN, T>), grid, dim3(256), 0, st, N, M, Q, B, z, mu, s, gamma, alpha, y, ldy,
                        part, nper);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
@@ -344,7 +344,7 @@ template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
                  double *yy_out, hipStream_t st) {
     int blocks = 1 + (yy_out ? dpgp_ceil_div(D, 64) : 0);
-    hipLaunchKernelGGL((kl_yy_kernel<TIN>), dim3(blocks), dim3(256), 0, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((kl_yy_kernel<TIN>), dim3(blocks), dim3(256), 0, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -387,7 +387,7 @@ static int diag_api(int B, int N, const T *alpha, const T *beta, int flags, doub
     CHECK_ARG(B > 0, 1); CHECK_ARG(N > 0, 2); CHECK_ARG(alpha, 3); CHECK_ARG(beta || !(flags & DPGP_FLAG_NOISE), 4);
     CHECK_ARG(out, 7);
     size_t tot = (size_t)B * N;
-    hipLaunchKernelGGL((diag_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((diag_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
                        alpha, beta, flags, (T)jitter, out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
@@ -403,7 +403,7 @@ extern "C" int dpgp_ard_rbf_diag_f64(int B, int N, const double *alpha, const do
 
 template <typename T> static int psi0_api(int B, int N, const T *alpha, T *out, void *stream) {
     CHECK_ARG(B > 0, 1); CHECK_ARG(N > 0, 2); CHECK_ARG(alpha, 3); CHECK_ARG(out, 4);
-    hipLaunchKernelGGL((psi0_kernel<T>), dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, N, alpha, out);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi0_kernel<T>), dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, N, alpha, out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -420,7 +420,7 @@ static int psi1_api(int B, int N, int M, int Q, const T *z, const T *mu, const T
     CHECK_ARG(B > 0, 1); CHECK_ARG(N > 0, 2); CHECK_ARG(M > 0, 3); CHECK_ARG(Q > 0 && Q <= DPGP_MAX_Q, 4);
     CHECK_ARG(z, 5); CHECK_ARG(mu, 6); CHECK_ARG(s, 7); CHECK_ARG(gamma, 8); CHECK_ARG(alpha, 9); CHECK_ARG(out, 10);
     size_t lds = sizeof(T) * (2 * PSI1_NT * Q + PSI1_NT + 64 * (Q + 1));
-    hipLaunchKernelGGL((psi1_kernel<T>), dim3(dpgp_ceil_div(N, PSI1_NT), B), dim3(256), lds, (hipStream_t)stream, N, M,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1_kernel<T>), dim3(dpgp_ceil_div(N, PSI1_NT), B), dim3(256), lds, (hipStream_t)stream, N, M,
                        Q, z, mu, s, gamma, alpha, out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
@@ -450,7 +450,7 @@ static int psi1T_y_api(int B, int N, int M, int Q, const T *z, const T *mu, cons
                                           (hipStream_t)stream);
     if (rc) return rc;
     size_t tot = (size_t)B * M;
-    hipLaunchKernelGGL((sum_slabs_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((sum_slabs_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        tot, ns, (const double *)ws, out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;

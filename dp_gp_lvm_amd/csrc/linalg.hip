@@ -382,7 +382,7 @@ int launch_la_chain(int D, int N, int M, TL *kuu_ws, const TP *psi2_part, int ns
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
         return DPGP_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(D), dim3(256), lds, st, D, N, M, Mp, psi2_part, ns2, v_part, ns1, alpha, beta, yy,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(D), dim3(256), lds, st, D, N, M, Mp, psi2_part, ns2, v_part, ns1, alpha, beta, yy,
                        terms, info, ws, la_chain_ws_elems(M), algo == DPGP_ALGO_PLAIN ? 1 : 0);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void sum_terms_kernel(int D, const double *__r
     if (threadIdx.x == 0) sums[0] = a;
 }
 int launch_sum_terms(int D, const double *terms, double *sums, hipStream_t st) {
-    hipLaunchKernelGGL(sum_terms_kernel, dim3(1), dim3(256), 0, st, D, terms, sums);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(sum_terms_kernel, dim3(1), dim3(256), 0, st, D, terms, sums);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -501,7 +501,7 @@ static int potrf_api(int B, int M, T *a, int *info, void *ws, size_t ws_bytes, i
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
         return DPGP_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, M, Mp, a, info, (T *)ws,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, M, Mp, a, info, (T *)ws,
                        algo == DPGP_ALGO_PLAIN ? 1 : 0);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
@@ -534,7 +534,7 @@ static int trsm_api(int B, int M, int K, const T *l, T *rhs, void *ws, size_t ws
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
         return DPGP_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, M, K, Mp, Kp, l, rhs, (T *)ws,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, M, K, Mp, Kp, l, rhs, (T *)ws,
                        algo == DPGP_ALGO_PLAIN ? 1 : 0);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;

@@ -29,36 +29,52 @@ __device__ __forceinline__ void patch_from_index(int p, int &pi, int &pj) {
     pj = p - i * (i + 1) / 2;
 }
 
+// LDS geometry shared by the kernel and the host-side size computation
+template <typename T, int KS, int PT> struct Psi2Lds {
+    static constexpr int PS = 16 * PT;                       // patch edge
+    static constexpr int KP = 4 * KS;                        // K padded to the MFMA step
+    static constexpr int ZLD = ((KP / 4) & 1) ? KP : KP + 4; // z row stride: multiple of 4, odd number of 16-B slots
+    static constexpr int PLD = 2 * PS + 4;                   // P row stride
+    static constexpr int NR = 8;                             // rows (n) per wave-private chunk
+    static constexpr int WSZ = 3 * NR * KP + 2 * NR * KP / 2 + NR * PLD;   // xa, w4, tm, (cn + cr), pm  per wave
+    static constexpr int OFF_W = 2 * PS * ZLD + 2 * (DPGP_MAX_Q + 2);      // start of the per-wave regions
+    static constexpr int FILL = OFF_W + 4 * WSZ;
+    static constexpr int RED = 2 * PS * ZLD + 2 * (DPGP_MAX_Q + 2) + 4 * PT * 4 * 64;
+    static constexpr int ELEMS = FILL > RED ? FILL : RED;
+};
+
 // DIAG is a compile-time property of the patch (pi == pj: only tiles J <= I are computed) so that the MFMA / exp
 // sequences are straight-line code.  (With a run-time `diag` predicate around each MFMA, hipcc 7.2 shuffled the
 // accumulators through AGPRs and overwrote a SrcC register of an in-flight v_mfma_f32_16x16x4_f32 with
 // v_accvgpr_write_b32 with no wait states in between: one register of one tile came out wrong on the GPU.)
+//
+// The four waves of the workgroup are AUTONOMOUS in the main loop: wave w owns the observations n = nbeg + w + 4 j and
+// a private LDS region; for every chunk of NR of its rows it (A) computes the per-(n,q) factors, (B) the P[n, .] rows
+// of both column blocks, (C) runs the MFMA + exp2 accumulation.  No workgroup barrier separates the phases, so the
+// waves drift apart and one wave's VALU phases overlap another wave's matrix-core phase on the same SIMD.
 template <typename TIN, typename T, int KS, int PT, bool DIAG>
 __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN *__restrict__ z,
                                            const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                            const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
                                            T *__restrict__ part, int Mp, int n_per_split, int pi, int pj,
                                            unsigned char *smem_raw) {
-    constexpr int PS = 16 * PT;        // patch edge
-    constexpr int KP = 4 * KS;         // padded K
-    constexpr int PLD = 2 * PS + 4;    // row stride of the P tile (breaks the power-of-two stride)
+    typedef Psi2Lds<T, KS, PT> G;
+    constexpr int PS = G::PS, KP = G::KP, ZLD = G::ZLD, PLD = G::PLD, NR = G::NR;
     typedef typename Mfma<T>::acc_t acc_t;
-    T *zs = reinterpret_cast<T *>(smem_raw);        // [2*PS][KP+1] centred z rows: m-block then m'-block (0 beyond Q / M)
-    T *xa = zs + 2 * PS * (KP + 1);                  // [NT][KP]     X[n,k] (0 for k >= Q)
-    T *pm = xa + PSI2_NT * KP;                       // [NT][PLD]    P[n, m-block | m'-block]
-    T *w4 = pm + PSI2_NT * PLD;                      // [NT][Q]      1/4 w log2e
-    T *tm = w4 + PSI2_NT * DPGP_MAX_Q;               // [NT][Q]      2 (mu - c)
-    T *cn = tm + PSI2_NT * DPGP_MAX_Q;               // [NT][Q]      (1/2 w (mu-c)^2 - 1/4 log den) log2e
-    T *zc = cn + PSI2_NT * DPGP_MAX_Q;               // [Q]          column means of z
-    T *gq = zc + DPGP_MAX_Q + 2;                     // [Q]          gamma_b
-    // the cross-wave reduction at the end reuses the buffer from `xa` on: 4 waves * PT tiles * 4 regs * 64 lanes
-
+    T *zs = reinterpret_cast<T *>(smem_raw);        // [2*PS][ZLD] centred z rows: m-block then m'-block (0 beyond Q / M)
+    T *zc = zs + 2 * PS * ZLD;                       // [Q]  column means of z
+    T *gq = zc + DPGP_MAX_Q + 2;                     // [Q]  gamma_b
     const int b = blockIdx.y, sp = blockIdx.z;
-    constexpr bool diag = DIAG;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
     const int m_base = pi * PS, mp_base = pj * PS;
+    T *wp = zs + G::OFF_W + wv * G::WSZ;             // this wave's private region
+    T *xa = wp;                                      // [NR][KP]  X[n,k]  (0 for k >= Q)
+    T *w4 = xa + NR * KP;                            // [NR][KP]  1/4 w log2e      (0 for k >= Q)
+    T *tm = w4 + NR * KP;                            // [NR][KP]  2 (mu - c)
+    T *cn = tm + NR * KP;                            // [NR][KP]  (1/2 w (mu-c)^2 - 1/4 log den) log2e
+    T *pm = cn + NR * KP;                            // [NR][PLD] P[n, m-block | m'-block]
 
-    // ---- prologue: gamma_b, z column means, centred z rows of both blocks -----------------------------------
+    // ---- prologue (workgroup-wide): gamma_b, z column means, centred z rows of both blocks -----------------------
     if (t < Q) {
         gq[t] = (T)gamma[(size_t)b * Q + t];
         double a = 0.0;
@@ -66,12 +82,11 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
         zc[t] = (T)(a / (double)M);
     }
     __syncthreads();
-    for (int e = t; e < 2 * PS * (KP + 1); e += 256) {
-        int r = e / (KP + 1), k = e - r * (KP + 1);
+    for (int e = t; e < 2 * PS * ZLD; e += 256) {
+        int r = e / ZLD, k = e - r * ZLD;
         int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
         zs[e] = (k < Q && m < M) ? (T)z[(size_t)m * Q + k] - zc[k] : (T)0;
     }
-    for (int e = t; e < PSI2_NT * KP; e += 256) xa[e] = (T)0;
     __syncthreads();
 
     // ---- per-lane constant MFMA operands ---------------------------------------------------------------------
@@ -86,8 +101,8 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
         cPb[ks] = (k == Q + 1) ? (T)1 : (T)0;
 #pragma unroll
         for (int I = 0; I < PT; ++I) {
-            zA[I][ks] = zs[(16 * I + li) * (KP + 1) + k];                    // already 0 for k >= Q
-            zB[I][ks] = (k == Q) ? (T)1 : zs[(PS + 16 * I + li) * (KP + 1) + k];
+            zA[I][ks] = zs[(16 * I + li) * ZLD + k];                         // already 0 for k >= Q
+            zB[I][ks] = (k == Q) ? (T)1 : zs[(PS + 16 * I + li) * ZLD + k];
         }
     }
 
@@ -98,46 +113,76 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
         for (int J = 0; J < PT; ++J) acc[I][J] = (acc_t){0, 0, 0, 0};
 
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
-    const int pcols = diag ? PS : 2 * PS;
-    const int pb_off = diag ? 0 : PS;
+    constexpr int pb_off = DIAG ? 0 : PS;
+    constexpr int NCOL = DIAG ? PS : 2 * PS;         // columns whose P rows are needed (m-block, then m'-block)
+    constexpr int CPL = (NCOL + 63) / 64;            // ... per lane
 
-    for (int n0 = nbeg; n0 < nend; n0 += PSI2_NT) {
-        __syncthreads();   // previous tile's readers are done with xa/pm/w4/tm/cn
-        // phase 1: per-(n,q) factors
-        for (int e = t; e < PSI2_NT * Q; e += 256) {
-            const int r = e / Q, q = e - r * Q, n = n0 + r;
-            if (n < nend) {
-                const T g = gq[q];
-                const T sv = (T)s[(size_t)n * Q + q];
-                const T mc = (T)mu[(size_t)n * Q + q] - zc[q];
-                const T den = (T)2 * g * sv + (T)1;
-                const T w = g / den;
-                xa[r * KP + q] = (T)(-0.5 * DPGP_LOG2E) * w;
-                w4[r * DPGP_MAX_Q + q] = (T)(0.25 * DPGP_LOG2E) * w;
-                tm[r * DPGP_MAX_Q + q] = (T)2 * mc;
-                cn[r * DPGP_MAX_Q + q] = (T)DPGP_LOG2E * ((T)0.5 * w * mc * mc - (T)0.25 * dpgp_log(den));
-            } else {   // rows past the end of this split contribute exp2(-huge) = 0
-                xa[r * KP + q] = (T)0;
-                w4[r * DPGP_MAX_Q + q] = (T)0;
-                tm[r * DPGP_MAX_Q + q] = (T)0;
-                cn[r * DPGP_MAX_Q + q] = (T)-1.0e30;
+    for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {     // this wave's chunk: rows nc, nc+4, ..., nc+4(NR-1)
+        // ---- phase A: per-(row,k) factors ----
+#pragma unroll
+        for (int e0 = 0; e0 < NR * KP; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < NR * KP) {
+                const int r = e / KP, k = e - r * KP, n = nc + 4 * r;
+                T vx = 0, vw = 0, vt = 0, vc = 0;
+                if (k < Q) {
+                    if (n < nend) {
+                        const T g = gq[k];
+                        const T sv = (T)s[(size_t)n * Q + k];
+                        const T mc = (T)mu[(size_t)n * Q + k] - zc[k];
+                        const T den = (T)2 * g * sv + (T)1;
+                        const T w = g / den;
+                        vx = (T)(-0.5 * DPGP_LOG2E) * w;
+                        vw = (T)(0.25 * DPGP_LOG2E) * w;
+                        vt = (T)2 * mc;
+                        vc = (T)DPGP_LOG2E * ((T)0.5 * w * mc * mc - (T)0.25 * dpgp_log(den));
+                    } else {
+                        vc = (T)-1.0e30;             // rows past the end of this split contribute exp2(-huge) = 0
+                    }
+                }
+                xa[e] = vx; w4[e] = vw; tm[e] = vt; cn[e] = vc;
             }
         }
-        __syncthreads();
-        // phase 2: P[n, m] for the rows of both blocks
-        for (int e = t; e < PSI2_NT * pcols; e += 256) {
-            const int r = e / pcols, c = e - r * pcols;
-            const T *zr = zs + c * (KP + 1);
-            T p = 0;
-            for (int q = 0; q < Q; ++q) {
-                const T d = zr[q] - tm[r * DPGP_MAX_Q + q];
-                p += cn[r * DPGP_MAX_Q + q] - w4[r * DPGP_MAX_Q + q] * d * d;
-            }
-            pm[r * PLD + c] = p;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // row sums C_r of cn (lanes 0..NR-1), kept in registers across the overwrite
+        T crv = 0;
+        if (lane < NR) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) crv += cn[lane * KP + k];
         }
-        __syncthreads();
-        // phase 3: each wave takes every 4th n of the tile
-        for (int r = wv; r < PSI2_NT; r += 4) {
+        // ---- phase B: P[r, c] = C_r - sum_k w4_rk (z_ck - tm_rk)^2 for this lane's column of each block ----
+        T zr[CPL][KP];
+#pragma unroll
+        for (int h = 0; h < CPL; ++h)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) zr[h][k] = (h * 64 + lane < NCOL) ? zs[(h * 64 + lane) * ZLD + k] : (T)0;
+#pragma unroll 2
+        for (int r = 0; r < NR; ++r) {
+            const T c0 = __shfl(crv, r, 64);
+            T p[CPL];
+#pragma unroll
+            for (int h = 0; h < CPL; ++h) p[h] = c0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const T wk = w4[r * KP + k], tk = tm[r * KP + k];
+#pragma unroll
+                for (int h = 0; h < CPL; ++h) {
+                    const T d = zr[h][k] - tk;
+                    p[h] = fma(-wk * d, d, p[h]);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < CPL; ++h)
+                if (h * 64 + lane < NCOL) pm[r * PLD + h * 64 + lane] = p[h];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase C: per row, E = A_n B_n on the matrix cores, psi2 += exp2(E) ----
+#pragma unroll 1
+        for (int r = 0; r < NR; ++r) {
             T a[PT][KS], bq[PT][KS];
             T xk[KS];
 #pragma unroll
@@ -169,19 +214,20 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int J = 0; J < PT; ++J)
-                        if (!(diag && J > I)) c[J] = Mfma<T>::mma(a[I][ks], bq[J][ks], c[J]);
+                        if (!(DIAG && J > I)) c[J] = Mfma<T>::mma(a[I][ks], bq[J][ks], c[J]);
 #pragma unroll
                 for (int J = 0; J < PT; ++J)
-                    if (!(diag && J > I)) {
+                    if (!(DIAG && J > I)) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) acc[I][J][v] += dpgp_exp2(c[J][v]);
                     }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // next chunk's phase A overwrites what phase C read
     }
 
     // ---- epilogue: sum the 4 waves' accumulators through LDS, apply alpha^2 exp2(beta_mm'), store the lower tiles ----
-    T *red = xa;   // [4 waves][PT][4][64]
+    T *red = zs + G::OFF_W;   // [4 waves][PT][4][64] (reuses the per-wave regions)
     const T al = (T)alpha[b];
     const T al2 = al * al;
     T *out = part + ((size_t)sp * B + b) * (size_t)Mp * Mp;
@@ -195,7 +241,7 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
         __syncthreads();
         for (int e = t; e < PT * 256; e += 256) {
             const int J = e >> 8, v = (e >> 6) & 3, l = e & 63;
-            if (diag && J > I) continue;
+            if (DIAG && J > I) continue;
             T sum = 0;
 #pragma unroll
             for (int w_ = 0; w_ < 4; ++w_) sum += red[((w_ * PT + J) * 4 + v) * 64 + l];
@@ -204,7 +250,7 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
             if (m < Mp && mp < Mp) {
                 T val = 0;
                 if (m < M && mp < M) {
-                    const T *z1 = zs + row * (KP + 1), *z2 = zs + (PS + col) * (KP + 1);
+                    const T *z1 = zs + row * ZLD, *z2 = zs + (PS + col) * ZLD;
                     T bsum = 0;
                     for (int q = 0; q < Q; ++q) {
                         const T d = z1[q] - z2[q];
@@ -302,13 +348,8 @@ template <typename T> struct Psi2Cfg;
 template <> struct Psi2Cfg<float> { static constexpr int PT = 4; };
 template <> struct Psi2Cfg<double> { static constexpr int PT = 2; };
 
-template <typename T> static size_t psi2_lds_bytes(int KS) {
-    constexpr int PT = Psi2Cfg<T>::PT, PS = 16 * PT, PLD = 2 * PS + 4;
-    const int KP = 4 * KS;
-    size_t fill = (size_t)2 * PS * (KP + 1) + (size_t)PSI2_NT * KP + (size_t)PSI2_NT * PLD +
-                  3 * (size_t)PSI2_NT * DPGP_MAX_Q + 2 * (DPGP_MAX_Q + 2);
-    size_t red = (size_t)2 * PS * (KP + 1) + (size_t)4 * PT * 4 * 64;
-    return sizeof(T) * (fill > red ? fill : red);
+template <typename T, int KS> static size_t psi2_lds_bytes() {
+    return sizeof(T) * (size_t)Psi2Lds<T, KS, Psi2Cfg<T>::PT>::ELEMS;
 }
 
 int psi2_nsplit(int B, int N, int M) {
@@ -329,14 +370,14 @@ static int launch_psi2_ks(int B, int N, int M, int Q, const TIN *z, const TIN *m
     const int nps = dpgp_ceil_div(Mp, PS);
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
     dim3 grid(nps * (nps + 1) / 2, B, ns);
-    size_t lds = psi2_lds_bytes<T>(KS);
+    size_t lds = psi2_lds_bytes<T, KS>();
     auto kern = psi2_mfma_kernel<TIN, T, KS, PT>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -351,7 +392,7 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
                           hipSuccess)
             return DPGP_ERR_LAUNCH;
         dim3 grid(dpgp_ceil_div(Mp * Mp, 256), B);
-        hipLaunchKernelGGL((psi2_plain_kernel<TIN, T>), grid, dim3(256), 0, st, N, M, Q, z, mu, s, gamma, alpha, part,
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_plain_kernel<TIN, T>), grid, dim3(256), 0, st, N, M, Q, z, mu, s, gamma, alpha, part,
                            Mp);
         DPGP_LAUNCH_CHECK();
         return DPGP_OK;
@@ -401,7 +442,7 @@ static int psi2_api(int B, int N, int M, int Q, const T *z, const T *mu, const T
     int rc = launch_psi2_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, (T *)ws, ns, algo, (hipStream_t)stream);
     if (rc) return rc;
     size_t tot = (size_t)B * M * M;
-    hipLaunchKernelGGL((psi2_finish_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_finish_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        B, M, Mp, ns, (const T *)ws, out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;

@@ -1,0 +1,218 @@
+"""
+DP-GP-LVM — mirror of the reference's ``dp_gp_lvm`` factory (src/models/dp_gp_lvm.py:22-510) with the same signature,
+assertions and accessors; ``.objective`` is evaluated by the HIP library (libdpgp_hip.so):
+
+    dpgp_model_prepare  ->  dpgp_elbo_fhat  ->  [one packed all-reduce when D is sharded]  ->  dpgp_model_finalize
+
+i.e. eight kernel launches and at most one collective per evaluation, with no host arithmetic in between.
+Where the reference returns lazy TensorFlow nodes, accessors here return torch tensors computed from the current
+parameter values, and ``objective`` re-evaluates on every access.
+
+Multi-GPU: the per-output-dimension terms are independent given (q(X), Z, atoms), so the D outputs are sharded over the
+ranks of ``process_group`` (rank r keeps columns r*D/W .. (r+1)*D/W of Y and the matching rows of phi); q(X), Z and the
+atoms are replicated.  The only exchange per evaluation is a sum all-reduce of the two scalars (f_hat, DP objective).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import _lib, ops
+from ..kernels.interfaces.kernel import KernelHyperparameters
+from ..kernels.rbf_kernel import k_ard_rbf
+from ..utils.constants import GP_LVM_DEFAULT_LATENT_DIMENSIONS, GP_LVM_DEFAULT_NUM_INDUCING_POINTS, \
+    DP_DEFAULT_TRUNCATION_LEVEL, DP_DEFAULT_ALPHA_PRIOR_PARAMS, GP_INIT_GAMMA, GP_INIT_ALPHA, GP_INIT_BETA, \
+    GP_DEFAULT_JITTER
+from ..utils.expressions import principal_component_analysis as pca
+from ..utils.types import TORCH_DTYPE, create_positive_variable, default_device
+from .dirichlet_process import dirichlet_process
+from .interfaces.trainable import Trainable
+
+
+def shard_bounds(num_dimensions, rank, world_size):
+    """Contiguous, balanced split of the D output dims: rank r owns [lo, hi)."""
+    base, rem = divmod(num_dimensions, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def dp_gp_lvm(y_train,
+              num_latent_dims=GP_LVM_DEFAULT_LATENT_DIMENSIONS,
+              num_inducing_points=GP_LVM_DEFAULT_NUM_INDUCING_POINTS,
+              truncation_level=DP_DEFAULT_TRUNCATION_LEVEL,
+              alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
+              mask_size=1,
+              device=None, precision='mixed', process_group=None, initial_values=None):
+    """
+    :param y_train: [N x D] numpy array, columns normalised to zero mean / unit variance (dp_gp_lvm.py:30-32).
+    :param num_latent_dims: Q.  :param num_inducing_points: M.  :param truncation_level: T.
+    :param alpha_prior_params: Gamma prior (s_1, s_2) on the DP concentration.  :param mask_size: see the reference.
+    Extensions (keyword-only in spirit, all optional):
+    :param device: torch device of the parameters (default: current GPU).
+    :param precision: 'mixed' (psi-statistics fp32 on the matrix cores, Cholesky chain fp64), 'f64' or 'f32'.
+    :param process_group: torch.distributed group over which the D output dims are sharded (None: single GPU).
+    :param initial_values: dict of post-initialisation parameter VALUES (x_mean, x_var, x_u, phi_logits, gamma_atoms,
+           alpha_atoms, beta_atoms, gamma_1, gamma_2, w_1, w_2) that replace the random/PCA initialisation — used by the
+           parity tests and the benchmark, which must not depend on PCA sign conventions or NumPy's global RNG.
+    """
+    num_samples, num_dimensions = np.shape(y_train)
+    assert 0 < num_latent_dims <= num_dimensions, \
+        'Number of latent dimensions must be postive and less than the dimensionality of the observed data.'
+    assert 0 < num_inducing_points <= num_samples, \
+        'Number of inducing points must be positive and less than the number of observations in the observed data.'
+    assert 0 < truncation_level <= min(num_samples, num_dimensions), \
+        'The truncation level must be positive and less than the dimensionality of the observed data and ' \
+        'less than the number of observations.'
+    assert precision in _lib.PREC, 'precision must be one of %s' % sorted(_lib.PREC)
+    device = default_device() if device is None else torch.device(device)
+    iv = dict(initial_values or {})
+
+    def _t(a):
+        return torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=TORCH_DTYPE, device=device).contiguous()
+
+    def _raw_pos(name, init, shape):
+        if name in iv:
+            v = np.asarray(iv[name], dtype=np.float64).reshape(shape)
+            return _t(np.log(np.expm1(v)))
+        return create_positive_variable(init, shape, device=device)
+
+    # ---- variational parameters (dp_gp_lvm.py:62-74) ----
+    if 'x_mean' in iv:
+        x_init = np.asarray(iv['x_mean'], dtype=np.float64)
+    else:
+        x_init = pca(np.asarray(y_train), num_latent_dimensions=num_latent_dims)
+    x_mean = _t(x_init)                                                        # [N x Q]
+    x_var_raw = _raw_pos('x_var', 1.0, (num_samples, num_latent_dims))         # softplus(raw) = diag of q(X) covariance
+    if 'x_u' in iv:
+        x_u = _t(iv['x_u'])
+    else:
+        x_u = _t(np.random.permutation(x_init)[:num_inducing_points] +
+                 np.random.normal(loc=0.0, scale=0.01, size=(num_inducing_points, num_latent_dims)))   # [M x Q]
+
+    # ---- DP over the D output dims (:77-80) and the atoms of the kernel hyper-parameters (:84-94) ----
+    dp_model = dirichlet_process(num_samples=num_dimensions, alpha_prior_params=alpha_prior_params,
+                                 truncation_level=truncation_level, mask_size=mask_size, device=device)
+    for key, name in (('logits', 'phi_logits'), ('gamma_1', 'gamma_1'), ('gamma_2', 'gamma_2')):
+        if name in iv:
+            v = np.asarray(iv[name], dtype=np.float64)
+            dp_model.raw[key].copy_(_t(v if key == 'logits' else np.log(np.expm1(v))).reshape(dp_model.raw[key].shape))
+    for i, name in enumerate(('w_1', 'w_2')):
+        if name in iv:
+            dp_model.raw['w'][i] = float(np.log(np.expm1(float(iv[name]))))
+    gamma_atoms_raw = _raw_pos('gamma_atoms', GP_INIT_GAMMA, (truncation_level, num_latent_dims))
+    sig_var_atoms_raw = _raw_pos('alpha_atoms', GP_INIT_ALPHA, (truncation_level, 1))
+    beta_atoms_raw = _raw_pos('beta_atoms', GP_INIT_BETA, (truncation_level, 1))
+
+    # ---- D-sharding ----
+    if process_group is not None:
+        import torch.distributed as dist
+        rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    else:
+        dist, rank, world = None, 0, 1
+    d_lo, d_hi = shard_bounds(num_dimensions, rank, world)
+    d_local = d_hi - d_lo
+    assert d_local > 0, 'more ranks than output dimensions'
+    y_local = _t(np.asarray(y_train)[:, d_lo:d_hi])                            # [N x D_local]
+
+    # ---- device buffers of one objective evaluation (allocated once) ----
+    f64 = dict(dtype=TORCH_DTYPE, device=device)
+    buf = dict(gamma=torch.empty((d_local, num_latent_dims), **f64), alpha=torch.empty((d_local, 1), **f64),
+               beta=torch.empty((d_local, 1), **f64), s=torch.empty((num_samples, num_latent_dims), **f64),
+               phi=torch.empty((d_local, truncation_level), **f64), scal=torch.zeros(2, **f64),
+               red=torch.zeros(2, **f64), out=torch.zeros(5, **f64))
+    workspace = ops.ElboWorkspace(d_local, num_samples, num_inducing_points, num_latent_dims, precision, device)
+    s_1, s_2 = dp_model.prior
+
+    def evaluate(events=None):
+        """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior)."""
+        lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+        r = dp_model.raw
+        _lib.check(lib.dpgp_model_prepare(
+            d_local, truncation_level, num_latent_dims, num_samples, d_lo, mask_size, r['logits'].data_ptr(),
+            gamma_atoms_raw.data_ptr(), sig_var_atoms_raw.data_ptr(), beta_atoms_raw.data_ptr(), x_var_raw.data_ptr(),
+            r['gamma_1'].data_ptr(), r['gamma_2'].data_ptr(), r['w'].data_ptr(), s_1, s_2, 1 if rank == 0 else 0,
+            buf['gamma'].data_ptr(), buf['alpha'].data_ptr(), buf['beta'].data_ptr(), buf['s'].data_ptr(),
+            buf['phi'].data_ptr(), buf['scal'].data_ptr(), st), 'dpgp_model_prepare')
+        _, sums, _ = ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
+                                   jitter=GP_DEFAULT_JITTER, prec=precision, workspace=workspace, events=events)
+        red = buf['red']
+        red[0:1].copy_(sums[0:1])
+        red[1:2].copy_(buf['scal'][0:1])
+        if world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=process_group)    # the only exchange: 2 fp64 scalars
+        _lib.check(lib.dpgp_model_finalize(red.data_ptr(), sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
+                                           buf['out'].data_ptr(), st), 'dpgp_model_finalize')
+        return buf['out']
+
+    def _mixed():
+        phi = dp_model.assignments                                               # [D x T], all output dims
+        return (phi @ F.softplus(gamma_atoms_raw), phi @ F.softplus(sig_var_atoms_raw), phi @ F.softplus(beta_atoms_raw))
+
+    class DP_GP_LVM(Trainable):
+        """Accessors as in the reference (dp_gp_lvm.py:161-231,502-508)."""
+        raw = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw,
+                   beta_atoms=beta_atoms_raw, **{'dp_' + k: v for k, v in dp_model.raw.items()})
+        shard = (d_lo, d_hi)
+
+        @property
+        def assignments(self):
+            return dp_model.assignments
+
+        @property
+        def dp(self):
+            return dp_model
+
+        @property
+        def dp_atoms(self):
+            return F.softplus(gamma_atoms_raw), F.softplus(sig_var_atoms_raw), F.softplus(beta_atoms_raw)
+
+        @property
+        def kernel(self):
+            g, a, b = _mixed()
+            return k_ard_rbf(gamma=g, alpha=a, beta=b)                           # batch size D (:105)
+
+        @property
+        def ard_weights(self):
+            return _mixed()[0]
+
+        @property
+        def signal_variance(self):
+            return _mixed()[1]
+
+        @property
+        def noise_precision(self):
+            return _mixed()[2]
+
+        @property
+        def inducing_input(self):
+            return x_u
+
+        @property
+        def q_x(self):
+            return x_mean, torch.diag_embed(F.softplus(x_var_raw))               # mean [N x Q], covariance [N x Q x Q]
+
+        @property
+        def objective(self):
+            """dp.objective - (f_hat - KL) - hyper-prior (dp_gp_lvm.py:154): 0-d fp64 device tensor."""
+            return evaluate()[0].clone()
+
+        @property
+        def objective_terms(self):
+            """(objective, f_hat, KL, DP objective, hyper-prior log-likelihood) of one evaluation, as a device tensor."""
+            return evaluate().clone()
+
+        @property
+        def per_dimension_terms(self):
+            """[D_local x 5] f_hat terms and the Cholesky info flags of the last evaluation."""
+            return workspace.terms, workspace.info
+
+        evaluate_ = staticmethod(evaluate)
+
+        @staticmethod
+        def predict_new_latent_variables(y_test, use_pca=False):
+            raise NotImplementedError('prediction paths (dp_gp_lvm.py:233-500) are SURVEY.md §8(f) row 2: not built yet')
+
+        @staticmethod
+        def predict_missing_data(y_test):
+            raise NotImplementedError('prediction paths (dp_gp_lvm.py:233-500) are SURVEY.md §8(f) row 2: not built yet')
+
+    return DP_GP_LVM()

@@ -200,7 +200,7 @@ class ElboWorkspace:
         self.info = torch.empty(d, dtype=torch.int32, device=device)
 
 
-def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None):
+def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None, events=None):
     """
     The fused per-output ELBO reduction of dp_gp_lvm.py:108-148 for the D output dims in ``y`` [N,D] (a column slice of
     the full data when D is sharded over GPUs).  All inputs fp64 device tensors.
@@ -218,9 +218,10 @@ def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='
     assert mu.shape == (n, q) and s.shape == (n, q) and gamma.shape == (d, q)
     w = workspace if workspace is not None else ElboWorkspace(d, n, m, q, prec, y.device)
     assert w.shape == (d, n, m, q) and w.prec == prec, 'workspace was sized for another problem'
-    _lib.check(_lib.lib().dpgp_elbo_fhat(d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(),
-                                         s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(),
-                                         float(jitter), _lib.PREC[prec], _lib.ALGO[algo], w.terms.data_ptr(),
-                                         w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes, _stream()),
-               'dpgp_elbo_fhat')
+    ev0, ev1 = events if events is not None else (None, None)     # optional hipEvent handles around the psi2 kernel
+    _lib.check(_lib.lib().dpgp_elbo_fhat_timed(d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(),
+                                               s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(),
+                                               float(jitter), _lib.PREC[prec], _lib.ALGO[algo], w.terms.data_ptr(),
+                                               w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes,
+                                               _stream(), ev0, ev1), 'dpgp_elbo_fhat')
     return w.terms, w.sums, w.info

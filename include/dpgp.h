@@ -45,6 +45,8 @@ extern "C" {
 #define DPGP_PREC_F64 2   /* everything fp64                                                   */
 
 int dpgp_version(void);
+/* text of the HIP error behind the last DPGP_ERR_LAUNCH returned to the calling thread (diagnostics) */
+const char *dpgp_last_hip_error(void);
 
 /* ---- Kernel.covariance_matrix (rbf_kernel.py:58-93): out[B,N0,N1] = alpha_b exp(-1/2 sum_q gamma_bq (x0_iq-x1_jq)^2)
  *      x1 == NULL means input_1 is None: N1 is ignored (= N0) and noise/jitter flags apply on the diagonal.          */
@@ -118,6 +120,33 @@ int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const d
                    const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                    int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
                    void *stream);
+/* same, with two caller-created hipEvent_t (void*) recorded on `stream` immediately before / after the psi2 kernel, so a
+ * harness can time the dominant kernel inside its timed region; either may be NULL.                                  */
+int dpgp_elbo_fhat_timed(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                         const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
+                         int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
+                         void *stream, void *ev_psi2_begin, void *ev_psi2_end);
+/* hipEvent helpers for hosts without their own HIP binding */
+void *dpgp_event_create(void);
+void dpgp_event_destroy(void *event);
+float dpgp_event_elapsed_ms(void *begin, void *end);
+
+/* ---- model-level glue of dp_gp_lvm(...).objective that is O(D T + N Q) (all fp64):
+ *   dpgp_model_prepare : from the RAW variational parameters (softplus / softmax parameterisation of utils/types.py:40-57,
+ *     dirichlet_process.py:39-59) of the D output dims resident on this GPU (global index d_offset + d; logits row
+ *     (d_offset+d)/mask_size) compute  phi[D,T] (optional), gamma[D,Q] = phi gamma_atoms, alpha[D], beta[D]
+ *     (dp_gp_lvm.py:100-102), s[N,Q] = softplus(s_raw), and
+ *       scal[0] = this GPU's share of the DP objective (dirichlet_process.py:64-88; the D-independent terms are added
+ *                 iff add_constants != 0, i.e. on exactly one rank),
+ *       scal[1] = hyper-prior log-likelihood of the atoms (dp_gp_lvm.py:96-98).
+ *   dpgp_model_finalize: red[2] = {f_hat, DP objective} (summed over GPUs), kl[1], hyper[1] ->
+ *       out[5] = {objective (dp_gp_lvm.py:154), f_hat, KL, DP objective, hyper-prior}.                               */
+int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
+                       const double *gamma_atoms_raw, const double *alpha_atoms_raw, const double *beta_atoms_raw,
+                       const double *s_raw, const double *g1_raw, const double *g2_raw, const double *w_raw, double s1,
+                       double s2, int add_constants, double *gamma, double *alpha, double *beta, double *s, double *phi,
+                       double *scal, void *stream);
+int dpgp_model_finalize(const double *red, const double *kl, const double *hyper, double *out, void *stream);
 
 #ifdef __cplusplus
 }

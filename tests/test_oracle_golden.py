@@ -1,0 +1,121 @@
+"""
+CPU tests (no GPU): the oracle (oracle/dpgp_oracle.py, oracle/dpgp_oracle.c) against the golden vectors that
+oracle/gen_golden.py produced from the reference's own source and known-answer functions (tests/golden/*.npz).
+The oracle is test infrastructure; this file is what pins it.  Tolerance: rtol 1e-10 (fp64 vs fp64, different
+summation order / LAPACK vs hand-written Cholesky).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import dpgp_oracle as orc
+from oracle.c_oracle import COracle
+from dp_gp_lvm_amd.utils.synthetic import make_problem
+
+RT = 1e-10
+
+
+@pytest.fixture(scope='module', params=[False, True], ids=['c-strict', 'c-fast'])
+def corc(request):
+    return COracle(fast=request.param)
+
+
+@pytest.mark.parametrize('fixture', ['kernel_b1', 'kernel_b7'])
+def test_kernel_operators_numpy_oracle(fixture):
+    g = golden(fixture)
+    gam, al, be = g['gamma'], g['alpha'], g['beta']
+    combos = {'xx': ('x0', None), 'x01': ('x0', 'x1'), 'x10': ('x1', 'x0'), 'uu_same': ('x_u', 'x_u'), 'uu': ('x_u', None)}
+    for tag, (a, c) in combos.items():
+        for noise in (0, 1):
+            for jit in (0, 1):
+                got = orc.ard_rbf_gram(g[a], None if c is None else g[c], gam, al, be, bool(noise), bool(jit))
+                np.testing.assert_allclose(got, g['gram_%s_n%d_j%d' % (tag, noise, jit)], rtol=RT)
+    # the reference semantics the unit tests pin: noise/jitter are ignored whenever input_1 is passed (rbf_kernel.py:80,86)
+    np.testing.assert_array_equal(g['gram_uu_same_n1_j1'], g['gram_uu_same_n0_j0'])
+    assert not np.array_equal(g['gram_uu_n1_j1'], g['gram_uu_n0_j0'])
+    for noise in (0, 1):
+        for jit in (0, 1):
+            np.testing.assert_allclose(orc.ard_rbf_diag(g['x0'].shape[0], al, be, bool(noise), bool(jit)),
+                                       g['diag_n%d_j%d' % (noise, jit)], rtol=RT)
+    np.testing.assert_allclose(orc.psi0(g['x_mean'].shape[0], al), g['psi_0'], rtol=RT)
+    np.testing.assert_allclose(orc.psi1(g['x_u'], g['x_mean'], g['x_var'], gam, al), g['psi_1'], rtol=RT)
+    np.testing.assert_allclose(orc.psi2(g['x_u'], g['x_mean'], g['x_var'], gam, al), g['psi_2'], rtol=RT)
+
+
+@pytest.mark.parametrize('fixture', ['kernel_b1', 'kernel_b7'])
+def test_kernel_operators_c_oracle(fixture, corc):
+    g = golden(fixture)
+    gam, al, be = g['gamma'], g['alpha'], g['beta']
+    for tag, (a, c) in {'xx': ('x0', None), 'x01': ('x0', 'x1'), 'uu': ('x_u', None)}.items():
+        for noise in (0, 1):
+            for jit in (0, 1):
+                got = corc.gram(g[a], None if c is None else g[c], gam, al, be, bool(noise), bool(jit), nthreads=2)
+                np.testing.assert_allclose(got, g['gram_%s_n%d_j%d' % (tag, noise, jit)], rtol=RT)
+    z, mu, s = g['x_u'], g['x_mean'], g['x_var']
+    np.testing.assert_allclose(corc.psi1(z, mu, s, gam, al, nthreads=2), g['psi_1'], rtol=RT)
+    np.testing.assert_allclose(corc.psi2(z, mu, s, gam, al, nthreads=2), g['psi_2'], rtol=RT)                 # streamed form
+    np.testing.assert_allclose(corc.psi2(z, mu, s, gam, al, nthreads=2, literal=True), g['psi_2'], rtol=RT)   # literal formula
+
+
+@pytest.mark.parametrize('fixture', ['dpgplvm_50_10_25_3_T8', 'dpgplvm_T1_d5', 'dpgplvm_d2', 'plumbing_100_12_20_4',
+                                     'script_100_20_25_10'])
+def test_model_objective_oracles(fixture, corc):
+    g = golden(fixture)
+    if 'y' not in g:
+        g.update(make_problem(int(g['cfg'])))
+    terms, parts = orc.fhat_terms(g['y'], g['z'], g['mu'], g['s'], g['gamma'], g['alpha'], g['beta'], return_parts=True)
+    np.testing.assert_allclose(terms, g['fhat_terms'], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(terms.sum(axis=1), g['fhat_per_d'], rtol=1e-9)        # vs the reference's own expression
+    for k in ('k_uu', 'psi_2', 'l_uu', 'l_a'):
+        np.testing.assert_allclose(parts[k], g[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(orc.kl_qx(g['mu'], g['s']), float(g['kl']), rtol=RT)
+    np.testing.assert_allclose(orc.hyperprior(g['gamma_atoms'], g['alpha_atoms'], g['beta_atoms']), float(g['hyperprior']),
+                               rtol=RT, atol=1e-12)
+    np.testing.assert_allclose(orc.dp_objective(g['phi'], g['g1'], g['g2'], g['w1'], g['w2'], g['s1'], g['s2']),
+                               float(g['dp_objective']), rtol=RT, atol=1e-10)
+    mg, ma, mb = orc.mix_hyperparameters(g['phi'], g['gamma_atoms'], g['alpha_atoms'], g['beta_atoms'])
+    np.testing.assert_allclose(mg, g['gamma'], rtol=RT)
+    obj = orc.objective(g['y'], g['z'], g['mu'], g['s'], g['phi'], g['gamma_atoms'], g['alpha_atoms'], g['beta_atoms'],
+                        g['g1'], g['g2'], g['w1'], g['w2'], g['s1'], g['s2'])
+    np.testing.assert_allclose(obj, float(g['objective']), rtol=1e-11)
+    if 'objective_naive' in g:      # the reference's naive NumPy known answer (dpgplvm_unitttests.py:78-126)
+        np.testing.assert_allclose(obj, float(g['objective_naive']), rtol=1e-7)
+    if 'fhat_literal' in g:         # dp_gp_lvm.py:108-145 op for op, including its [D,N,N] product
+        np.testing.assert_allclose(terms.sum(), float(g['fhat_literal']), rtol=1e-10)
+    # the C restatement
+    ct, info, cparts = corc.fhat_terms(g['y'], g['z'], g['mu'], g['s'], g['gamma'], g['alpha'], g['beta'], nthreads=2,
+                                       return_parts=True)
+    assert not info.any()
+    np.testing.assert_allclose(ct, g['fhat_terms'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(cparts['psi_2'], g['psi_2'], rtol=RT)
+    np.testing.assert_allclose(corc.kl_qx(g['mu'], g['s']), float(g['kl']), rtol=RT)
+
+
+@pytest.mark.parametrize('cfg,name', [(2, 'spot_C2'), (3, 'spot_C3'), (5, 'spot_C5')])
+def test_c_oracle_at_baseline_shapes(cfg, name):
+    """Full N, M, Q of the BASELINE configs on the 4 output dims the reference kernel was evaluated on (N-chunked)."""
+    g = golden(name)
+    p = make_problem(cfg, d_slice=g['dsel'])
+    c = COracle(fast=True)
+    terms, info, parts = c.fhat_terms(p['y'], p['z'], p['mu'], p['s'], p['gamma'], p['alpha'], p['beta'],
+                                      nthreads=min(4, c.max_threads), return_parts=True)
+    assert not info.any()
+    np.testing.assert_allclose(terms, g['fhat_terms'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(terms.sum(axis=1), g['fhat_per_d'], rtol=1e-9)
+    p2 = parts['psi_2']
+    np.testing.assert_allclose(np.sqrt((p2 * p2).sum(axis=(1, 2))), g['psi_2_fro'], rtol=RT)
+    np.testing.assert_allclose(p2[:, g['sample_i'], g['sample_j']], g['psi_2_samples'], rtol=RT)
+    np.testing.assert_allclose(parts['psi1T_y'], g['psi1T_y'], rtol=1e-9, atol=1e-12)
+
+
+def test_c_cholesky_and_solve(corc):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((37, 50))
+    a = a @ a.T + 37 * np.eye(37)
+    l, info = corc.potrf(a)
+    assert info == 0
+    np.testing.assert_allclose(l, np.linalg.cholesky(a), rtol=1e-12, atol=1e-13)
+    b = rng.standard_normal((37, 5))
+    np.testing.assert_allclose(corc.trsm(l, b), np.linalg.solve(l, b), rtol=1e-11)
+    a[20, 20] = -1.0
+    assert corc.potrf(a)[1] == 21
