@@ -8,10 +8,11 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdpgp_hip.so')
+# DPGP_LIBRARY overrides the in-tree path (used to load diagnostic builds of the same ABI)
+LIB_PATH = os.environ.get('DPGP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libdpgp_hip.so')
 
 FLAG_NOISE, FLAG_JITTER = 1, 2
-ALGO = {'auto': 0, 'mfma': 0, 'plain': 1}
+ALGO = {'auto': 0, 'plain': 1, 'mfma_f32': 2}
 PREC = {'f32': 0, 'mixed': 1, 'f64': 2}
 
 _vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
@@ -27,8 +28,8 @@ SIGNATURES = {
     'dpgp_elbo_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'dpgp_elbo_fhat': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp, _sz,
                             _vp]),
-    'dpgp_elbo_fhat_timed': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp,
-                                  _sz, _vp, _vp, _vp]),
+    'dpgp_elbo_fhat_ex': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp, _sz,
+                               _vp, _vp]),
     'dpgp_event_create': (_vp, []),
     'dpgp_event_destroy': (None, [_vp]),
     'dpgp_event_elapsed_ms': (ctypes.c_float, [_vp, _vp]),
@@ -48,6 +49,13 @@ for _t in ('f32', 'f64'):
         'dpgp_trsm_batched_' + _t: (_i, [_i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
         'dpgp_kl_qx_' + _t: (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     })
+
+
+
+class ExecResources(ctypes.Structure):
+    """dpgp_exec_t of include/dpgp.h: optional second stream + fork/join events, optional psi2 timing events."""
+    _fields_ = [('aux_stream', _vp), ('ev_fork', _vp), ('ev_join', _vp), ('ev_psi2_begin', _vp), ('ev_psi2_end', _vp)]
+
 
 _lib = None
 

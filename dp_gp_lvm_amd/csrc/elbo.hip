@@ -1,15 +1,17 @@
-// Fused per-output ELBO reduction (the hot path of dp_gp_lvm.py:108-148): six kernel launches on one stream, no host
-// synchronisation, no allocation — graph-capturable.
-//   1. KL(q(X)||p(X)) and y_d^T y_d                        (kl_yy_kernel)
-//   2. K_uu + jitter I straight into the padded Cholesky workspace (gram_kernel)
-//   3. Psi1_d^T y_d partial slabs                          (psi1T_y_kernel)
-//   4. Psi2_d partial slabs on the matrix cores            (psi2_mfma_kernel)
-//   5. per-d Cholesky chain + the five f_hat terms         (la_chain_kernel)
-//   6. f_hat = sum of terms                                 (sum_terms_kernel)
+// Fused per-output ELBO reduction (the hot path of dp_gp_lvm.py:108-148): no host synchronisation, no allocation —
+// graph-capturable.  Launch order on the main stream:
+//   1. KL(q(X)||p(X)) and y_d^T y_d partials                 (kl_yy_kernel)
+//   2. Psi1_d^T y_d partial slabs                            (psi1T_y_kernel)
+//   3. Psi2_d partial slabs on the matrix cores              (psi2_mfma_kernel)
+//   4. B = K + beta Psi2, bordered Cholesky, f_hat terms     (chain_b_kernel)
+//   5. f_hat = sum of terms                                   (sum_terms_kernel)
+// and, forked onto exec->aux_stream when the caller provides one (else in line before step 2):
+//   a. K_uu + jitter I                                        (gram_kernel)
+//   b. chol(K_uu), log-det, K_uu^-1                           (chain_k_kernel)   — overlaps steps 1-3
 #include "internal.h"
 
 struct ElboLayout {
-    size_t off_yy, off_v, off_p2, off_la, total;
+    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, total;
     int ns1, ns2, Mp;
 };
 
@@ -20,7 +22,9 @@ static ElboLayout elbo_layout(int D, int N, int M, int prec) {
     L.ns2 = psi2_nsplit(D, N, M);
     const size_t sp = (prec == DPGP_PREC_F64) ? 8 : 4, sl = (prec == DPGP_PREC_F32) ? 4 : 8;
     size_t o = 0;
-    L.off_yy = o; o += dpgp_align256(sizeof(double) * D);
+    L.off_yy = o; o += dpgp_align256(sizeof(double) * DPGP_YY_NCH * D);
+    L.off_ld = o; o += dpgp_align256(sizeof(double) * D);
+    L.off_ik = o; o += dpgp_align256(sizeof(int) * D);
     L.off_v = o;  o += dpgp_align256(sizeof(double) * (size_t)L.ns1 * D * M);
     L.off_p2 = o; o += dpgp_align256(sp * (size_t)L.ns2 * D * L.Mp * L.Mp);
     L.off_la = o; o += dpgp_align256(sl * (size_t)D * la_chain_ws_elems(M));
@@ -37,32 +41,46 @@ template <typename TP, typename TL>
 static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                     const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                     int algo, double *terms, double *sums, int *info, unsigned char *ws, const ElboLayout &L,
-                    hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                    hipStream_t st, const dpgp_exec_t *ex) {
     double *yy = reinterpret_cast<double *>(ws + L.off_yy);
+    double *ldk = reinterpret_cast<double *>(ws + L.off_ld);
+    int *ik = reinterpret_cast<int *>(ws + L.off_ik);
     double *vpart = reinterpret_cast<double *>(ws + L.off_v);
     TP *p2 = reinterpret_cast<TP *>(ws + L.off_p2);
     TL *la = reinterpret_cast<TL *>(ws + L.off_la);
+    hipEvent_t ev0 = ex ? (hipEvent_t)ex->ev_psi2_begin : nullptr, ev1 = ex ? (hipEvent_t)ex->ev_psi2_end : nullptr;
+    const bool fork = ex && ex->aux_stream && ex->ev_fork && ex->ev_join;
+    hipStream_t sk = fork ? (hipStream_t)ex->aux_stream : st;
     int rc;
-    if ((rc = launch_kl_yy<double>(N, Q, mu, s, sums + 1, D, y, ldy, yy, st))) return rc;
+    if (fork) {
+        if (hipEventRecord((hipEvent_t)ex->ev_fork, st) != hipSuccess) return DPGP_ERR_LAUNCH;
+        if (hipStreamWaitEvent(sk, (hipEvent_t)ex->ev_fork, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
+    }
+    // K_uu branch
     if ((rc = launch_gram<double, TL>(D, M, M, Q, z, nullptr, gamma, alpha, beta, DPGP_FLAG_JITTER, jitter, la, L.Mp,
-                                      la_chain_ws_elems(M), st)))
+                                      la_chain_ws_elems(M), sk)))
         return rc;
+    if ((rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, sk))) return rc;
+    if (fork && hipEventRecord((hipEvent_t)ex->ev_join, sk) != hipSuccess) return DPGP_ERR_LAUNCH;
+    // psi-statistics branch
+    if ((rc = launch_kl_yy<double>(N, Q, mu, s, sums + 1, D, y, ldy, yy, st))) return rc;
     if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, st)))
         return rc;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st))) return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
-    if ((rc = launch_la_chain<TP, TL>(D, N, M, la, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, terms, info, la, algo,
-                                      st)))
+    // join
+    if (fork && hipStreamWaitEvent(st, (hipEvent_t)ex->ev_join, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
+    if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info, la, algo,
+                                     st)))
         return rc;
     return launch_sum_terms(D, terms, sums, st);
 }
 
-extern "C" int dpgp_elbo_fhat_timed(int D, int N, int M, int Q, const double *y, int ldy, const double *z,
-                                    const double *mu, const double *s, const double *gamma, const double *alpha,
-                                    const double *beta, double jitter, int prec, int algo, double *terms, double *sums,
-                                    int *info, void *ws, size_t ws_bytes, void *stream, void *ev_psi2_begin,
-                                    void *ev_psi2_end) {
+extern "C" int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z,
+                                 const double *mu, const double *s, const double *gamma, const double *alpha,
+                                 const double *beta, double jitter, int prec, int algo, double *terms, double *sums,
+                                 int *info, void *ws, size_t ws_bytes, void *stream, const dpgp_exec_t *exec) {
     if (D <= 0) return -1;
     if (N <= 0) return -2;
     if (M <= 0 || M > N) return -3;
@@ -77,7 +95,7 @@ extern "C" int dpgp_elbo_fhat_timed(int D, int N, int M, int Q, const double *y,
     if (!beta) return -12;
     if (!(jitter >= 0.0)) return -13;
     if (prec < 0 || prec > 2) return -14;
-    if (algo != DPGP_ALGO_AUTO && algo != DPGP_ALGO_PLAIN) return -15;
+    if (algo < 0 || algo > DPGP_ALGO_MFMA_F32) return -15;
     if (!terms) return -16;
     if (!sums) return -17;
     if (!info) return -18;
@@ -89,13 +107,13 @@ extern "C" int dpgp_elbo_fhat_timed(int D, int N, int M, int Q, const double *y,
     switch (prec) {
     case DPGP_PREC_F32:
         return elbo_run<float, float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, algo, terms, sums, info,
-                                      w, L, st, (hipEvent_t)ev_psi2_begin, (hipEvent_t)ev_psi2_end);
+                                      w, L, st, exec);
     case DPGP_PREC_MIXED:
         return elbo_run<float, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, algo, terms, sums,
-                                       info, w, L, st, (hipEvent_t)ev_psi2_begin, (hipEvent_t)ev_psi2_end);
+                                       info, w, L, st, exec);
     default:
         return elbo_run<double, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, algo, terms, sums,
-                                        info, w, L, st, (hipEvent_t)ev_psi2_begin, (hipEvent_t)ev_psi2_end);
+                                        info, w, L, st, exec);
     }
 }
 
@@ -103,8 +121,8 @@ extern "C" int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int l
                               const double *s, const double *gamma, const double *alpha, const double *beta,
                               double jitter, int prec, int algo, double *terms, double *sums, int *info, void *ws,
                               size_t ws_bytes, void *stream) {
-    return dpgp_elbo_fhat_timed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, prec, algo, terms, sums, info,
-                                ws, ws_bytes, stream, nullptr, nullptr);
+    return dpgp_elbo_fhat_ex(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, prec, algo, terms, sums, info, ws,
+                             ws_bytes, stream, nullptr);
 }
 
 // HIP events for callers that have no HIP runtime binding of their own (bench.py times the psi2 kernel with these).

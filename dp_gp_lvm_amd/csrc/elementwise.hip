@@ -307,9 +307,11 @@ __global__ void sum_slabs_kernel(size_t n, int ns, const double *__restrict__ pa
 // ---------------------------------------------------------------------------------------------------------------
 // KL(q(X) || N(0,I)) (gp_expressions.py:18-23) and, in the same launch, y_d^T y_d for the data-fit term
 // (dp_gp_lvm.py:143-144; the reference forms the whole [D,D] product and takes its diagonal).
-//   block 0            : KL  -> kl_out[0]
-//   blocks 1 .. 1+D/64 : yy[d] for 64 consecutive d (coalesced along d, 4 waves stride over n)
+//   block 0      : KL  -> kl_out[0]
+//   other blocks : (64 consecutive d) x (one of YY_NCH chunks of n); coalesced along d, 4 waves stride over n, partial
+//                  sums written to yy_out[chunk][d] (DPGP_YY_NCH slabs, summed in fixed order by the consumer: deterministic)
 // ---------------------------------------------------------------------------------------------------------------
+#define YY_NCH DPGP_YY_NCH
 template <typename TIN>
 __global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__restrict__ mu,
                                                     const TIN *__restrict__ s, double *__restrict__ kl_out, int D,
@@ -318,32 +320,50 @@ __global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__r
     const int t = threadIdx.x;
     if (blockIdx.x == 0) {
         if (kl_out == nullptr) return;
-        double a = 0.0;
-        size_t tot = (size_t)N * Q;
-        for (size_t i = t; i < tot; i += 256) {
-            double m = (double)mu[i], v = (double)s[i];
-            a += m * m + v - log(v);
+        double a0 = 0.0, a1 = 0.0;
+        const size_t tot = (size_t)N * Q;
+        size_t i = t;
+        for (; i + 256 < tot; i += 512) {
+            const double m0 = (double)mu[i], v0 = (double)s[i], m1 = (double)mu[i + 256], v1 = (double)s[i + 256];
+            a0 += m0 * m0 + v0 - log(v0);
+            a1 += m1 * m1 + v1 - log(v1);
         }
-        a = block_sum(a, &scratch[0][0]);
+        for (; i < tot; i += 256) {
+            const double m0 = (double)mu[i], v0 = (double)s[i];
+            a0 += m0 * m0 + v0 - log(v0);
+        }
+        const double a = block_sum(a0 + a1, &scratch[0][0]);
         if (t == 0) kl_out[0] = 0.5 * (a - (double)N * (double)Q);
         return;
     }
-    const int d = (blockIdx.x - 1) * 64 + (t & 63), wv = t >> 6;
-    double a = 0.0;
-    if (d < D)
-        for (int n = wv; n < N; n += 4) {
-            double v = (double)y[(size_t)n * ldy + d];
-            a += v * v;
+    const int bid = blockIdx.x - 1, dblk = bid / YY_NCH, ch = bid - dblk * YY_NCH;
+    const int d = dblk * 64 + (t & 63), wv = t >> 6;
+    const int nper = (N + YY_NCH - 1) / YY_NCH, n0 = ch * nper, n1 = min(N, n0 + nper);
+    double a0 = 0.0, a1 = 0.0;
+    if (d < D) {
+        int n = n0 + wv;
+        for (; n + 4 < n1; n += 8) {
+            const double v0 = (double)y[(size_t)n * ldy + d], v1 = (double)y[(size_t)(n + 4) * ldy + d];
+            a0 += v0 * v0;
+            a1 += v1 * v1;
         }
-    scratch[wv][t & 63] = a;
+        for (; n < n1; n += 4) {
+            const double v0 = (double)y[(size_t)n * ldy + d];
+            a0 += v0 * v0;
+        }
+    }
+    scratch[wv][t & 63] = a0 + a1;
     __syncthreads();
-    if (t < 64 && d < D) yy_out[d] = scratch[0][t] + scratch[1][t] + scratch[2][t] + scratch[3][t];
+    if (t < 64 && d < D) yy_out[(size_t)ch * D + d] = scratch[0][t] + scratch[1][t] + scratch[2][t] + scratch[3][t];
 }
 
 template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
                  double *yy_out, hipStream_t st) {
-    int blocks = 1 + (yy_out ? dpgp_ceil_div(D, 64) : 0);
+    int blocks = 1;
+    if (yy_out) {
+        blocks += dpgp_ceil_div(D, 64) * YY_NCH;
+    }
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((kl_yy_kernel<TIN>), dim3(blocks), dim3(256), 0, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;

@@ -15,6 +15,8 @@ template <typename TIN, typename T>
 int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                            const TIN *alpha, const TIN *y, int ldy, double *part, int ns, hipStream_t st);
 
+// yy_out: DPGP_YY_NCH partial slabs [DPGP_YY_NCH][D]
+#define DPGP_YY_NCH 16
 template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
                  double *yy_out, hipStream_t st);
@@ -28,10 +30,14 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st);
 
 // ---- linalg.hip ------------------------------------------------------------------------------------------------
-// per-d workspace of the fused Cholesky chain, in elements of TL
+// per-d workspace of the fused Cholesky chain, in elements of TL (layout: linalg.hip)
 size_t la_chain_ws_elems(int M);
+// everything that depends on K_uu only (may overlap the psi2 kernel on another stream)
+template <typename TL>
+int launch_chain_k(int D, int M, TL *ws, double *logdet_k, int *info_k, int algo, hipStream_t st);
+// everything after Psi2: B = K + beta Psi2, bordered Cholesky, the five f_hat terms per output dim
 template <typename TP, typename TL>
-int launch_la_chain(int D, int N, int M, TL *kuu_ws /* gram already written, see linalg.hip */, const TP *psi2_part,
-                    int ns2, const double *v_part, int ns1, const double *alpha, const double *beta,
-                    const double *yy, double *terms, int *info, TL *ws, int algo, hipStream_t st);
+int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1,
+                   const double *alpha, const double *beta, const double *yy_part, const double *logdet_k,
+                   const int *info_k, double *terms, int *info, TL *ws, int algo, hipStream_t st);
 int launch_sum_terms(int D, const double *terms, double *sums, hipStream_t st);

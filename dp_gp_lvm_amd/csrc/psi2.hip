@@ -264,6 +264,301 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
     }
 }
 
+// ===============================================================================================================
+// fp32 psi2 on the REAL matrix pipe: f16 hi/lo-split operands, v_mfma_f32_16x16x32_f16, fp32 accumulate.
+//
+// Why: on gfx950 the fp32-input MFMA runs at the vector rate and does NOT co-execute with VALU work (measured:
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0, micro-benchmark scratch/ubench/coexec.hip: mfma 26.7 ms + valu 15.0 ms -> 44.9 ms
+// together), so the fp32-MFMA kernel above pays (matrix + exp) serially.  The f16 MFMA is a separate pipe (14.9 + 14.9
+// -> 23.3 ms, the remainder is its 8 issue cycles per instruction).  Each fp32 operand x is split as x = hi + lo with
+// hi = f16(x), lo = f16(x - hi) (22 significant bits; f16 subnormals are honoured by the MFMA, verified on the GPU) and
+//      a*b ~= ah*bh + ah*bl + al*bh          (the dropped al*bl is 2^-22 relative)
+// so one fp32 product becomes three f16 K-columns.  Exponent error vs fp64 is the same ~1e-6 (log2 units) as the fp32
+// kernel's (scratch/f16split_sim.py).  |P| must stay below the f16 range: it is clamped to +-30000 (2^-30000 = 0).
+//
+// K layout: 8-slot groups, group g = kk + 4 s (kk = lane >> 4, s = K-step of 32), two latent dims q0 = 2g, q1 = 2g+1:
+//      A slots { ah0, ah1, ah0, ah1, al0, al1, spA0, spA1 }      A_q = X[n,q] * z[m,q]
+//      B slots { bh0, bh1, bl0, bl1, bh0, bh1, spB0, spB1 }      B_q = z[m',q]
+//   spare slots: group 0: A = (Ph, Pl) of P[n,m], B = (1, 1);  group 1: A = (1, 1), B = (Ph, Pl) of P[n,m'];  else 0.
+// ===============================================================================================================
+typedef _Float16 dpgp_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dpgp_h8 __attribute__((ext_vector_type(8)));
+typedef unsigned dpgp_u4 __attribute__((ext_vector_type(4)));
+#define DPGP_H2_ONES 0x3C003C00u
+#ifndef PSI2_F16_WAVES
+#define PSI2_F16_WAVES 2   // waves per SIMD the register allocator must allow (3 = 168 VGPRs spills in the hot loop: slower)
+#endif
+
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+    dpgp_h2 h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+// hi/lo split of two fp32 products x0*z0, x1*z1 into packed f16 pairs (compiles to v_fma_mix* / v_cvt_pk_f16_f32)
+__device__ __forceinline__ void split_products(float x0, float z0, float x1, float z1, unsigned &hi, unsigned &lo) {
+    const _Float16 h0 = (_Float16)(x0 * z0), h1 = (_Float16)(x1 * z1);
+    const float l0 = __builtin_fmaf(x0, z0, -(float)h0), l1 = __builtin_fmaf(x1, z1, -(float)h1);
+    dpgp_h2 hv = {h0, h1};
+    hi = __builtin_bit_cast(unsigned, hv);
+    lo = pack_h2(l0, l1);
+}
+
+template <int KB> struct Psi2F16Lds {
+    static constexpr int PT = 4, PS = 64;
+    static constexpr int KF = (KB + 1) / 2;                  // K-steps of 32 (4 groups of 2 latent dims each)
+    static constexpr int KQ = 4 * KB;                        // latent dims padded to a multiple of 4 (phase B unroll)
+    static constexpr int XLD = 8 * KF;                       // row stride of the per-(n,q) arrays (>= KQ)
+    static constexpr int ZLD = ((KQ / 4) & 1) ? KQ : KQ + 4;
+    static constexpr int PLD = 2 * PS + 4;
+    static constexpr int NR = 8;
+    static constexpr int WSZ = 4 * NR * XLD + NR * PLD + 4;  // xa, w4, tm, cn, packed P rows, 2 constant words (+pad)
+    static constexpr int OFF_W = 2 * PS * ZLD + 2 * (DPGP_MAX_Q + 2);
+    static constexpr int FILL = OFF_W + 4 * WSZ;
+    static constexpr int RED = OFF_W + 4 * PT * 4 * 64;
+    static constexpr int ELEMS = FILL > RED ? FILL : RED;
+};
+
+template <typename TIN, int KB, bool DIAG>
+__device__ __forceinline__ void psi2_patch_f16(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                               const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                               const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
+                                               float *__restrict__ part, int Mp, int n_per_split, int pi, int pj,
+                                               unsigned char *smem_raw) {
+    typedef Psi2F16Lds<KB> G;
+    constexpr int PT = G::PT, PS = G::PS, KF = G::KF, KQ = G::KQ, XLD = G::XLD, ZLD = G::ZLD, PLD = G::PLD, NR = G::NR;
+    float *zs = reinterpret_cast<float *>(smem_raw);     // [2*PS][ZLD] centred z rows: m-block then m'-block
+    float *zc = zs + 2 * PS * ZLD;                        // [Q] column means of z
+    float *gq = zc + DPGP_MAX_Q + 2;                      // [Q] gamma_b
+    const int b = blockIdx.y, sp = blockIdx.z;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
+    const int m_base = pi * PS, mp_base = pj * PS;
+    float *wp = zs + G::OFF_W + wv * G::WSZ;
+    float *xa = wp;                                       // [NR][XLD]  X[n,q] = -1/2 w log2e  (0 for q >= Q)
+    float *w4 = xa + NR * XLD;                            // [NR][XLD]  1/4 w log2e
+    float *tm = w4 + NR * XLD;                            // [NR][XLD]  2 (mu - c)
+    float *cn = tm + NR * XLD;                            // [NR][XLD]  (1/2 w (mu-c)^2 - 1/4 log den) log2e
+    unsigned *pw = reinterpret_cast<unsigned *>(cn + NR * XLD);   // [NR][PLD] packed (Ph, Pl) + [2] constants
+    constexpr int CONST_ONE = NR * PLD, CONST_ZERO = NR * PLD + 1;
+
+    if (t < Q) {
+        gq[t] = (float)gamma[(size_t)b * Q + t];
+        double a = 0.0;
+        for (int m = 0; m < M; ++m) a += (double)z[(size_t)m * Q + t];
+        zc[t] = (float)(a / (double)M);
+    }
+    __syncthreads();
+    for (int e = t; e < 2 * PS * ZLD; e += 256) {
+        int r = e / ZLD, k = e - r * ZLD;
+        int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
+        zs[e] = (k < Q && m < M) ? (float)z[(size_t)m * Q + k] - zc[k] : 0.0f;
+    }
+    if (lane == 0) { pw[CONST_ONE] = DPGP_H2_ONES; pw[CONST_ZERO] = 0u; }
+    __syncthreads();
+
+    // ---- per-lane constants: A-side z values (fp32) and B-side split z (packed f16) of this lane's groups ----
+    float zA[PT][KF][2];
+    unsigned bh[PT][KF], bl[PT][KF];
+#pragma unroll
+    for (int ks = 0; ks < KF; ++ks) {
+        const int q0 = 2 * (kk + 4 * ks);                 // < XLD <= ZLD? zs rows hold ZLD >= KQ entries; guard by Q
+#pragma unroll
+        for (int I = 0; I < PT; ++I) {
+            const float a0 = (q0 < Q) ? zs[(16 * I + li) * ZLD + q0] : 0.0f;
+            const float a1 = (q0 + 1 < Q) ? zs[(16 * I + li) * ZLD + q0 + 1] : 0.0f;
+            zA[I][ks][0] = a0;
+            zA[I][ks][1] = a1;
+            const float b0 = (q0 < Q) ? zs[(PS + 16 * I + li) * ZLD + q0] : 0.0f;
+            const float b1 = (q0 + 1 < Q) ? zs[(PS + 16 * I + li) * ZLD + q0 + 1] : 0.0f;
+            const _Float16 h0 = (_Float16)b0, h1 = (_Float16)b1;
+            dpgp_h2 hv = {h0, h1};
+            bh[I][ks] = __builtin_bit_cast(unsigned, hv);
+            bl[I][ks] = pack_h2(b0 - (float)h0, b1 - (float)h1);
+        }
+    }
+    // spare-slot sources (K-step 0 only): lane group 0 carries P[n,m] on the A side, group 1 carries P[n,m'] on the B side
+    constexpr int pb_off = DIAG ? 0 : PS;
+    const int rmulA = (kk == 0) ? PLD : 0, rmulB = (kk == 1) ? PLD : 0;
+    int offA[PT], offB[PT];
+#pragma unroll
+    for (int I = 0; I < PT; ++I) {
+        offA[I] = (kk == 0) ? 16 * I + li : (kk == 1 ? CONST_ONE : CONST_ZERO);
+        offB[I] = (kk == 1) ? pb_off + 16 * I + li : (kk == 0 ? CONST_ONE : CONST_ZERO);
+    }
+
+    f32x4 acc[PT][PT];
+#pragma unroll
+    for (int I = 0; I < PT; ++I)
+#pragma unroll
+        for (int J = 0; J < PT; ++J) acc[I][J] = (f32x4){0, 0, 0, 0};
+
+    const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    constexpr int NCOL = DIAG ? PS : 2 * PS;
+    constexpr int CPL = (NCOL + 63) / 64;
+
+    for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {
+        // ---- phase A: per-(row,q) factors ----
+#pragma unroll
+        for (int e0 = 0; e0 < NR * XLD; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < NR * XLD) {
+                const int r = e / XLD, k = e - r * XLD, n = nc + 4 * r;
+                float vx = 0, vw = 0, vt = 0, vc = 0;
+                if (k < Q) {
+                    if (n < nend) {
+                        const float g = gq[k];
+                        const float sv = (float)s[(size_t)n * Q + k];
+                        const float mc = (float)mu[(size_t)n * Q + k] - zc[k];
+                        const float den = 2.0f * g * sv + 1.0f;
+                        const float w = g / den;
+                        vx = (float)(-0.5 * DPGP_LOG2E) * w;
+                        vw = (float)(0.25 * DPGP_LOG2E) * w;
+                        vt = 2.0f * mc;
+                        vc = (float)DPGP_LOG2E * (0.5f * w * mc * mc - 0.25f * dpgp_log(den));
+                    } else {
+                        vc = -1.0e30f;
+                    }
+                }
+                xa[e] = vx; w4[e] = vw; tm[e] = vt; cn[e] = vc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float crv = 0;
+        if (lane < NR) {
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) crv += cn[lane * XLD + k];
+        }
+        // ---- phase B: P[r, c], clamped to the f16 range and stored as packed (hi, lo) ----
+        float zr[CPL][KQ];
+#pragma unroll
+        for (int h = 0; h < CPL; ++h)
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) zr[h][k] = (h * 64 + lane < NCOL) ? zs[(h * 64 + lane) * ZLD + k] : 0.0f;
+#pragma unroll 2
+        for (int r = 0; r < NR; ++r) {
+            const float c0 = __shfl(crv, r, 64);
+            float p[CPL];
+#pragma unroll
+            for (int h = 0; h < CPL; ++h) p[h] = c0;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) {
+                const float wk = w4[r * XLD + k], tk = tm[r * XLD + k];
+#pragma unroll
+                for (int h = 0; h < CPL; ++h) {
+                    const float d = zr[h][k] - tk;
+                    p[h] = fmaf(-wk * d, d, p[h]);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < CPL; ++h) {
+                const float pc = fminf(fmaxf(p[h], -30000.0f), 30000.0f);
+                const _Float16 ph = (_Float16)pc;
+                dpgp_h2 hv = {ph, (_Float16)(pc - (float)ph)};
+                if (h * 64 + lane < NCOL) pw[r * PLD + h * 64 + lane] = __builtin_bit_cast(unsigned, hv);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase C: per row, exponent tile on the f16 matrix pipe, psi2 += exp2(E) ----
+#pragma unroll 1
+        for (int r = 0; r < NR; ++r) {
+            float xk[KF][2];
+#pragma unroll
+            for (int ks = 0; ks < KF; ++ks) {
+                xk[ks][0] = xa[r * XLD + 2 * (kk + 4 * ks)];
+                xk[ks][1] = xa[r * XLD + 2 * (kk + 4 * ks) + 1];
+            }
+            unsigned spA[PT], spB[PT];
+#pragma unroll
+            for (int I = 0; I < PT; ++I) {
+                spA[I] = pw[r * rmulA + offA[I]];
+                spB[I] = pw[r * rmulB + offB[I]];
+            }
+#pragma unroll
+            for (int I = 0; I < PT; ++I) {
+                dpgp_u4 aop[KF];
+#pragma unroll
+                for (int ks = 0; ks < KF; ++ks) {
+                    unsigned hi, lo;
+                    split_products(xk[ks][0], zA[I][ks][0], xk[ks][1], zA[I][ks][1], hi, lo);
+                    aop[ks] = (dpgp_u4){hi, hi, lo, ks == 0 ? spA[I] : 0u};
+                }
+                f32x4 c[PT];
+#pragma unroll
+                for (int J = 0; J < PT; ++J) c[J] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KF; ++ks)
+#pragma unroll
+                    for (int J = 0; J < PT; ++J)
+                        if (!(DIAG && J > I)) {
+                            const dpgp_u4 bop = {bh[J][ks], bl[J][ks], bh[J][ks], ks == 0 ? spB[J] : 0u};
+                            c[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dpgp_h8, aop[ks]),
+                                                                          __builtin_bit_cast(dpgp_h8, bop), c[J], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int J = 0; J < PT; ++J)
+                    if (!(DIAG && J > I)) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[I][J][v] += dpgp_exp2(c[J][v]);
+                    }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+
+    // ---- epilogue (as in the fp32-MFMA kernel) ----
+    float *red = zs + G::OFF_W;
+    const float al = (float)alpha[b];
+    const float al2 = al * al;
+    float *out = part + ((size_t)sp * B + b) * (size_t)Mp * Mp;
+#pragma unroll
+    for (int I = 0; I < PT; ++I) {
+        __syncthreads();
+#pragma unroll
+        for (int J = 0; J < PT; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[((wv * PT + J) * 4 + v) * 64 + lane] = acc[I][J][v];
+        __syncthreads();
+        for (int e = t; e < PT * 256; e += 256) {
+            const int J = e >> 8, v = (e >> 6) & 3, l = e & 63;
+            if (DIAG && J > I) continue;
+            float sum = 0;
+#pragma unroll
+            for (int w_ = 0; w_ < 4; ++w_) sum += red[((w_ * PT + J) * 4 + v) * 64 + l];
+            const int row = 16 * I + Mfma<float>::row(l, v), col = 16 * J + (l & 15);
+            const int m = m_base + row, mp = mp_base + col;
+            if (m < Mp && mp < Mp) {
+                float val = 0;
+                if (m < M && mp < M) {
+                    const float *z1 = zs + row * ZLD, *z2 = zs + (PS + col) * ZLD;
+                    float bsum = 0;
+                    for (int q = 0; q < Q; ++q) {
+                        const float d = z1[q] - z2[q];
+                        bsum += gq[q] * d * d;
+                    }
+                    val = al2 * sum * dpgp_exp2((float)(-0.25 * DPGP_LOG2E) * bsum);
+                }
+                out[(size_t)m * Mp + mp] = val;
+            }
+        }
+    }
+}
+
+template <typename TIN, int KB>
+__global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                                       const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                                       const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
+                                                       float *__restrict__ part, int Mp, int n_per_split) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    int pi, pj;
+    patch_from_index(blockIdx.x, pi, pj);
+    if (pi == pj)
+        psi2_patch_f16<TIN, KB, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, pi, pj, smem_raw);
+    else
+        psi2_patch_f16<TIN, KB, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, pi, pj, smem_raw);
+}
+
 template <typename TIN, typename T, int KS, int PT>
 __global__ __launch_bounds__(256) void psi2_mfma_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
                                                         const TIN *__restrict__ mu, const TIN *__restrict__ s,
@@ -382,6 +677,45 @@ static int launch_psi2_ks(int B, int N, int M, int Q, const TIN *z, const TIN *m
     return DPGP_OK;
 }
 
+template <typename TIN, int KB>
+static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                              const TIN *alpha, float *part, int ns, hipStream_t st) {
+    const int Mp = dpgp_round_up(M, 16);
+    const int nps = dpgp_ceil_div(Mp, 64);
+    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
+    dim3 grid(nps * (nps + 1) / 2, B, ns);
+    size_t lds = sizeof(float) * (size_t)Psi2F16Lds<KB>::ELEMS;
+    auto kern = psi2_f16_kernel<TIN, KB>;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
+    }
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
+// the f16-split kernel exists for fp32 results only
+template <typename TIN, typename T> struct Psi2F16Dispatch {
+    static int run(int, int, int, int, const TIN *, const TIN *, const TIN *, const TIN *, const TIN *, T *, int,
+                   hipStream_t) {
+        return -13;
+    }
+};
+template <typename TIN> struct Psi2F16Dispatch<TIN, float> {
+    static int run(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                   const TIN *alpha, float *part, int ns, hipStream_t st) {
+        switch (dpgp_ceil_div(Q, 4)) {
+#define CASE(k) \
+    case k: return launch_psi2_f16_kb<TIN, k>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, st);
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+        }
+        return -4;
+    }
+};
+
 template <typename TIN, typename T>
 int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st) {
@@ -397,6 +731,9 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
         DPGP_LAUNCH_CHECK();
         return DPGP_OK;
     }
+    // fp32 results: f16-split operands on the matrix pipe unless the exact-fp32 MFMA kernel is asked for
+    if (sizeof(T) == 4 && algo != DPGP_ALGO_MFMA_F32)
+        return Psi2F16Dispatch<TIN, T>::run(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, st);
     const int KS = dpgp_ceil_div(Q + 2, 4);
     switch (KS) {
 #define CASE(k) \
@@ -437,7 +774,7 @@ static int psi2_api(int B, int N, int M, int Q, const T *z, const T *mu, const T
     if (!out) return -10;
     if (!ws) return -11;
     if (ws_bytes < dpgp_psi2_workspace_bytes(B, N, M, Q, sizeof(T))) return -12;
-    if (algo != DPGP_ALGO_AUTO && algo != DPGP_ALGO_PLAIN) return -13;
+    if (algo < 0 || algo > DPGP_ALGO_MFMA_F32) return -13;
     const int ns = psi2_nsplit(B, N, M), Mp = dpgp_round_up(M, 16);
     int rc = launch_psi2_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, (T *)ws, ns, algo, (hipStream_t)stream);
     if (rc) return rc;

@@ -188,9 +188,11 @@ def kl_qx(mu, s):
 
 
 class ElboWorkspace:
-    """Caller-owned scratch + outputs of the fused ELBO for one (D,N,M,Q,prec): allocate once, evaluate many times."""
+    """Caller-owned scratch + outputs of the fused ELBO for one (D,N,M,Q,prec): allocate once, evaluate many times.
+    With ``overlap=True`` it also owns a side stream and two events so that the K_uu branch (gram, Cholesky, inverse)
+    overlaps the psi2 kernel (dpgp_exec_t of include/dpgp.h)."""
 
-    def __init__(self, d, n, m, q, prec='mixed', device='cuda'):
+    def __init__(self, d, n, m, q, prec='mixed', device='cuda', overlap=True):
         self.shape, self.prec = (d, n, m, q), prec
         l = _lib.lib()
         self.nbytes = l.dpgp_elbo_workspace_bytes(d, n, m, q, _lib.PREC[prec])
@@ -198,6 +200,22 @@ class ElboWorkspace:
         self.terms = torch.empty((d, 5), dtype=torch.float64, device=device)
         self.sums = torch.empty(2, dtype=torch.float64, device=device)
         self.info = torch.empty(d, dtype=torch.int32, device=device)
+        self.exec = _lib.ExecResources()
+        self._events = []
+        self.aux = None
+        if overlap:
+            with torch.cuda.device(device):
+                self.aux = torch.cuda.Stream(device=device)
+                self._events = [l.dpgp_event_create(), l.dpgp_event_create()]
+            self.exec.aux_stream = self.aux.cuda_stream
+            self.exec.ev_fork, self.exec.ev_join = self._events
+
+    def __del__(self):
+        try:
+            for e in self._events:
+                _lib.lib().dpgp_event_destroy(e)
+        except Exception:
+            pass
 
 
 def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None, events=None):
@@ -219,9 +237,12 @@ def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='
     w = workspace if workspace is not None else ElboWorkspace(d, n, m, q, prec, y.device)
     assert w.shape == (d, n, m, q) and w.prec == prec, 'workspace was sized for another problem'
     ev0, ev1 = events if events is not None else (None, None)     # optional hipEvent handles around the psi2 kernel
-    _lib.check(_lib.lib().dpgp_elbo_fhat_timed(d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(),
-                                               s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(),
-                                               float(jitter), _lib.PREC[prec], _lib.ALGO[algo], w.terms.data_ptr(),
-                                               w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes,
-                                               _stream(), ev0, ev1), 'dpgp_elbo_fhat')
+    w.exec.ev_psi2_begin, w.exec.ev_psi2_end = ev0, ev1
+    import ctypes
+    _lib.check(_lib.lib().dpgp_elbo_fhat_ex(d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(),
+                                            s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(),
+                                            float(jitter), _lib.PREC[prec], _lib.ALGO[algo], w.terms.data_ptr(),
+                                            w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes,
+                                            _stream(), ctypes.cast(ctypes.pointer(w.exec), ctypes.c_void_p)),
+               'dpgp_elbo_fhat_ex')
     return w.terms, w.sums, w.info

@@ -36,8 +36,9 @@ extern "C" {
 #define DPGP_MAX_Q 30
 
 /* algorithm selectors for the calls that have a matrix-core and a plain-VALU implementation */
-#define DPGP_ALGO_AUTO 0  /* MFMA kernels (the product path)                                   */
-#define DPGP_ALGO_PLAIN 1 /* straightforward one-thread-per-element HIP kernels (cross-check)  */
+#define DPGP_ALGO_AUTO 0     /* matrix-core kernels (the product path); fp32 psi2 uses f16 hi/lo-split operands   */
+#define DPGP_ALGO_PLAIN 1    /* straightforward one-thread-per-element HIP kernels (cross-check)                  */
+#define DPGP_ALGO_MFMA_F32 2 /* as AUTO, but fp32 psi2 on v_mfma_f32_16x16x4_f32 (exact fp32 products; slower)    */
 
 /* precision modes of the fused ELBO */
 #define DPGP_PREC_F32 0   /* psi-statistics fp32, Cholesky chain fp32                          */
@@ -120,12 +121,24 @@ int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const d
                    const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                    int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
                    void *stream);
-/* same, with two caller-created hipEvent_t (void*) recorded on `stream` immediately before / after the psi2 kernel, so a
- * harness can time the dominant kernel inside its timed region; either may be NULL.                                  */
-int dpgp_elbo_fhat_timed(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
-                         const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
-                         int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
-                         void *stream, void *ev_psi2_begin, void *ev_psi2_end);
+/* same, with optional execution resources owned by the caller (the library creates no streams or events itself):
+ *   aux_stream + ev_fork + ev_join : a second hipStream_t and two hipEvent_t.  When all three are given, everything that
+ *       depends on K_uu only (gram, Cholesky, log-det, inverse) is forked onto aux_stream and overlaps the psi2 kernel;
+ *       it is joined back into `stream` before the final per-output Cholesky.  NULL: everything runs in order on `stream`.
+ *   ev_psi2_begin / ev_psi2_end    : hipEvent_t recorded on `stream` immediately before / after the psi2 kernel so that
+ *       a harness can time the dominant kernel inside its timed region; either may be NULL.
+ * exec itself may be NULL (= dpgp_elbo_fhat).                                                                        */
+typedef struct dpgp_exec {
+    void *aux_stream;
+    void *ev_fork;
+    void *ev_join;
+    void *ev_psi2_begin;
+    void *ev_psi2_end;
+} dpgp_exec_t;
+int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                      const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
+                      int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
+                      void *stream, const dpgp_exec_t *exec);
 /* hipEvent helpers for hosts without their own HIP binding */
 void *dpgp_event_create(void);
 void dpgp_event_destroy(void *event);

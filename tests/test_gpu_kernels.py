@@ -63,7 +63,7 @@ def test_diag_psi0_psi1(dev, fixture, dt):
 
 @pytest.mark.parametrize('fixture', ['kernel_b1', 'kernel_b7'])
 @pytest.mark.parametrize('dt', [torch.float64, torch.float32])
-@pytest.mark.parametrize('algo', ['auto', 'plain'])
+@pytest.mark.parametrize('algo', ['auto', 'plain', 'mfma_f32'])
 def test_psi2_golden(dev, fixture, dt, algo):
     g = golden(fixture)
     p2 = ops.psi2(T(g['x_u'], dt, dev), T(g['x_mean'], dt, dev), T(g['x_var'], dt, dev), T(g['gamma'], dt, dev),
@@ -84,7 +84,9 @@ def test_psi_statistics_vs_oracle_ragged(dev, shape, dt):
     gam, al = np.exp(0.3 * rng.standard_normal((b, q))), np.exp(0.3 * rng.standard_normal((b, 1)))
     y = rng.standard_normal((n, b))
     args = [T(a, dt, dev) for a in (z, mu, s, gam, al)]
-    close(ops.psi2(*args), orc.psi2(z, mu, s, gam, al), TOL_PSI2[dt], 'psi2')
+    ref2 = orc.psi2(z, mu, s, gam, al)
+    close(ops.psi2(*args), ref2, TOL_PSI2[dt], 'psi2')
+    close(ops.psi2(*args, algo='mfma_f32'), ref2, TOL_PSI2[dt], 'psi2 fp32-MFMA variant')
     close(ops.psi1(*args), orc.psi1(z, mu, s, gam, al), TOL[dt], 'psi1')
     tol = dict(TOL[dt])
     if dt == torch.float32:
