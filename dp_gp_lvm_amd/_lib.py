@@ -35,6 +35,8 @@ SIGNATURES = {
     'dpgp_event_elapsed_ms': (ctypes.c_float, [_vp, _vp]),
     'dpgp_model_prepare': (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
+    'dpgp_model_scal_count': (_i, [_i]),
+    'dpgp_model_pack': (_i, [_i, _vp, _vp, _vp, _vp]),
     'dpgp_model_finalize': (_i, [_vp, _vp, _vp, _vp, _vp]),
 }
 for _t in ('f32', 'f64'):

@@ -157,102 +157,130 @@ __device__ double digamma_d(double x) {
 }
 
 #define PREP_MAX_T 64
+#define PREP_ROWS 16   // output dims per row-block (4 waves x 4 rows)
+
+// grid: block 0 = atoms, hyper-prior and the D-independent DP terms; blocks 1..nrb = PREP_ROWS output dims each (one wave
+// per row, lane t = stick t); remaining blocks = softplus of the q(X) variances.
+//   scal[0] = D-independent DP terms (0 unless add_constants), scal[1] = hyper-prior, scal[2 + rb] = row-block partials.
 __global__ __launch_bounds__(256) void model_prepare_kernel(
-    int D, int T, int Q, int N, int d_offset, int mask_size, const double *__restrict__ logits,
+    int D, int T, int Q, int N, int d_offset, int mask_size, int nrb, const double *__restrict__ logits,
     const double *__restrict__ gat_raw, const double *__restrict__ aat_raw, const double *__restrict__ bat_raw,
     const double *__restrict__ s_raw, const double *__restrict__ g1_raw, const double *__restrict__ g2_raw,
     const double *__restrict__ w_raw, double s1, double s2, int add_constants, double *__restrict__ gamma,
     double *__restrict__ alpha, double *__restrict__ beta, double *__restrict__ s_out, double *__restrict__ phi_out,
     double *__restrict__ scal) {
-    const int t = threadIdx.x;
-    if (blockIdx.x > 0) {   // q(X) variances: s = softplus(raw)   (dp_gp_lvm.py:67-69, utils/types.py:40-57)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    __shared__ double scratch[8];
+    if ((int)blockIdx.x > nrb) {   // q(X) variances: s = softplus(raw)   (dp_gp_lvm.py:67-69, utils/types.py:40-57)
         const size_t tot = (size_t)N * Q;
-        for (size_t i = (size_t)(blockIdx.x - 1) * 256 + t; i < tot; i += (size_t)(gridDim.x - 1) * 256)
+        const int nsb = gridDim.x - 1 - nrb;
+        for (size_t i = (size_t)(blockIdx.x - 1 - nrb) * 256 + t; i < tot; i += (size_t)nsb * 256)
             s_out[i] = softplus_d(s_raw[i]);
         return;
     }
-    __shared__ double gat[PREP_MAX_T * DPGP_MAX_Q], aat[PREP_MAX_T], bat[PREP_MAX_T];
-    __shared__ double c1[PREP_MAX_T], c2[PREP_MAX_T];   // psi(g1)-psi(g1+g2), psi(g2)-psi(g1+g2)
-    __shared__ double scratch[8];
-    double hyper = 0.0, consts = 0.0;
-    for (int i = t; i < T * Q; i += 256) {
-        const double v = softplus_d(gat_raw[i]);
-        gat[i] = v;
-        const double lx = log(v);
-        hyper += -lx - 0.5 * (DPGP_LOG_2PI + lx * lx);        // log_normal.log_pdf (log_normal.py:34-39)
+    if (blockIdx.x == 0) {
+        double hyper = 0.0, consts = 0.0;
+        for (int i = t; i < T * Q + 2 * T; i += 256) {
+            const double raw = i < T * Q ? gat_raw[i] : (i < T * Q + T ? aat_raw[i - T * Q] : bat_raw[i - T * Q - T]);
+            const double lx = log(softplus_d(raw));
+            hyper += -lx - 0.5 * (DPGP_LOG_2PI + lx * lx);        // log_normal.log_pdf (log_normal.py:34-39)
+        }
+        const double w1 = softplus_d(w_raw[0]), w2 = softplus_d(w_raw[1]);
+        if (t < T - 1) {
+            const double g1 = softplus_d(g1_raw[t]), g2 = softplus_d(g2_raw[t]);
+            const double p1 = digamma_d(g1), p2 = digamma_d(g2), p12 = digamma_d(g1 + g2);
+            // per stick t: part of E[log p(V|alpha)] and the Beta entropy
+            consts += (w1 / w2 - 1.0) * (p2 - p12) +
+                      (lgamma(g1) + lgamma(g2) - lgamma(g1 + g2) - (g1 - 1.0) * p1 - (g2 - 1.0) * p2 + (g1 + g2 - 2.0) * p12);
+        }
+        if (t == 0) {
+            const double pw = digamma_d(w1), lw2 = log(w2);
+            consts += (T - 1.0) * (pw - lw2)                                                   // rest of E[log p(V|alpha)]
+                      + s1 * log(s2) - lgamma(s1) + (s1 - 1.0) * (pw - lw2) - s2 * (w1 / w2)   // E[log p(alpha)]
+                      + w1 - lw2 + lgamma(w1) + (1.0 - w1) * pw;                               // Gamma entropy
+        }
+        hyper = block_sum(hyper, scratch);
+        consts = block_sum(consts, scratch);
+        if (t == 0) {
+            scal[0] = add_constants ? consts : 0.0;
+            scal[1] = hyper;
+        }
+        return;
     }
-    if (t < T) {
-        const double a = softplus_d(aat_raw[t]), b = softplus_d(bat_raw[t]);
-        aat[t] = a;
-        bat[t] = b;
-        const double la = log(a), lb = log(b);
-        hyper += -la - 0.5 * (DPGP_LOG_2PI + la * la) - lb - 0.5 * (DPGP_LOG_2PI + lb * lb);
-    }
-    const double w1 = softplus_d(w_raw[0]), w2 = softplus_d(w_raw[1]);
-    if (t < T - 1) {
-        const double g1 = softplus_d(g1_raw[t]), g2 = softplus_d(g2_raw[t]);
-        const double p1 = digamma_d(g1), p2 = digamma_d(g2), p12 = digamma_d(g1 + g2);
-        c1[t] = p1 - p12;
-        c2[t] = p2 - p12;
-        // D-independent pieces, per stick t: part of E[log p(V|alpha)] and the Beta entropy
-        consts += (w1 / w2 - 1.0) * (p2 - p12) +
-                  (lgamma(g1) + lgamma(g2) - lgamma(g1 + g2) - (g1 - 1.0) * p1 - (g2 - 1.0) * p2 + (g1 + g2 - 2.0) * p12);
-    }
-    if (t == 0) {
-        const double pw = digamma_d(w1), lw2 = log(w2);
-        consts += (T - 1.0) * (pw - lw2)                                                       // rest of E[log p(V|alpha)]
-                  + s1 * log(s2) - lgamma(s1) + (s1 - 1.0) * (pw - lw2) - s2 * (w1 / w2)       // E[log p(alpha)]
-                  + w1 - lw2 + lgamma(w1) + (1.0 - w1) * pw;                                   // Gamma entropy
-    }
+    // ---- row blocks: lane t of a wave = stick t of one output dim ----
+    __shared__ double gat[PREP_MAX_T * DPGP_MAX_Q];
+    for (int i = t; i < T * Q; i += 256) gat[i] = softplus_d(gat_raw[i]);
     __syncthreads();
-    // per output dim: phi = softmax(logits row), mixing, entropy of q(Z) and E[log p(Z|V)]
+    const bool on = lane < T;
+    const double aat = on ? softplus_d(aat_raw[lane]) : 0.0, bat = on ? softplus_d(bat_raw[lane]) : 0.0;
+    double c1 = 0.0, c2 = 0.0;                 // psi(g1)-psi(g1+g2), psi(g2)-psi(g1+g2) of stick `lane`
+    if (lane < T - 1) {
+        const double g1 = softplus_d(g1_raw[lane]), g2 = softplus_d(g2_raw[lane]);
+        const double p12 = digamma_d(g1 + g2);
+        c1 = digamma_d(g1) - p12;
+        c2 = digamma_d(g2) - p12;
+    }
     double dsum = 0.0;
-    for (int d = t; d < D; d += 256) {
-        const double *lr = logits + (size_t)((d_offset + d) / mask_size) * T;
-        double mx = lr[0];
-        for (int k = 1; k < T; ++k) mx = fmax(mx, lr[k]);
-        double z = 0.0;
-        for (int k = 0; k < T; ++k) z += exp(lr[k] - mx);
-        const double lz = log(z);
-        double al = 0.0, be = 0.0, ent = 0.0, ev = 0.0, tail = 0.0;
-        for (int k = T - 1; k >= 0; --k) {
-            const double lp = lr[k] - mx - lz, p = exp(lp);
-            if (phi_out) phi_out[(size_t)d * T + k] = p;
-            al += p * aat[k];
-            be += p * bat[k];
-            ent -= p * lp;
-            if (k < T - 1) ev += p * c1[k] + tail * c2[k];     // tail = sum_{j>k} phi_dj  (exclusive reverse cumsum)
-            tail += p;
+    const int rb = blockIdx.x - 1;
+    for (int rr = wv; rr < PREP_ROWS; rr += 4) {
+        const int d = rb * PREP_ROWS + rr;
+        if (d >= D) break;                                              // wave-uniform
+        const double lg = on ? logits[(size_t)((d_offset + d) / mask_size) * T + lane] : -1.0e300;
+        double mx = lg;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+        const double ex = on ? exp(lg - mx) : 0.0;
+        const double lz = log(wave_sum(ex));
+        const double lp = lg - mx - lz, p = on ? exp(lp) : 0.0;        // phi_dt = softmax (dirichlet_process.py:40-42)
+        if (phi_out && on) phi_out[(size_t)d * T + lane] = p;
+        // tail_t = sum_{j>t} phi_dj (exclusive reverse cumulative sum, :65): inclusive prefix sum, then total - prefix
+        double pre = p;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double v = __shfl_up(pre, o, 64);
+            if (lane >= o) pre += v;
         }
-        alpha[d] = al;
-        beta[d] = be;
+        const double tail = wave_sum(p) - pre;
+        double contrib = on ? -p * lp : 0.0;                             // entropy of q(Z) (:75)
+        if (lane < T - 1) contrib += p * c1 + tail * c2;                 // E[log p(Z|V)] (:64-66)
+        dsum += contrib;                                                 // (summed over lanes below)
+        const double al = wave_sum(p * aat), be = wave_sum(p * bat);     // mixing (dp_gp_lvm.py:100-102)
+        if (lane == 0) { alpha[d] = al; beta[d] = be; }
         for (int q = 0; q < Q; ++q) {
-            double g = 0.0;
-            for (int k = 0; k < T; ++k) g += exp(lr[k] - mx - lz) * gat[k * Q + q];
-            gamma[(size_t)d * Q + q] = g;
+            const double g = wave_sum(on ? p * gat[lane * Q + q] : 0.0);
+            if (lane == 0) gamma[(size_t)d * Q + q] = g;
         }
-        dsum += ev + ent;
     }
     dsum = block_sum(dsum, scratch);
-    hyper = block_sum(hyper, scratch);
-    consts = block_sum(consts, scratch);
-    if (t == 0) {
-        scal[0] = -(dsum + (add_constants ? consts : 0.0));   // this rank's share of the DP objective (= -ELBO_DP)
-        scal[1] = hyper;                                       // hyper-prior log-likelihood of the atoms (replicated)
-    }
+    if (t == 0) scal[2 + rb] = dsum;
 }
 
-// objective = DP objective - (f_hat - KL) - hyper-prior   (dp_gp_lvm.py:151-154); red = {sum f_hat, sum dp share}
-__global__ void model_finalize_kernel(const double *__restrict__ red, const double *__restrict__ kl,
-                                      const double *__restrict__ hyper, double *__restrict__ out) {
+// objective = DP objective - (f_hat - KL) - hyper-prior   (dp_gp_lvm.py:151-154)
+//   fhat / dp: device scalars (already summed over GPUs when D is sharded)
+__global__ void model_finalize_kernel(const double *__restrict__ fhat, const double *__restrict__ dp,
+                                      const double *__restrict__ kl, const double *__restrict__ hyper,
+                                      double *__restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        out[0] = red[1] - (red[0] - kl[0]) - hyper[0];
-        out[1] = red[0];
+        out[0] = dp[0] - (fhat[0] - kl[0]) - hyper[0];
+        out[1] = fhat[0];
         out[2] = kl[0];
-        out[3] = red[1];
+        out[3] = dp[0];
         out[4] = hyper[0];
     }
 }
+
+// pack[0] = f_hat, pack[1] = -(constants + sum of the row-block partials) = this GPU's share of the DP objective
+__global__ void model_pack_kernel(const double *__restrict__ fhat, const double *__restrict__ scal, int nrb,
+                                  double *__restrict__ pack) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double a = scal[0];
+        for (int i = 0; i < nrb; ++i) a += scal[2 + i];
+        pack[0] = fhat[0];
+        pack[1] = -a;
+    }
+}
+
+extern "C" int dpgp_model_scal_count(int D) { return D > 0 ? 2 + dpgp_ceil_div(D, PREP_ROWS) : 0; }
 
 extern "C" int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
                                   const double *gamma_atoms_raw, const double *alpha_atoms_raw,
@@ -280,21 +308,34 @@ extern "C" int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int 
     if (!beta) return -20;
     if (!s) return -21;
     if (!scal) return -23;
-    int sblocks = dpgp_ceil_div(N * Q, 256 * 4);
+    const int nrb = dpgp_ceil_div(D, PREP_ROWS);
+    int sblocks = dpgp_ceil_div(N * Q, 256 * 2);
     if (sblocks > 512) sblocks = 512;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_prepare_kernel, dim3(1 + sblocks), dim3(256), 0, (hipStream_t)stream, D, T, Q, N, d_offset,
-                       mask_size, logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw, g1_raw, g2_raw, w_raw,
-                       s1, s2, add_constants, gamma, alpha, beta, s, phi, scal);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_prepare_kernel, dim3(1 + nrb + sblocks), dim3(256), 0, (hipStream_t)stream, D, T, Q, N,
+                       d_offset, mask_size, nrb, logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw, g1_raw,
+                       g2_raw, w_raw, s1, s2, add_constants, gamma, alpha, beta, s, phi, scal);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
 
-extern "C" int dpgp_model_finalize(const double *red, const double *kl, const double *hyper, double *out, void *stream) {
-    if (!red) return -1;
+extern "C" int dpgp_model_pack(int D, const double *fhat, const double *scal, double *pack, void *stream) {
+    if (D <= 0) return -1;
+    if (!fhat) return -2;
+    if (!scal) return -3;
+    if (!pack) return -4;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_pack_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fhat, scal,
+                       dpgp_ceil_div(D, PREP_ROWS), pack);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
+extern "C" int dpgp_model_finalize(const double *pack, const double *kl, const double *hyper, double *out,
+                                   void *stream) {
+    if (!pack) return -1;
     if (!kl) return -2;
     if (!hyper) return -3;
     if (!out) return -4;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, red, kl, hyper, out);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pack, pack + 1, kl, hyper, out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }

@@ -117,15 +117,18 @@ def dp_gp_lvm(y_train,
     f64 = dict(dtype=TORCH_DTYPE, device=device)
     buf = dict(gamma=torch.empty((d_local, num_latent_dims), **f64), alpha=torch.empty((d_local, 1), **f64),
                beta=torch.empty((d_local, 1), **f64), s=torch.empty((num_samples, num_latent_dims), **f64),
-               phi=torch.empty((d_local, truncation_level), **f64), scal=torch.zeros(2, **f64),
+               phi=torch.empty((d_local, truncation_level), **f64),
+               scal=torch.zeros(_lib.lib().dpgp_model_scal_count(d_local), **f64),
                red=torch.zeros(2, **f64), out=torch.zeros(5, **f64))
     workspace = ops.ElboWorkspace(d_local, num_samples, num_inducing_points, num_latent_dims, precision, device)
     s_1, s_2 = dp_model.prior
 
-    def evaluate(events=None):
-        """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior)."""
+    def evaluate(events=None, out=None):
+        """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior).
+        Launches: prepare, [gram, chain_k on the side stream], kl_yy, psi1T_y, psi2, chain_b, sum, pack, finalize."""
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
         r = dp_model.raw
+        out = buf['out'] if out is None else out
         _lib.check(lib.dpgp_model_prepare(
             d_local, truncation_level, num_latent_dims, num_samples, d_lo, mask_size, r['logits'].data_ptr(),
             gamma_atoms_raw.data_ptr(), sig_var_atoms_raw.data_ptr(), beta_atoms_raw.data_ptr(), x_var_raw.data_ptr(),
@@ -135,13 +138,13 @@ def dp_gp_lvm(y_train,
         _, sums, _ = ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
                                    jitter=GP_DEFAULT_JITTER, prec=precision, workspace=workspace, events=events)
         red = buf['red']
-        red[0:1].copy_(sums[0:1])
-        red[1:2].copy_(buf['scal'][0:1])
+        _lib.check(lib.dpgp_model_pack(d_local, sums.data_ptr(), buf['scal'].data_ptr(), red.data_ptr(), st),
+                   'dpgp_model_pack')
         if world > 1:
             dist.all_reduce(red, op=dist.ReduceOp.SUM, group=process_group)    # the only exchange: 2 fp64 scalars
         _lib.check(lib.dpgp_model_finalize(red.data_ptr(), sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
-                                           buf['out'].data_ptr(), st), 'dpgp_model_finalize')
-        return buf['out']
+                                           out.data_ptr(), st), 'dpgp_model_finalize')
+        return out
 
     def _mixed():
         phi = dp_model.assignments                                               # [D x T], all output dims

@@ -148,18 +148,22 @@ float dpgp_event_elapsed_ms(void *begin, void *end);
  *   dpgp_model_prepare : from the RAW variational parameters (softplus / softmax parameterisation of utils/types.py:40-57,
  *     dirichlet_process.py:39-59) of the D output dims resident on this GPU (global index d_offset + d; logits row
  *     (d_offset+d)/mask_size) compute  phi[D,T] (optional), gamma[D,Q] = phi gamma_atoms, alpha[D], beta[D]
- *     (dp_gp_lvm.py:100-102), s[N,Q] = softplus(s_raw), and
- *       scal[0] = this GPU's share of the DP objective (dirichlet_process.py:64-88; the D-independent terms are added
- *                 iff add_constants != 0, i.e. on exactly one rank),
- *       scal[1] = hyper-prior log-likelihood of the atoms (dp_gp_lvm.py:96-98).
- *   dpgp_model_finalize: red[2] = {f_hat, DP objective} (summed over GPUs), kl[1], hyper[1] ->
+ *     (dp_gp_lvm.py:100-102), s[N,Q] = softplus(s_raw), and scal[dpgp_model_scal_count(D)]:
+ *       scal[0] = D-independent terms of the DP ELBO (dirichlet_process.py:68-77; 0 unless add_constants != 0, i.e. on
+ *                 exactly one rank), scal[1] = hyper-prior log-likelihood of the atoms (dp_gp_lvm.py:96-98),
+ *       scal[2..] = per-row-block partial sums of E[log p(Z|V)] + H[q(Z)] (dirichlet_process.py:64-66,75).
+ *   dpgp_model_pack    : pack[0] = f_hat (from the fused ELBO's sums[0]), pack[1] = this GPU's share of the DP objective
+ *                        (= -(sum of scal[0], scal[2..])): the 2-vector that is sum-all-reduced when D is sharded.
+ *   dpgp_model_finalize: pack[2] (summed over GPUs), kl[1], hyper[1] ->
  *       out[5] = {objective (dp_gp_lvm.py:154), f_hat, KL, DP objective, hyper-prior}.                               */
+int dpgp_model_scal_count(int D);
 int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
                        const double *gamma_atoms_raw, const double *alpha_atoms_raw, const double *beta_atoms_raw,
                        const double *s_raw, const double *g1_raw, const double *g2_raw, const double *w_raw, double s1,
                        double s2, int add_constants, double *gamma, double *alpha, double *beta, double *s, double *phi,
                        double *scal, void *stream);
-int dpgp_model_finalize(const double *red, const double *kl, const double *hyper, double *out, void *stream);
+int dpgp_model_pack(int D, const double *fhat, const double *scal, double *pack, void *stream);
+int dpgp_model_finalize(const double *pack, const double *kl, const double *hyper, double *out, void *stream);
 
 #ifdef __cplusplus
 }
