@@ -1,17 +1,16 @@
 // Fused per-output ELBO reduction (the hot path of dp_gp_lvm.py:108-148): no host synchronisation, no allocation —
 // graph-capturable.  Launch order on the main stream:
-//   1. KL(q(X)||p(X)) and y_d^T y_d partials                 (kl_yy_kernel)
-//   2. Psi1_d^T y_d partial slabs                            (psi1T_y_kernel)
-//   3. Psi2_d partial slabs on the matrix cores              (psi2_mfma_kernel)
-//   4. B = K + beta Psi2, bordered Cholesky, f_hat terms     (chain_b_kernel)
-//   5. f_hat = sum of terms                                   (sum_terms_kernel)
-// and, forked onto exec->aux_stream when the caller provides one (else in line before step 2):
-//   a. K_uu + jitter I                                        (gram_kernel)
-//   b. chol(K_uu), log-det, K_uu^-1                           (chain_k_kernel)   — overlaps steps 1-3
+//   1. Psi2_d partial slabs on the matrix cores              (psi2_f16_kernel / psi2_mfma_kernel)
+//   2. B = K + beta Psi2, bordered Cholesky, f_hat terms     (chain_b_kernel)
+//   3. f_hat = sum of terms, KL = sum of partials             (sum_terms_kernel)
+// preceded by  a. K_uu + jitter I (gram_kernel)  c. KL(q(X)||p(X)) and y_d^T y_d partials (kl_yy_kernel)
+//              d. Psi1_d^T y_d partial slabs (psi1T_y_kernel)
+// and, forked onto exec->aux_stream after (a) when the caller provides one (else in line after (a)):
+//              b. chol(K_uu), log-det, K_uu^-1 (chain_k_kernel) — D latency-bound workgroups that overlap c, d and psi2
 #include "internal.h"
 
 struct ElboLayout {
-    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, total;
+    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, off_kl, total;
     int ns1, ns2, Mp;
 };
 
@@ -25,6 +24,7 @@ static ElboLayout elbo_layout(int D, int N, int M, int prec) {
     L.off_yy = o; o += dpgp_align256(sizeof(double) * DPGP_YY_NCH * D);
     L.off_ld = o; o += dpgp_align256(sizeof(double) * D);
     L.off_ik = o; o += dpgp_align256(sizeof(int) * D);
+    L.off_kl = o; o += dpgp_align256(sizeof(double) * DPGP_KL_NBLK);
     L.off_v = o;  o += dpgp_align256(sizeof(double) * (size_t)L.ns1 * D * M);
     L.off_p2 = o; o += dpgp_align256(sp * (size_t)L.ns2 * D * L.Mp * L.Mp);
     L.off_la = o; o += dpgp_align256(sl * (size_t)D * la_chain_ws_elems(M));
@@ -48,22 +48,26 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     double *vpart = reinterpret_cast<double *>(ws + L.off_v);
     TP *p2 = reinterpret_cast<TP *>(ws + L.off_p2);
     TL *la = reinterpret_cast<TL *>(ws + L.off_la);
+    double *klp = reinterpret_cast<double *>(ws + L.off_kl);
     hipEvent_t ev0 = ex ? (hipEvent_t)ex->ev_psi2_begin : nullptr, ev1 = ex ? (hipEvent_t)ex->ev_psi2_end : nullptr;
     const bool fork = ex && ex->aux_stream && ex->ev_fork && ex->ev_join;
     hipStream_t sk = fork ? (hipStream_t)ex->aux_stream : st;
     int rc;
+    // K_uu first, on the main stream: it is short, and the side branch must be in flight before the ~1500 psi2 workgroups
+    // claim every CU slot (kernels submitted later to another queue only get slots as psi2 workgroups retire)
+    if ((rc = launch_gram<double, TL>(D, M, M, Q, z, nullptr, gamma, alpha, beta, DPGP_FLAG_JITTER, jitter, la, L.Mp,
+                                      la_chain_ws_elems(M), st)))
+        return rc;
     if (fork) {
         if (hipEventRecord((hipEvent_t)ex->ev_fork, st) != hipSuccess) return DPGP_ERR_LAUNCH;
         if (hipStreamWaitEvent(sk, (hipEvent_t)ex->ev_fork, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
     }
-    // K_uu branch
-    if ((rc = launch_gram<double, TL>(D, M, M, Q, z, nullptr, gamma, alpha, beta, DPGP_FLAG_JITTER, jitter, la, L.Mp,
-                                      la_chain_ws_elems(M), sk)))
-        return rc;
+    // side branch (latency-bound, D workgroups): Cholesky, log-det and inverse of K_uu.  It starts together with the
+    // short KL / y'y / Psi1^T y kernels, i.e. while CU slots are still free, and keeps its slots while psi2 runs.
     if ((rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, sk))) return rc;
     if (fork && hipEventRecord((hipEvent_t)ex->ev_join, sk) != hipSuccess) return DPGP_ERR_LAUNCH;
-    // psi-statistics branch
-    if ((rc = launch_kl_yy<double>(N, Q, mu, s, sums + 1, D, y, ldy, yy, st))) return rc;
+    // main branch
+    if ((rc = launch_kl_yy<double>(N, Q, mu, s, klp, D, y, ldy, yy, st))) return rc;
     if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, st)))
         return rc;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
@@ -74,7 +78,9 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info, la, algo,
                                      st)))
         return rc;
-    return launch_sum_terms(D, terms, sums, st);
+    // f_hat and KL; with the model-level pointers of exec also the packed pair / the finished objective, in the same launch
+    return launch_sum_terms(D, terms, klp, sums, ex ? (const double *)ex->model_scal : nullptr,
+                            ex ? (double *)ex->model_pack : nullptr, ex ? (double *)ex->model_out : nullptr, st);
 }
 
 extern "C" int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z,
@@ -157,10 +163,10 @@ __device__ double digamma_d(double x) {
 }
 
 #define PREP_MAX_T 64
-#define PREP_ROWS 16   // output dims per row-block (4 waves x 4 rows)
+#define PREP_ROWS DPGP_PREP_ROWS   // output dims per row-block
 
-// grid: block 0 = atoms, hyper-prior and the D-independent DP terms; blocks 1..nrb = PREP_ROWS output dims each (one wave
-// per row, lane t = stick t); remaining blocks = softplus of the q(X) variances.
+// grid: block 0 = atoms, hyper-prior and the D-independent DP terms; blocks 1..nrb = PREP_ROWS output dims each (thread per
+// (d, column)); remaining blocks = softplus of the q(X) variances.
 //   scal[0] = D-independent DP terms (0 unless add_constants), scal[1] = hyper-prior, scal[2 + rb] = row-block partials.
 __global__ __launch_bounds__(256) void model_prepare_kernel(
     int D, int T, int Q, int N, int d_offset, int mask_size, int nrb, const double *__restrict__ logits,
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void model_prepare_kernel(
     const double *__restrict__ w_raw, double s1, double s2, int add_constants, double *__restrict__ gamma,
     double *__restrict__ alpha, double *__restrict__ beta, double *__restrict__ s_out, double *__restrict__ phi_out,
     double *__restrict__ scal) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x;
     __shared__ double scratch[8];
     if ((int)blockIdx.x > nrb) {   // q(X) variances: s = softplus(raw)   (dp_gp_lvm.py:67-69, utils/types.py:40-57)
         const size_t tot = (size_t)N * Q;
@@ -207,48 +213,51 @@ __global__ __launch_bounds__(256) void model_prepare_kernel(
         }
         return;
     }
-    // ---- row blocks: lane t of a wave = stick t of one output dim ----
-    __shared__ double gat[PREP_MAX_T * DPGP_MAX_Q];
+    // ---- row blocks: thread = (output dim d, column j); j < Q: gamma_dj, j == Q: alpha, beta, phi row and the DP terms ----
+    __shared__ double gat[PREP_MAX_T * DPGP_MAX_Q], aat[PREP_MAX_T], bat[PREP_MAX_T];
+    __shared__ double c1[PREP_MAX_T], c2[PREP_MAX_T];   // psi(g1)-psi(g1+g2), psi(g2)-psi(g1+g2)
     for (int i = t; i < T * Q; i += 256) gat[i] = softplus_d(gat_raw[i]);
-    __syncthreads();
-    const bool on = lane < T;
-    const double aat = on ? softplus_d(aat_raw[lane]) : 0.0, bat = on ? softplus_d(bat_raw[lane]) : 0.0;
-    double c1 = 0.0, c2 = 0.0;                 // psi(g1)-psi(g1+g2), psi(g2)-psi(g1+g2) of stick `lane`
-    if (lane < T - 1) {
-        const double g1 = softplus_d(g1_raw[lane]), g2 = softplus_d(g2_raw[lane]);
-        const double p12 = digamma_d(g1 + g2);
-        c1 = digamma_d(g1) - p12;
-        c2 = digamma_d(g2) - p12;
+    if (t < T) {
+        aat[t] = softplus_d(aat_raw[t]);
+        bat[t] = softplus_d(bat_raw[t]);
     }
+    if (t >= 64 && t - 64 < T - 1) {
+        const int k = t - 64;
+        const double g1 = softplus_d(g1_raw[k]), g2 = softplus_d(g2_raw[k]);
+        const double p12 = digamma_d(g1 + g2);
+        c1[k] = digamma_d(g1) - p12;
+        c2[k] = digamma_d(g2) - p12;
+    }
+    __syncthreads();
+    const int rb = blockIdx.x - 1, cols = Q + 1;
     double dsum = 0.0;
-    const int rb = blockIdx.x - 1;
-    for (int rr = wv; rr < PREP_ROWS; rr += 4) {
-        const int d = rb * PREP_ROWS + rr;
-        if (d >= D) break;                                              // wave-uniform
-        const double lg = on ? logits[(size_t)((d_offset + d) / mask_size) * T + lane] : -1.0e300;
-        double mx = lg;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-        const double ex = on ? exp(lg - mx) : 0.0;
-        const double lz = log(wave_sum(ex));
-        const double lp = lg - mx - lz, p = on ? exp(lp) : 0.0;        // phi_dt = softmax (dirichlet_process.py:40-42)
-        if (phi_out && on) phi_out[(size_t)d * T + lane] = p;
-        // tail_t = sum_{j>t} phi_dj (exclusive reverse cumulative sum, :65): inclusive prefix sum, then total - prefix
-        double pre = p;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double v = __shfl_up(pre, o, 64);
-            if (lane >= o) pre += v;
-        }
-        const double tail = wave_sum(p) - pre;
-        double contrib = on ? -p * lp : 0.0;                             // entropy of q(Z) (:75)
-        if (lane < T - 1) contrib += p * c1 + tail * c2;                 // E[log p(Z|V)] (:64-66)
-        dsum += contrib;                                                 // (summed over lanes below)
-        const double al = wave_sum(p * aat), be = wave_sum(p * bat);     // mixing (dp_gp_lvm.py:100-102)
-        if (lane == 0) { alpha[d] = al; beta[d] = be; }
-        for (int q = 0; q < Q; ++q) {
-            const double g = wave_sum(on ? p * gat[lane * Q + q] : 0.0);
-            if (lane == 0) gamma[(size_t)d * Q + q] = g;
+    for (int e = t; e < PREP_ROWS * cols; e += 256) {
+        const int rr = e / cols, j = e - rr * cols, d = rb * PREP_ROWS + rr;
+        if (d >= D) continue;
+        const double *lr = logits + (size_t)((d_offset + d) / mask_size) * T;
+        double mx = lr[0];
+        for (int k = 1; k < T; ++k) mx = fmax(mx, lr[k]);
+        double zsum = 0.0;
+        for (int k = 0; k < T; ++k) zsum += exp(lr[k] - mx);
+        const double lz = log(zsum);
+        if (j < Q) {                                                     // mixing (dp_gp_lvm.py:100)
+            double g = 0.0;
+            for (int k = 0; k < T; ++k) g += exp(lr[k] - mx - lz) * gat[k * Q + j];
+            gamma[(size_t)d * Q + j] = g;
+        } else {
+            double al = 0.0, be = 0.0, ent = 0.0, ev = 0.0, tail = 0.0;
+            for (int k = T - 1; k >= 0; --k) {
+                const double lp = lr[k] - mx - lz, p = exp(lp);        // phi_dt = softmax (dirichlet_process.py:40-42)
+                if (phi_out) phi_out[(size_t)d * T + k] = p;
+                al += p * aat[k];
+                be += p * bat[k];
+                ent -= p * lp;                                           // entropy of q(Z) (:75)
+                if (k < T - 1) ev += p * c1[k] + tail * c2[k];           // E[log p(Z|V)] (:64-66); tail = sum_{j>k} phi_dj
+                tail += p;
+            }
+            alpha[d] = al;                                               // (dp_gp_lvm.py:101-102)
+            beta[d] = be;
+            dsum += ev + ent;
         }
     }
     dsum = block_sum(dsum, scratch);

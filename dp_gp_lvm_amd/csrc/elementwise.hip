@@ -307,7 +307,7 @@ __global__ void sum_slabs_kernel(size_t n, int ns, const double *__restrict__ pa
 // ---------------------------------------------------------------------------------------------------------------
 // KL(q(X) || N(0,I)) (gp_expressions.py:18-23) and, in the same launch, y_d^T y_d for the data-fit term
 // (dp_gp_lvm.py:143-144; the reference forms the whole [D,D] product and takes its diagonal).
-//   block 0      : KL  -> kl_out[0]
+//   blocks 0..DPGP_KL_NBLK-1 : KL partial sums -> kl_out[DPGP_KL_NBLK] (summed in fixed order by the consumer)
 //   other blocks : (64 consecutive d) x (one of YY_NCH chunks of n); coalesced along d, 4 waves stride over n, partial
 //                  sums written to yy_out[chunk][d] (DPGP_YY_NCH slabs, summed in fixed order by the consumer: deterministic)
 // ---------------------------------------------------------------------------------------------------------------
@@ -318,25 +318,19 @@ __global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__r
                                                     const TIN *__restrict__ y, int ldy, double *__restrict__ yy_out) {
     __shared__ double scratch[4][64];
     const int t = threadIdx.x;
-    if (blockIdx.x == 0) {
+    if (blockIdx.x < DPGP_KL_NBLK) {      // KL partials: block k handles every DPGP_KL_NBLK-th run of 256 elements
         if (kl_out == nullptr) return;
-        double a0 = 0.0, a1 = 0.0;
+        double a0 = 0.0;
         const size_t tot = (size_t)N * Q;
-        size_t i = t;
-        for (; i + 256 < tot; i += 512) {
-            const double m0 = (double)mu[i], v0 = (double)s[i], m1 = (double)mu[i + 256], v1 = (double)s[i + 256];
-            a0 += m0 * m0 + v0 - log(v0);
-            a1 += m1 * m1 + v1 - log(v1);
-        }
-        for (; i < tot; i += 256) {
+        for (size_t i = (size_t)blockIdx.x * 256 + t; i < tot; i += (size_t)DPGP_KL_NBLK * 256) {
             const double m0 = (double)mu[i], v0 = (double)s[i];
-            a0 += m0 * m0 + v0 - log(v0);
+            a0 += m0 * m0 + v0 - log(v0) - 1.0;
         }
-        const double a = block_sum(a0 + a1, &scratch[0][0]);
-        if (t == 0) kl_out[0] = 0.5 * (a - (double)N * (double)Q);
+        const double a = block_sum(a0, &scratch[0][0]);
+        if (t == 0) kl_out[blockIdx.x] = 0.5 * a;     // sum over blocks = 1/2 (sum mu^2 + sum (s - log s) - N Q)
         return;
     }
-    const int bid = blockIdx.x - 1, dblk = bid / YY_NCH, ch = bid - dblk * YY_NCH;
+    const int bid = blockIdx.x - DPGP_KL_NBLK, dblk = bid / YY_NCH, ch = bid - dblk * YY_NCH;
     const int d = dblk * 64 + (t & 63), wv = t >> 6;
     const int nper = (N + YY_NCH - 1) / YY_NCH, n0 = ch * nper, n1 = min(N, n0 + nper);
     double a0 = 0.0, a1 = 0.0;
@@ -360,7 +354,7 @@ __global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__r
 template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
                  double *yy_out, hipStream_t st) {
-    int blocks = 1;
+    int blocks = DPGP_KL_NBLK;
     if (yy_out) {
         blocks += dpgp_ceil_div(D, 64) * YY_NCH;
     }
@@ -486,14 +480,29 @@ extern "C" int dpgp_psi1T_y_f64(int B, int N, int M, int Q, const double *z, con
     return psi1T_y_api<double>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, out, ws, ws_bytes, stream);
 }
 
-template <typename T> static int kl_api(int N, int Q, const T *mu, const T *s, double *out, void *stream) {
-    CHECK_ARG(N > 0, 1); CHECK_ARG(Q > 0, 2); CHECK_ARG(mu, 3); CHECK_ARG(s, 4); CHECK_ARG(out, 5);
-    return launch_kl_yy<T>(N, Q, mu, s, out, 0, nullptr, 0, nullptr, (hipStream_t)stream);
+__global__ void kl_single_block_kernel(int N, int Q, const float *muf, const float *sf, const double *mud,
+                                       const double *sd, double *out) {
+    __shared__ double scratch[8];
+    double a = 0.0;
+    const size_t tot = (size_t)N * Q;
+    for (size_t i = threadIdx.x; i < tot; i += 256) {
+        const double m0 = muf ? (double)muf[i] : mud[i], v0 = sf ? (double)sf[i] : sd[i];
+        a += m0 * m0 + v0 - log(v0) - 1.0;
+    }
+    a = block_sum(a, scratch);
+    if (threadIdx.x == 0) out[0] = 0.5 * a;
+}
+static int kl_api_launch(int N, int Q, const float *muf, const float *sf, const double *mud, const double *sd,
+                         double *out, void *stream) {
+    CHECK_ARG(N > 0, 1); CHECK_ARG(Q > 0, 2); CHECK_ARG(muf || mud, 3); CHECK_ARG(sf || sd, 4); CHECK_ARG(out, 5);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kl_single_block_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, N, Q, muf, sf, mud, sd, out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
 }
 extern "C" int dpgp_kl_qx_f32(int N, int Q, const float *mu, const float *s, double *out, void *stream) {
-    return kl_api<float>(N, Q, mu, s, out, stream);
+    return kl_api_launch(N, Q, mu, s, nullptr, nullptr, out, stream);
 }
 extern "C" int dpgp_kl_qx_f64(int N, int Q, const double *mu, const double *s, double *out, void *stream) {
-    return kl_api<double>(N, Q, mu, s, out, stream);
+    return kl_api_launch(N, Q, nullptr, nullptr, mu, s, out, stream);
 }
 extern "C" int dpgp_version(void) { return 100; }

@@ -15,8 +15,9 @@ template <typename TIN, typename T>
 int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                            const TIN *alpha, const TIN *y, int ldy, double *part, int ns, hipStream_t st);
 
-// yy_out: DPGP_YY_NCH partial slabs [DPGP_YY_NCH][D]
+// yy_out: DPGP_YY_NCH partial slabs [DPGP_YY_NCH][D];  kl_out: DPGP_KL_NBLK partial sums (their total is 2 KL + N Q)
 #define DPGP_YY_NCH 16
+#define DPGP_KL_NBLK 16
 template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
                  double *yy_out, hipStream_t st);
@@ -40,4 +41,9 @@ template <typename TP, typename TL>
 int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1,
                    const double *alpha, const double *beta, const double *yy_part, const double *logdet_k,
                    const int *info_k, double *terms, int *info, TL *ws, int algo, hipStream_t st);
-int launch_sum_terms(int D, const double *terms, double *sums, hipStream_t st);
+// sums[0] = sum of terms (f_hat); sums[1] = KL from the DPGP_KL_NBLK partials (kl_part may be null: sums[1] untouched)
+//   model_scal (optional, see dpgp_model_prepare): also pack[0..1] = {f_hat, this GPU's DP-objective share} and, if out is
+//   given, out[0..4] = {objective, f_hat, KL, DP objective, hyper-prior} (single-GPU finalisation) in the same launch
+int launch_sum_terms(int D, const double *terms, const double *kl_part, double *sums, const double *model_scal,
+                     double *model_pack, double *model_out, hipStream_t st);
+#define DPGP_PREP_ROWS 16   // output dims per row-block of dpgp_model_prepare (scal has 2 + ceil(D / 16) entries)

@@ -620,15 +620,47 @@ INST_CHAIN_B(float, double)
 INST_CHAIN_B(double, double)
 
 __global__ __launch_bounds__(256) void sum_terms_kernel(int D, const double *__restrict__ terms,
-                                                        double *__restrict__ sums) {
+                                                        const double *__restrict__ kl_part,
+                                                        double *__restrict__ sums,
+                                                        const double *__restrict__ model_scal,
+                                                        double *__restrict__ model_pack,
+                                                        double *__restrict__ model_out) {
     __shared__ double scratch[8];
     double a = 0.0;
     for (int i = threadIdx.x; i < D * 5; i += 256) a += terms[i];
     a = block_sum(a, scratch);
-    if (threadIdx.x == 0) sums[0] = a;
+    if (threadIdx.x == 0) {
+        sums[0] = a;
+        double kl = sums[1];
+        if (kl_part) {
+            kl = 0.0;
+            for (int i = 0; i < DPGP_KL_NBLK; ++i) kl += kl_part[i];
+            sums[1] = kl;
+        }
+        if (model_scal) {    // dp_gp_lvm.py:151-154 (see dpgp_model_pack / dpgp_model_finalize)
+            double dp = model_scal[0];
+            const int nrb = (D + DPGP_PREP_ROWS - 1) / DPGP_PREP_ROWS;
+            for (int i = 0; i < nrb; ++i) dp += model_scal[2 + i];
+            dp = -dp;
+            if (model_pack) {
+                model_pack[0] = a;
+                model_pack[1] = dp;
+            }
+            if (model_out) {
+                const double hyper = model_scal[1];
+                model_out[0] = dp - (a - kl) - hyper;
+                model_out[1] = a;
+                model_out[2] = kl;
+                model_out[3] = dp;
+                model_out[4] = hyper;
+            }
+        }
+    }
 }
-int launch_sum_terms(int D, const double *terms, double *sums, hipStream_t st) {
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(sum_terms_kernel, dim3(1), dim3(256), 0, st, D, terms, sums);
+int launch_sum_terms(int D, const double *terms, const double *kl_part, double *sums, const double *model_scal,
+                     double *model_pack, double *model_out, hipStream_t st) {
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(sum_terms_kernel, dim3(1), dim3(256), 0, st, D, terms, kl_part, sums, model_scal, model_pack,
+                       model_out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }

@@ -21,12 +21,22 @@
 
 #define PSI2_NT 32   // n per LDS tile
 
-__device__ __forceinline__ void patch_from_index(int p, int &pi, int &pj) {
-    int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
-    while ((i + 1) * (i + 2) / 2 <= p) ++i;
-    while (i * (i + 1) / 2 > p) --i;
-    pi = i;
-    pj = p - i * (i + 1) / 2;
+// Workgroup coordinates.  grid = (B, n-splits, patches); the patch index is the SLOWEST dimension and enumerates the
+// off-diagonal patches (16 tiles of work) before the diagonal ones (10 tiles), so the long workgroups are dispatched
+// first and the short ones fill the tail.
+__device__ __forceinline__ void psi2_block_coords(int nps, int &b, int &sp, int &pi, int &pj) {
+    b = blockIdx.x;
+    sp = blockIdx.y;
+    const int p = blockIdx.z, noff = nps * (nps - 1) / 2;
+    if (p < noff) {                    // strict lower triangle: p = pi (pi - 1) / 2 + pj, pj < pi
+        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        while (i * (i - 1) / 2 > p) --i;
+        while ((i + 1) * i / 2 <= p) ++i;
+        pi = i;
+        pj = p - i * (i - 1) / 2;
+    } else {
+        pi = pj = p - noff;
+    }
 }
 
 // LDS geometry shared by the kernel and the host-side size computation
@@ -56,7 +66,7 @@ template <typename TIN, typename T, int KS, int PT, bool DIAG>
 __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN *__restrict__ z,
                                            const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                            const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
-                                           T *__restrict__ part, int Mp, int n_per_split, int pi, int pj,
+                                           T *__restrict__ part, int Mp, int n_per_split, int b, int sp, int pi, int pj,
                                            unsigned char *smem_raw) {
     typedef Psi2Lds<T, KS, PT> G;
     constexpr int PS = G::PS, KP = G::KP, ZLD = G::ZLD, PLD = G::PLD, NR = G::NR;
@@ -64,7 +74,6 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
     T *zs = reinterpret_cast<T *>(smem_raw);        // [2*PS][ZLD] centred z rows: m-block then m'-block (0 beyond Q / M)
     T *zc = zs + 2 * PS * ZLD;                       // [Q]  column means of z
     T *gq = zc + DPGP_MAX_Q + 2;                     // [Q]  gamma_b
-    const int b = blockIdx.y, sp = blockIdx.z;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
     const int m_base = pi * PS, mp_base = pj * PS;
     T *wp = zs + G::OFF_W + wv * G::WSZ;             // this wave's private region
@@ -321,14 +330,13 @@ template <typename TIN, int KB, bool DIAG>
 __device__ __forceinline__ void psi2_patch_f16(int N, int M, int Q, int B, const TIN *__restrict__ z,
                                                const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                                const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
-                                               float *__restrict__ part, int Mp, int n_per_split, int pi, int pj,
-                                               unsigned char *smem_raw) {
+                                               float *__restrict__ part, int Mp, int n_per_split, int b, int sp, int pi,
+                                               int pj, unsigned char *smem_raw) {
     typedef Psi2F16Lds<KB> G;
     constexpr int PT = G::PT, PS = G::PS, KF = G::KF, KQ = G::KQ, XLD = G::XLD, ZLD = G::ZLD, PLD = G::PLD, NR = G::NR;
     float *zs = reinterpret_cast<float *>(smem_raw);     // [2*PS][ZLD] centred z rows: m-block then m'-block
     float *zc = zs + 2 * PS * ZLD;                        // [Q] column means of z
     float *gq = zc + DPGP_MAX_Q + 2;                      // [Q] gamma_b
-    const int b = blockIdx.y, sp = blockIdx.z;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
     const int m_base = pi * PS, mp_base = pj * PS;
     float *wp = zs + G::OFF_W + wv * G::WSZ;
@@ -551,12 +559,12 @@ __global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, in
                                                        const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
                                                        float *__restrict__ part, int Mp, int n_per_split) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    int pi, pj;
-    patch_from_index(blockIdx.x, pi, pj);
+    int b, sp, pi, pj;
+    psi2_block_coords((Mp + 63) / 64, b, sp, pi, pj);
     if (pi == pj)
-        psi2_patch_f16<TIN, KB, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, pi, pj, smem_raw);
+        psi2_patch_f16<TIN, KB, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
     else
-        psi2_patch_f16<TIN, KB, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, pi, pj, smem_raw);
+        psi2_patch_f16<TIN, KB, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
 }
 
 template <typename TIN, typename T, int KS, int PT>
@@ -565,12 +573,12 @@ __global__ __launch_bounds__(256) void psi2_mfma_kernel(int N, int M, int Q, int
                                                         const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
                                                         T *__restrict__ part, int Mp, int n_per_split) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    int pi, pj;
-    patch_from_index(blockIdx.x, pi, pj);
+    int b, sp, pi, pj;
+    psi2_block_coords((Mp + 16 * PT - 1) / (16 * PT), b, sp, pi, pj);
     if (pi == pj)
-        psi2_patch<TIN, T, KS, PT, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, pi, pj, smem_raw);
+        psi2_patch<TIN, T, KS, PT, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
     else
-        psi2_patch<TIN, T, KS, PT, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, pi, pj, smem_raw);
+        psi2_patch<TIN, T, KS, PT, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
 }
 
 // Plain-VALU variant (cross-check of the matrix-core kernel): thread per (m, m') of the lower block-triangle, literal
@@ -648,13 +656,21 @@ template <typename T, int KS> static size_t psi2_lds_bytes() {
 }
 
 int psi2_nsplit(int B, int N, int M) {
-    // enough workgroups for >= 2 per CU (512); never fewer than 4 LDS tiles of n per split
-    int np64 = dpgp_ceil_div(M, 64);
-    int wgs = B * np64 * (np64 + 1) / 2;
-    int ns = dpgp_ceil_div(512, wgs);
-    int max_ns = dpgp_ceil_div(N, 4 * PSI2_NT);
-    if (ns > max_ns) ns = max_ns;
-    return ns < 1 ? 1 : ns;
+    // Split the observations so that the workgroups fill whole "rounds" of the GPU: R = 256 CUs x 2 resident workgroups
+    // (the fp32 kernel holds 2 waves per SIMD).  With W = B * patches * ns workgroups of N / ns rows each, the makespan
+    // is ~ ceil(W / R) * N / ns: take the ns (<= 8, >= 128 rows per split) that minimises it.
+    const int np64 = dpgp_ceil_div(M, 64), patches = np64 * (np64 + 1) / 2, R = 512;
+    int max_ns = N / 128;
+    if (max_ns > 8) max_ns = 8;
+    if (max_ns < 1) max_ns = 1;
+    int best = 1;
+    double best_t = 1e300;
+    for (int ns = 1; ns <= max_ns; ++ns) {
+        const long long W = (long long)B * patches * ns;
+        const double t = (double)((W + R - 1) / R) / (double)ns;
+        if (t < best_t * 0.999) { best_t = t; best = ns; }
+    }
+    return best;
 }
 
 template <typename TIN, typename T, int KS>
@@ -664,7 +680,7 @@ static int launch_psi2_ks(int B, int N, int M, int Q, const TIN *z, const TIN *m
     const int Mp = dpgp_round_up(M, 16);
     const int nps = dpgp_ceil_div(Mp, PS);
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
-    dim3 grid(nps * (nps + 1) / 2, B, ns);
+    dim3 grid(B, ns, nps * (nps + 1) / 2);
     size_t lds = psi2_lds_bytes<T, KS>();
     auto kern = psi2_mfma_kernel<TIN, T, KS, PT>;
     if (lds > 48 * 1024) {
@@ -683,7 +699,7 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
     const int Mp = dpgp_round_up(M, 16);
     const int nps = dpgp_ceil_div(Mp, 64);
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
-    dim3 grid(nps * (nps + 1) / 2, B, ns);
+    dim3 grid(B, ns, nps * (nps + 1) / 2);
     size_t lds = sizeof(float) * (size_t)Psi2F16Lds<KB>::ELEMS;
     auto kern = psi2_f16_kernel<TIN, KB>;
     if (lds > 48 * 1024) {

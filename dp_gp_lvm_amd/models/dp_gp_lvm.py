@@ -125,7 +125,7 @@ def dp_gp_lvm(y_train,
 
     def evaluate(events=None, out=None):
         """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior).
-        Launches: prepare, [gram, chain_k on the side stream], kl_yy, psi1T_y, psi2, chain_b, sum, pack, finalize."""
+        Launches: prepare, gram, [chain_k on the side stream], kl_yy, psi1T_y, psi2, chain_b, tail (sum+pack+finalize)."""
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
         r = dp_model.raw
         out = buf['out'] if out is None else out
@@ -135,15 +135,15 @@ def dp_gp_lvm(y_train,
             r['gamma_1'].data_ptr(), r['gamma_2'].data_ptr(), r['w'].data_ptr(), s_1, s_2, 1 if rank == 0 else 0,
             buf['gamma'].data_ptr(), buf['alpha'].data_ptr(), buf['beta'].data_ptr(), buf['s'].data_ptr(),
             buf['phi'].data_ptr(), buf['scal'].data_ptr(), st), 'dpgp_model_prepare')
-        _, sums, _ = ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
-                                   jitter=GP_DEFAULT_JITTER, prec=precision, workspace=workspace, events=events)
         red = buf['red']
-        _lib.check(lib.dpgp_model_pack(d_local, sums.data_ptr(), buf['scal'].data_ptr(), red.data_ptr(), st),
-                   'dpgp_model_pack')
+        # single GPU: the last kernel of the fused ELBO also packs and finalises; sharded: it packs, then one all-reduce
+        _, sums, _ = ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
+                                   jitter=GP_DEFAULT_JITTER, prec=precision, workspace=workspace, events=events,
+                                   model_tail=(buf['scal'], red, out if world == 1 else None))
         if world > 1:
             dist.all_reduce(red, op=dist.ReduceOp.SUM, group=process_group)    # the only exchange: 2 fp64 scalars
-        _lib.check(lib.dpgp_model_finalize(red.data_ptr(), sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
-                                           out.data_ptr(), st), 'dpgp_model_finalize')
+            _lib.check(lib.dpgp_model_finalize(red.data_ptr(), sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
+                                               out.data_ptr(), st), 'dpgp_model_finalize')
         return out
 
     def _mixed():

@@ -205,7 +205,9 @@ class ElboWorkspace:
         self.aux = None
         if overlap:
             with torch.cuda.device(device):
-                self.aux = torch.cuda.Stream(device=device)
+                # high priority: the side branch is short and latency-bound; its workgroups must not queue behind the
+                # ~1500 psi2 workgroups that otherwise own every CU slot
+                self.aux = torch.cuda.Stream(device=device, priority=-1)
                 self._events = [l.dpgp_event_create(), l.dpgp_event_create()]
             self.exec.aux_stream = self.aux.cuda_stream
             self.exec.ev_fork, self.exec.ev_join = self._events
@@ -218,7 +220,8 @@ class ElboWorkspace:
             pass
 
 
-def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None, events=None):
+def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None, events=None,
+              model_tail=None):
     """
     The fused per-output ELBO reduction of dp_gp_lvm.py:108-148 for the D output dims in ``y`` [N,D] (a column slice of
     the full data when D is sharded over GPUs).  All inputs fp64 device tensors.
@@ -238,6 +241,10 @@ def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='
     assert w.shape == (d, n, m, q) and w.prec == prec, 'workspace was sized for another problem'
     ev0, ev1 = events if events is not None else (None, None)     # optional hipEvent handles around the psi2 kernel
     w.exec.ev_psi2_begin, w.exec.ev_psi2_end = ev0, ev1
+    # model_tail = (scal, pack, out) device tensors (out may be None): fold dpgp_model_pack / _finalize into the last launch
+    w.exec.model_scal, w.exec.model_pack, w.exec.model_out = (
+        (None, None, None) if model_tail is None else
+        tuple(None if t_ is None else t_.data_ptr() for t_ in model_tail))
     import ctypes
     _lib.check(_lib.lib().dpgp_elbo_fhat_ex(d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(),
                                             s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(),

@@ -127,6 +127,9 @@ int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const d
  *       it is joined back into `stream` before the final per-output Cholesky.  NULL: everything runs in order on `stream`.
  *   ev_psi2_begin / ev_psi2_end    : hipEvent_t recorded on `stream` immediately before / after the psi2 kernel so that
  *       a harness can time the dominant kernel inside its timed region; either may be NULL.
+ *   model_scal / model_pack / model_out : fold the model-level tail into the last launch.  model_scal = the scal array
+ *       written by dpgp_model_prepare for the same D; then model_pack[2] (if given) receives what dpgp_model_pack would
+ *       write and model_out[5] (if given; single-GPU case) what dpgp_model_finalize would write.  NULL: not done.
  * exec itself may be NULL (= dpgp_elbo_fhat).                                                                        */
 typedef struct dpgp_exec {
     void *aux_stream;
@@ -134,6 +137,9 @@ typedef struct dpgp_exec {
     void *ev_join;
     void *ev_psi2_begin;
     void *ev_psi2_end;
+    const double *model_scal;
+    double *model_pack;
+    double *model_out;
 } dpgp_exec_t;
 int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
