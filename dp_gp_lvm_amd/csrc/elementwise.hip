@@ -267,6 +267,146 @@ __global__ __launch_bounds__(256) void psi1T_y_kernel(int N, int M, int Q, int B
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K2f on the matrix pipe (fp32 results): the exponent of psi1 is a rank-(2Q+1) form in (n, m),
+//      log2 psi1[n,m] / alpha = c_n + sum_q a_nq z_mq^2 + sum_q b_nq z_mq,     a = -1/2 w1 log2e,  b = w1 (mu-c) log2e,
+//      c_n = -1/2 log2e sum_q ( w1 (mu-c)^2 + log(g s + 1) ),   w1 = g / (g s + 1),   z centred by its column mean c,
+// evaluated tile by tile as [16 n x K] x [K x 16 m] with v_mfma_f32_16x16x32_f16 on f16 hi/lo-split operands (three
+// products per term, see psi2.hip), K = 6Q + 2 slots; then v[m] += y_n exp2(E[n,m]).  Per 256 (n,m) pairs: 2-6 MFMAs,
+// 4 v_exp_f32 and 4 FMAs per lane instead of ~40 VALU ops per pair.
+//   slot 3t+{0,1,2} of term t (t = 2q: (a, z^2), t = 2q+1: (b, z)):  A = {h, h, l},  B = {h, l, h};   slots 6Q, 6Q+1: (c_h, c_l) x (1, 1)
+// grid (ns, ceil(M/128), B); each wave takes every 4th 16-row tile of the split and owns a 2 KB LDS operand image.
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 p1_h8 __attribute__((ext_vector_type(8)));
+typedef float p1_f4 __attribute__((ext_vector_type(4)));
+
+template <typename TIN, int KF1>
+__global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                                          const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                                          const TIN *__restrict__ gamma,
+                                                          const TIN *__restrict__ alpha, const TIN *__restrict__ y,
+                                                          int ldy, double *__restrict__ part, int n_per_split) {
+    constexpr int SL = 32 * KF1;                          // K slots (f16) per row of an operand image
+    __shared__ __align__(16) _Float16 bimg[128 * SL];     // m-side image of this 128-column chunk
+    __shared__ __align__(16) _Float16 aimg[4][16 * SL];   // n-side image, one per wave
+    __shared__ float yv[4][16];
+    __shared__ float zc[DPGP_MAX_Q + 2], gq[DPGP_MAX_Q + 2];
+    __shared__ float red[16][128];
+    const int b = blockIdx.z, mc = blockIdx.y * 128, sp = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
+    if (t < Q) {
+        gq[t] = (float)gamma[(size_t)b * Q + t];
+        double a = 0.0;
+        for (int m = 0; m < M; ++m) a += (double)z[(size_t)m * Q + t];
+        zc[t] = (float)(a / (double)M);
+    }
+    for (int e = t; e < 128 * SL; e += 256) bimg[e] = (_Float16)0.0f;
+    for (int e = t; e < 4 * 16 * SL; e += 256) (&aimg[0][0])[e] = (_Float16)0.0f;
+    __syncthreads();
+    for (int e = t; e < 128 * 2 * Q; e += 256) {          // (m, term)
+        const int m = e / (2 * Q), tt = e - m * 2 * Q, q = tt >> 1;
+        float v = 0.0f;
+        if (mc + m < M) {
+            const float zz = (float)z[(size_t)(mc + m) * Q + q] - zc[q];
+            v = (tt & 1) ? zz : zz * zz;
+        }
+        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+        _Float16 *dst = bimg + m * SL + 3 * tt;
+        dst[0] = h; dst[1] = l; dst[2] = h;
+    }
+    for (int m = t; m < 128; m += 256) {
+        bimg[m * SL + 6 * Q] = (_Float16)1.0f;
+        bimg[m * SL + 6 * Q + 1] = (_Float16)1.0f;
+    }
+    __syncthreads();
+    // m-side operands of this lane: 8 column tiles x KF1 K-steps, resident in registers
+    p1_h8 bop[8][KF1];
+#pragma unroll
+    for (int J = 0; J < 8; ++J)
+#pragma unroll
+        for (int ks = 0; ks < KF1; ++ks)
+            bop[J][ks] = *reinterpret_cast<const p1_h8 *>(bimg + (16 * J + li) * SL + 32 * ks + 8 * kk);
+    float acc[8];
+#pragma unroll
+    for (int J = 0; J < 8; ++J) acc[J] = 0.0f;
+    _Float16 *am = &aimg[wv][0];
+    const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    for (int n0 = nbeg + 16 * wv; n0 < nend; n0 += 64) {
+        // ---- n-side image of rows n0 .. n0+15 ----
+        for (int e = lane; e < 16 * Q; e += 64) {
+            const int r = e / Q, q = e - r * Q, n = n0 + r;
+            float a = 0.0f, bb = 0.0f;
+            if (n < nend) {
+                const float g = gq[q];
+                const float w1 = g / (g * (float)s[(size_t)n * Q + q] + 1.0f);
+                a = (float)(-0.5 * DPGP_LOG2E) * w1;
+                bb = (float)DPGP_LOG2E * w1 * ((float)mu[(size_t)n * Q + q] - zc[q]);
+            }
+            const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
+            const _Float16 bh = (_Float16)bb, bl = (_Float16)(bb - (float)bh);
+            _Float16 *dst = am + r * SL + 6 * q;
+            dst[0] = ah; dst[1] = ah; dst[2] = al; dst[3] = bh; dst[4] = bh; dst[5] = bl;
+        }
+        if (lane < 16) {
+            const int n = n0 + lane;
+            float c = 0.0f, yn = 0.0f;
+            if (n < nend) {
+                for (int q = 0; q < Q; ++q) {
+                    const float g = gq[q], den = g * (float)s[(size_t)n * Q + q] + 1.0f;
+                    const float mcq = (float)mu[(size_t)n * Q + q] - zc[q];
+                    c += (g / den) * mcq * mcq + dpgp_log(den);
+                }
+                c = fmaxf((float)(-0.5 * DPGP_LOG2E) * c, -60000.0f);
+                yn = (float)y[(size_t)n * ldy + b];
+            }
+            const _Float16 ch = (_Float16)c;
+            am[lane * SL + 6 * Q] = ch;
+            am[lane * SL + 6 * Q + 1] = (_Float16)(c - (float)ch);
+            yv[wv][lane] = yn;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        p1_h8 aop[KF1];
+#pragma unroll
+        for (int ks = 0; ks < KF1; ++ks) aop[ks] = *reinterpret_cast<const p1_h8 *>(am + li * SL + 32 * ks + 8 * kk);
+        float y4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y4[v] = yv[wv][4 * kk + v];
+#pragma unroll
+        for (int J = 0; J < 8; ++J) {
+            p1_f4 c = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KF1; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop[ks], bop[J][ks], c, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[J] = fmaf(y4[v], dpgp_exp2(c[v]), acc[J]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next tile overwrites the image just read
+    }
+    // ---- sum the 4 row groups of each wave and the 4 waves ----
+#pragma unroll
+    for (int J = 0; J < 8; ++J) red[wv * 4 + kk][16 * J + li] = acc[J];
+    __syncthreads();
+    if (t < 128 && mc + t < M) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += (double)red[k][t];
+        part[((size_t)sp * B + b) * M + mc + t] = (double)alpha[b] * v;
+    }
+}
+
+template <typename TIN, int KF1>
+static int launch_psi1T_y_f16_kf(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s,
+                                 const TIN *gamma, const TIN *alpha, const TIN *y, int ldy, double *part, int ns,
+                                 hipStream_t st) {
+    int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);
+    dim3 grid(ns, dpgp_ceil_div(M, 128), B);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1T_y_f16_kernel<TIN, KF1>), grid, dim3(256), 0, st, N, M, Q, B, z, mu, s, gamma, alpha, y, ldy,
+                       part, nper);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
 int psi1T_y_nsplit(int B, int N, int M) {
     int wgs = B * dpgp_ceil_div(M, 128);
     int ns = dpgp_ceil_div(1024, wgs);          // aim for >= ~4 workgroups per CU
@@ -278,6 +418,15 @@ int psi1T_y_nsplit(int B, int N, int M) {
 template <typename TIN, typename T>
 int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                            const TIN *alpha, const TIN *y, int ldy, double *part, int ns, hipStream_t st) {
+    if (sizeof(T) == 4) {        // fp32 results: f16-split operands on the matrix pipe
+        switch (dpgp_ceil_div(6 * Q + 2, 32)) {
+#define CASE(k) \
+    case k: return launch_psi1T_y_f16_kf<TIN, k>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, part, ns, st);
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
+#undef CASE
+        }
+        return -4;
+    }
     int nper = dpgp_round_up(dpgp_ceil_div(N, ns), P1Y_NT);
     dim3 grid(ns, dpgp_ceil_div(M, 128), B);
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1T_y_kernel<TIN, T>), grid, dim3(256), 0, st, N, M, Q, B, z, mu, s, gamma, alpha, y, ldy,

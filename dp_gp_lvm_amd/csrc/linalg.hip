@@ -492,10 +492,18 @@ __global__ __launch_bounds__(256) void chain_b_kernel(int D, int N, int M, int M
             tl4 k0 = *reinterpret_cast<const tl4 *>(K0 + off);
             tl4 ki = *reinterpret_cast<const tl4 *>(KI + off);
             double p2[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int k = 0; k < ns2; ++k) {
-                const tp4 v = *reinterpret_cast<const tp4 *>(psi2_part + ((size_t)k * D + d) * (size_t)Mp * Mp + off);
+            for (int kb = 0; kb < ns2; kb += 8) {      // up to 8 slab loads in flight (psi2_nsplit() never exceeds 8)
+                tp4 v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) p2[e] += (double)v[e];
+                for (int k = 0; k < 8; ++k)
+                    if (kb + k < ns2)
+                        v[k] = *reinterpret_cast<const tp4 *>(psi2_part + ((size_t)(kb + k) * D + d) * (size_t)Mp * Mp + off);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (kb + k < ns2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p2[e] += (double)v[k][e];
+                    }
             }
             if (t0 + u < nlow) {
                 TL *dst = (mode == 0) ? tiles + lds_tile_index(I, J, nb) * TSZ + r * LDT + c4 : Wb + off;
