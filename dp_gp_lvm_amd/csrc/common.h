@@ -77,3 +77,23 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T *scratch) {
     for (int i = 0; i < nw; ++i) t += scratch[i];
     return t;
 }
+
+// Column means of z[M,Q] (Q <= 30) by the whole 256-thread workgroup: thread = (column t & 31, row group t >> 5), partial
+// sums in fp64, 8-way reduction through LDS (scratch: 8 * 32 doubles).  Result in zc[0..Q) (type T), valid after the
+// trailing barrier.  Replaces a per-column serial loop over M dependent loads in every workgroup's prologue.
+template <typename TIN, typename T>
+__device__ __forceinline__ void block_column_means(const TIN *__restrict__ z, int M, int Q, T *zc, double *scratch) {
+    const int t = threadIdx.x, q = t & 31, rg = t >> 5;
+    double a = 0.0;
+    if (q < Q)
+        for (int m = rg; m < M; m += 8) a += (double)z[(size_t)m * Q + q];
+    scratch[rg * 32 + q] = a;
+    __syncthreads();
+    if (t < Q) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += scratch[k * 32 + t];
+        zc[t] = (T)(v / (double)M);
+    }
+    __syncthreads();
+}

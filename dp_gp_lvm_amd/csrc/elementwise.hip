@@ -291,15 +291,11 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
     __shared__ __align__(16) _Float16 aimg[4][16 * SL];   // n-side image, one per wave
     __shared__ float yv[4][16];
     __shared__ float zc[DPGP_MAX_Q + 2], gq[DPGP_MAX_Q + 2];
-    __shared__ float red[16][128];
+    __shared__ __align__(16) float red[16][128];
     const int b = blockIdx.z, mc = blockIdx.y * 128, sp = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
-    if (t < Q) {
-        gq[t] = (float)gamma[(size_t)b * Q + t];
-        double a = 0.0;
-        for (int m = 0; m < M; ++m) a += (double)z[(size_t)m * Q + t];
-        zc[t] = (float)(a / (double)M);
-    }
+    if (t < Q) gq[t] = (float)gamma[(size_t)b * Q + t];
+    block_column_means(z, M, Q, zc, reinterpret_cast<double *>(&red[0][0]));
     for (int e = t; e < 128 * SL; e += 256) bimg[e] = (_Float16)0.0f;
     for (int e = t; e < 4 * 16 * SL; e += 256) (&aimg[0][0])[e] = (_Float16)0.0f;
     __syncthreads();

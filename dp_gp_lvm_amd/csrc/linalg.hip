@@ -42,9 +42,12 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 
 
 // ---- diagonal tile: Cholesky (optional) + inverse, by the calling wave; lanes 0..15 hold one row each ------------
-// A: tile origin in global memory (row stride ld).  On exit (FACTOR): tile holds L (upper zeroed).  dinv_lds[16][LDT]
+// A: tile origin (global memory or LDS, row stride ld).  On exit (FACTOR): tile holds L (upper zeroed).  dinv_lds[16][LDT]
 // and, if non-null, dinv_glob[16][16] receive L^-1.  *fail (LDS) gets base+j+1 for the first non-positive pivot.
-template <typename T, bool FACTOR>
+// INV_FROM_LDS (tile lives in LDS): the inverse reads L back from the tile with wave-uniform addresses (LDS broadcast
+// reads) instead of 120 more cross-lane broadcasts — the v_readlane form keeps ~240 SGPRs live and the compiler spills
+// them through v_writelane (measured 4.6 us per fp64 tile, ~2200 instructions).
+template <typename T, bool FACTOR, bool INV_FROM_LDS>
 __device__ __forceinline__ void diag_tile(T *A, int ld, T *dinv_lds, T *dinv_glob, int *fail, int base) {
     const int lane = threadIdx.x & 63, li = lane & 15;
     T a[16], rinv[16];
@@ -77,12 +80,25 @@ __device__ __forceinline__ void diag_tile(T *A, int ld, T *dinv_lds, T *dinv_glo
     }
     // inverse: lane c owns column c of X = L^-1;  x_i = (delta_ic - sum_{k<i} L_ik x_k) / L_ii
     T x[16];
+    if (INV_FROM_LDS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // the tile (L) written above has landed in LDS
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        T acc = (li == i) ? (T)1 : (T)0;
+        for (int i = 0; i < 16; ++i) {
+            T acc = (li == i) ? (T)1 : (T)0;
 #pragma unroll
-        for (int k = 0; k < i; ++k) acc -= lane_bcast(a[k], i) * x[k];
-        x[i] = acc * rinv[i];
+            for (int k = 0; k < i; ++k) acc = fma(-A[(size_t)i * ld + k], x[k], acc);   // wave-uniform address: broadcast
+            x[i] = acc * rinv[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            T acc = (li == i) ? (T)1 : (T)0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) acc -= lane_bcast(a[k], i) * x[k];
+            x[i] = acc * rinv[i];
+        }
     }
     if (lane < 16) {
 #pragma unroll
@@ -102,7 +118,7 @@ __device__ void potrf_blocked(T *A, int ld, int nbf, int nbr, T *lds, T *dinv_gl
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
     for (int k = 0; k < nbf; ++k) {
         if (wv == 0)
-            diag_tile<T, true>(A + (size_t)(16 * k) * ld + 16 * k, ld, dinv, dinv_glob ? dinv_glob + k * 256 : nullptr,
+            diag_tile<T, true, false>(A + (size_t)(16 * k) * ld + 16 * k, ld, dinv, dinv_glob ? dinv_glob + k * 256 : nullptr,
                                fail, fail_base + 16 * k);
         __syncthreads();
         // panel: P_I = A_Ik * Linv^T
@@ -307,7 +323,7 @@ template <typename T>
 __device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail) {
     typedef typename Mfma<T>::acc_t acc_t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
-    if (wv == 0) diag_tile<T, true>(tiles, LDT, dinv, (T *)nullptr, fail, 0);
+    if (wv == 0) diag_tile<T, true, true>(tiles, LDT, dinv, (T *)nullptr, fail, 0);
     __syncthreads();
     for (int k = 0; k < nbf; ++k) {
         // panel: P_I = A_Ik * Linv_kk^T, in place
@@ -339,7 +355,7 @@ __device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 ACC_BEGIN();
-                diag_tile<T, true>(tile, LDT, dinv, (T *)nullptr, fail, 16 * (k + 1));
+                diag_tile<T, true, true>(tile, LDT, dinv, (T *)nullptr, fail, 16 * (k + 1));
                 ACC_END(4);
             }
         } else {
@@ -724,7 +740,7 @@ __global__ __launch_bounds__(256) void trsm_batched_kernel(int M, int K, int Mp,
     } else {
         const int wv = t >> 6;
         for (int k = wv; k < nb; k += 4)
-            diag_tile<T, false>(Lw + (size_t)(16 * k) * Mp + 16 * k, Mp, lds + (size_t)wv * 16 * LDT, dinv + k * 256,
+            diag_tile<T, false, false>(Lw + (size_t)(16 * k) * Mp + 16 * k, Mp, lds + (size_t)wv * 16 * LDT, dinv + k * 256,
                                 (int *)nullptr, 0);
         __syncthreads();
         trsm_left_blocked<T>(Lw, Mp, dinv, Rw, Kp, nb, Kp / 16, lds);

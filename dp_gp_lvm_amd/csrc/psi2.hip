@@ -84,13 +84,8 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
     T *pm = cn + NR * KP;                            // [NR][PLD] P[n, m-block | m'-block]
 
     // ---- prologue (workgroup-wide): gamma_b, z column means, centred z rows of both blocks -----------------------
-    if (t < Q) {
-        gq[t] = (T)gamma[(size_t)b * Q + t];
-        double a = 0.0;
-        for (int m = 0; m < M; ++m) a += (double)z[(size_t)m * Q + t];
-        zc[t] = (T)(a / (double)M);
-    }
-    __syncthreads();
+    if (t < Q) gq[t] = (T)gamma[(size_t)b * Q + t];
+    block_column_means(z, M, Q, zc, reinterpret_cast<double *>(zs + G::OFF_W));   // scratch: the (not yet used) wave regions
     for (int e = t; e < 2 * PS * ZLD; e += 256) {
         int r = e / ZLD, k = e - r * ZLD;
         int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
@@ -347,13 +342,8 @@ __device__ __forceinline__ void psi2_patch_f16(int N, int M, int Q, int B, const
     unsigned *pw = reinterpret_cast<unsigned *>(cn + NR * XLD);   // [NR][PLD] packed (Ph, Pl) + [2] constants
     constexpr int CONST_ONE = NR * PLD, CONST_ZERO = NR * PLD + 1;
 
-    if (t < Q) {
-        gq[t] = (float)gamma[(size_t)b * Q + t];
-        double a = 0.0;
-        for (int m = 0; m < M; ++m) a += (double)z[(size_t)m * Q + t];
-        zc[t] = (float)(a / (double)M);
-    }
-    __syncthreads();
+    if (t < Q) gq[t] = (float)gamma[(size_t)b * Q + t];
+    block_column_means(z, M, Q, zc, reinterpret_cast<double *>(zs + G::OFF_W));   // scratch: the (not yet used) wave regions
     for (int e = t; e < 2 * PS * ZLD; e += 256) {
         int r = e / ZLD, k = e - r * ZLD;
         int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);

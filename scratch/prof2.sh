@@ -13,7 +13,7 @@ import csv, glob, collections
 for f in sorted(glob.glob('$O/pmc*/*/*counter_collection.csv')):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'psi2_mfma' in r['Kernel_Name']:
+        if 'psi2_f16' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for c, v in agg.items():
         print('%-28s %.4g' % (c, sum(v)/len(v)))
