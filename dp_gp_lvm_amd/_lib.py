@@ -55,9 +55,9 @@ for _t in ('f32', 'f64'):
 
 
 class ExecResources(ctypes.Structure):
-    """dpgp_exec_t of include/dpgp.h: optional second stream + fork/join events, optional psi2 timing events."""
-    _fields_ = [('aux_stream', _vp), ('ev_fork', _vp), ('ev_join', _vp), ('ev_psi2_begin', _vp), ('ev_psi2_end', _vp),
-                ('model_scal', _vp), ('model_pack', _vp), ('model_out', _vp)]
+    """dpgp_exec_t of include/dpgp.h: optional psi2 timing events and model-level tail pointers."""
+    _fields_ = [('ev_psi2_begin', _vp), ('ev_psi2_end', _vp), ('model_scal', _vp), ('model_pack', _vp),
+                ('model_out', _vp)]
 
 
 _lib = None

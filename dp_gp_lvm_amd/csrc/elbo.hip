@@ -1,12 +1,12 @@
 // Fused per-output ELBO reduction (the hot path of dp_gp_lvm.py:108-148): no host synchronisation, no allocation —
 // graph-capturable.  Launch order on the main stream:
-//   1. Psi2_d partial slabs on the matrix cores              (psi2_f16_kernel / psi2_mfma_kernel)
-//   2. B = K + beta Psi2, bordered Cholesky, f_hat terms     (chain_b_kernel)
-//   3. f_hat = sum of terms, KL = sum of partials             (sum_terms_kernel)
-// preceded by  a. K_uu + jitter I (gram_kernel)  c. KL(q(X)||p(X)) and y_d^T y_d partials (kl_yy_kernel)
-//              d. Psi1_d^T y_d partial slabs (psi1T_y_kernel)
-// and, forked onto exec->aux_stream after (a) when the caller provides one (else in line after (a)):
-//              b. chol(K_uu), log-det, K_uu^-1 (chain_k_kernel) — D latency-bound workgroups that overlap c, d and psi2
+//   1. K_uu + jitter I                                        (gram_kernel)
+//   2. KL(q(X)||p(X)) and y_d^T y_d partials                  (kl_yy_kernel)
+//   3. Psi1_d^T y_d partial slabs                             (psi1T_y_f16_kernel)
+//   4. Psi2_d partial slabs on the matrix cores, with the K_uu branch (chol(K_uu), log-det, K_uu^-1: D latency-bound
+//      workgroups) as an extra task slice of the SAME dispatch  (psi2_f16_kernel + chain_k_body)
+//   5. B = K + beta Psi2, bordered Cholesky, f_hat terms      (chain_b_kernel)
+//   6. f_hat = sum of terms, KL = sum of partials [+ model-level tail]  (sum_terms_kernel)
 #include "internal.h"
 
 struct ElboLayout {
@@ -50,31 +50,22 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     TL *la = reinterpret_cast<TL *>(ws + L.off_la);
     double *klp = reinterpret_cast<double *>(ws + L.off_kl);
     hipEvent_t ev0 = ex ? (hipEvent_t)ex->ev_psi2_begin : nullptr, ev1 = ex ? (hipEvent_t)ex->ev_psi2_end : nullptr;
-    const bool fork = ex && ex->aux_stream && ex->ev_fork && ex->ev_join;
-    hipStream_t sk = fork ? (hipStream_t)ex->aux_stream : st;
     int rc;
-    // K_uu first, on the main stream: it is short, and the side branch must be in flight before the ~1500 psi2 workgroups
-    // claim every CU slot (kernels submitted later to another queue only get slots as psi2 workgroups retire)
     if ((rc = launch_gram<double, TL>(D, M, M, Q, z, nullptr, gamma, alpha, beta, DPGP_FLAG_JITTER, jitter, la, L.Mp,
                                       la_chain_ws_elems(M), st)))
         return rc;
-    if (fork) {
-        if (hipEventRecord((hipEvent_t)ex->ev_fork, st) != hipSuccess) return DPGP_ERR_LAUNCH;
-        if (hipStreamWaitEvent(sk, (hipEvent_t)ex->ev_fork, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
-    }
-    // side branch (latency-bound, D workgroups): Cholesky, log-det and inverse of K_uu.  It starts together with the
-    // short KL / y'y / Psi1^T y kernels, i.e. while CU slots are still free, and keeps its slots while psi2 runs.
-    if ((rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, sk))) return rc;
-    if (fork && hipEventRecord((hipEvent_t)ex->ev_join, sk) != hipSuccess) return DPGP_ERR_LAUNCH;
-    // main branch
     if ((rc = launch_kl_yy<double>(N, Q, mu, s, klp, D, y, ldy, yy, st))) return rc;
     if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, st)))
         return rc;
+    const bool fused_k = (algo != DPGP_ALGO_PLAIN);
+    if (!fused_k && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, st))) return rc;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
-    if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st))) return rc;
+    // psi2 on the matrix cores; the same dispatch carries, ahead of the psi2 workgroups, the D workgroups of the K_uu
+    // branch (Cholesky, log-det, inverse of K_uu), which are latency-bound and overlap the psi2 work completely
+    if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st,
+                                              fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik)))
+        return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
-    // join
-    if (fork && hipStreamWaitEvent(st, (hipEvent_t)ex->ev_join, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
     if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info, la, algo,
                                      st)))
         return rc;

@@ -26,9 +26,13 @@ int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int 
 // partial Psi2 slabs: part[ns][B][Mp][Mp] (type T), Mp = round_up(M,16); only the lower block-triangle (16x16 tiles,
 // J <= I) is written; entries with row/col >= M are zero.  ns = psi2_nsplit(B, N, M).
 int psi2_nsplit(int B, int N, int M);
+// chain_ws != nullptr (matrix-core algos only): the launch carries an extra slice of B workgroups in front of the psi2
+// workgroups that run the K_uu branch (chain_k_body, linalg_dev.h) on the per-output workspaces chain_ws (elements of
+// chain_elem = 4 or 8 bytes) -> logdet_k[B], info_k[B].
 template <typename TIN, typename T>
 int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                        const TIN *alpha, T *part, int ns, int algo, hipStream_t st);
+                        const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,
+                        double *logdet_k, int *info_k);
 
 // ---- linalg.hip ------------------------------------------------------------------------------------------------
 // per-d workspace of the fused Cholesky chain, in elements of TL (layout: linalg.hip)

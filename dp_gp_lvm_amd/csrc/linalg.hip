@@ -20,283 +20,6 @@
 //  stream WHILE the psi2 kernel runs, and the part after Psi2 (chain_b_kernel) is one fused assemble + one bordered
 //  Cholesky.  Matrices are padded to a multiple of 16 with an identity block so no tile needs bounds checks.
 #include "internal.h"
-
-#define LDT 17          // LDS tile row stride (16 + 1 pad)
-#define TSZ (16 * LDT)  // elements per LDS tile
-#define LA_LDS_HDR 128  // bytes at the start of the dynamic LDS region: 8 doubles of reduction scratch + fail flag
-#define LA_LDS_LIMIT (150 * 1024)
-
-__device__ __forceinline__ float dpgp_rsqrt(float x) { return rsqrtf(x); }
-__device__ __forceinline__ double dpgp_rsqrt(double x) { return rsqrt(x); }
-
-// broadcast of lane `src` (a compile-time constant after unrolling) through an SGPR: v_readlane_b32, no LDS crossbar
-__device__ __forceinline__ float lane_bcast(float v, int src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-}
-__device__ __forceinline__ double lane_bcast(double v, int src) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-
-// ---- diagonal tile: Cholesky (optional) + inverse, by the calling wave; lanes 0..15 hold one row each ------------
-// A: tile origin (global memory or LDS, row stride ld).  On exit (FACTOR): tile holds L (upper zeroed).  dinv_lds[16][LDT]
-// and, if non-null, dinv_glob[16][16] receive L^-1.  *fail (LDS) gets base+j+1 for the first non-positive pivot.
-// INV_FROM_LDS (tile lives in LDS): the inverse reads L back from the tile with wave-uniform addresses (LDS broadcast
-// reads) instead of 120 more cross-lane broadcasts — the v_readlane form keeps ~240 SGPRs live and the compiler spills
-// them through v_writelane (measured 4.6 us per fp64 tile, ~2200 instructions).
-template <typename T, bool FACTOR, bool INV_FROM_LDS>
-__device__ __forceinline__ void diag_tile(T *A, int ld, T *dinv_lds, T *dinv_glob, int *fail, int base) {
-    const int lane = threadIdx.x & 63, li = lane & 15;
-    T a[16], rinv[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = (c <= li) ? A[(size_t)li * ld + c] : (T)0;
-    if (FACTOR) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            T d = lane_bcast(a[j], j);
-            if (!(d > (T)0)) {
-                if (lane == 0 && *fail == 0) *fail = base + j + 1;
-                d = (T)1;
-            }
-            rinv[j] = dpgp_rsqrt(d);                 // one rsq + refinement instead of sqrt followed by a division
-            const T piv = d * rinv[j];
-            a[j] = (li == j) ? piv : a[j] * rinv[j];  // (rows li < j: don't-care)
-#pragma unroll
-            for (int c = j + 1; c < 16; ++c) {
-                const T lcj = lane_bcast(a[j], c);
-                a[c] = fma(-a[j], lcj, a[c]);    // entries above the diagonal (li < c) hold don't-care values, zeroed on store
-            }
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) A[(size_t)li * ld + c] = (c <= li) ? a[c] : (T)0;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) rinv[j] = (T)1 / lane_bcast(a[j], j);
-    }
-    // inverse: lane c owns column c of X = L^-1;  x_i = (delta_ic - sum_{k<i} L_ik x_k) / L_ii
-    T x[16];
-    if (INV_FROM_LDS) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xc07f);      // the tile (L) written above has landed in LDS
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            T acc = (li == i) ? (T)1 : (T)0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) acc = fma(-A[(size_t)i * ld + k], x[k], acc);   // wave-uniform address: broadcast
-            x[i] = acc * rinv[i];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            T acc = (li == i) ? (T)1 : (T)0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) acc -= lane_bcast(a[k], i) * x[k];
-            x[i] = acc * rinv[i];
-        }
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dinv_lds[i * LDT + li] = x[i];
-            if (dinv_glob) dinv_glob[i * 16 + li] = x[i];
-        }
-    }
-}
-
-// ---- blocked Cholesky of the leading nbf x nbf tiles of A, carrying nbr - nbf border tile-rows --------------------
-// lds: dinv[16*LDT] + panel[(nbr)*16*LDT];  dinv_glob: [nbf][256] or null.
-template <typename T>
-__device__ void potrf_blocked(T *A, int ld, int nbf, int nbr, T *lds, T *dinv_glob, int *fail, int fail_base) {
-    typedef typename Mfma<T>::acc_t acc_t;
-    T *dinv = lds, *panel = lds + 16 * LDT;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
-    for (int k = 0; k < nbf; ++k) {
-        if (wv == 0)
-            diag_tile<T, true, false>(A + (size_t)(16 * k) * ld + 16 * k, ld, dinv, dinv_glob ? dinv_glob + k * 256 : nullptr,
-                               fail, fail_base + 16 * k);
-        __syncthreads();
-        // panel: P_I = A_Ik * Linv^T
-        for (int I = k + 1 + wv; I < nbr; I += 4) {
-            T *tile = A + (size_t)(16 * I) * ld + 16 * k;
-            acc_t c = {0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const T av = tile[(size_t)li * ld + 4 * ks + kk];
-                const T bv = dinv[li * LDT + 4 * ks + kk];
-                c = Mfma<T>::mma(av, bv, c);
-            }
-            T *pl = panel + (I - k - 1) * 16 * LDT;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = Mfma<T>::row(lane, v);
-                tile[(size_t)r * ld + li] = c[v];
-                pl[r * LDT + li] = c[v];
-            }
-        }
-        __syncthreads();
-        // trailing update: A_IJ -= P_I P_J^T for k < J < nbf, J <= I < nbr
-        int cnt = 0;
-        for (int I = k + 1; I < nbr; ++I) {
-            const int jmax = min(I, nbf - 1);
-            for (int J = k + 1; J <= jmax; ++J, ++cnt) {
-                if ((cnt & 3) != wv) continue;
-                T *tile = A + (size_t)(16 * I) * ld + 16 * J;
-                const T *pI = panel + (I - k - 1) * 16 * LDT, *pJ = panel + (J - k - 1) * 16 * LDT;
-                acc_t c;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) c[v] = tile[(size_t)Mfma<T>::row(lane, v) * ld + li];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    c = Mfma<T>::mma(-pI[li * LDT + 4 * ks + kk], pJ[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) tile[(size_t)Mfma<T>::row(lane, v) * ld + li] = c[v];
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---- X = L^-1 B (in place in Bm), L lower nb x nb tiles with inverted diagonal tiles dinv_glob, B nb x nbc tiles -----
-// lds: dinv[16*LDT] + xrow[nbc*16*LDT]
-template <typename T>
-__device__ void trsm_left_blocked(const T *L, int ldl, const T *dinv_glob, T *Bm, int ldb, int nb, int nbc, T *lds) {
-    typedef typename Mfma<T>::acc_t acc_t;
-    T *dinv = lds, *xrow = lds + 16 * LDT;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
-    for (int k = 0; k < nb; ++k) {
-        dinv[(t >> 4) * LDT + (t & 15)] = dinv_glob[k * 256 + t];
-        __syncthreads();
-        for (int J = wv; J < nbc; J += 4) {
-            T *tile = Bm + (size_t)(16 * k) * ldb + 16 * J;
-            acc_t c = {0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                c = Mfma<T>::mma(dinv[li * LDT + 4 * ks + kk], tile[(size_t)(4 * ks + kk) * ldb + li], c);
-            T *xl = xrow + J * 16 * LDT;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = Mfma<T>::row(lane, v);
-                tile[(size_t)r * ldb + li] = c[v];
-                xl[r * LDT + li] = c[v];
-            }
-        }
-        __syncthreads();
-        int cnt = 0;
-        for (int I = k + 1; I < nb; ++I) {
-            const T *lt = L + (size_t)(16 * I) * ldl + 16 * k;
-            for (int J = 0; J < nbc; ++J, ++cnt) {
-                if ((cnt & 3) != wv) continue;
-                T *tile = Bm + (size_t)(16 * I) * ldb + 16 * J;
-                const T *xl = xrow + J * 16 * LDT;
-                acc_t c;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) c[v] = tile[(size_t)Mfma<T>::row(lane, v) * ldb + li];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    c = Mfma<T>::mma(-lt[(size_t)li * ldl + 4 * ks + kk], xl[(4 * ks + kk) * LDT + li], c);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) tile[(size_t)Mfma<T>::row(lane, v) * ldb + li] = c[v];
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---- T = X L^-T on the lower block-triangle (I >= J), in place in X ------------------------------------------------
-// lds: dinv[16*LDT] + tpan[nb*16*LDT]
-template <typename T>
-__device__ void trsm_right_lower_blocked(const T *L, int ldl, const T *dinv_glob, T *X, int ldx, int nb, T *lds) {
-    typedef typename Mfma<T>::acc_t acc_t;
-    T *dinv = lds, *tpan = lds + 16 * LDT;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
-    for (int J = 0; J < nb; ++J) {
-        dinv[(t >> 4) * LDT + (t & 15)] = dinv_glob[J * 256 + t];
-        __syncthreads();
-        for (int I = J + wv; I < nb; I += 4) {
-            T *tile = X + (size_t)(16 * I) * ldx + 16 * J;
-            acc_t c = {0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                c = Mfma<T>::mma(tile[(size_t)li * ldx + 4 * ks + kk], dinv[li * LDT + 4 * ks + kk], c);
-            T *pl = tpan + (I - J) * 16 * LDT;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = Mfma<T>::row(lane, v);
-                tile[(size_t)r * ldx + li] = c[v];
-                pl[r * LDT + li] = c[v];
-            }
-        }
-        __syncthreads();
-        int cnt = 0;
-        for (int Jp = J + 1; Jp < nb; ++Jp) {
-            const T *lt = L + (size_t)(16 * Jp) * ldl + 16 * J;
-            for (int I = Jp; I < nb; ++I, ++cnt) {
-                if ((cnt & 3) != wv) continue;
-                T *tile = X + (size_t)(16 * I) * ldx + 16 * Jp;
-                const T *pl = tpan + (I - J) * 16 * LDT;
-                acc_t c;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) c[v] = tile[(size_t)Mfma<T>::row(lane, v) * ldx + li];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    c = Mfma<T>::mma(-pl[li * LDT + 4 * ks + kk], lt[(size_t)li * ldl + 4 * ks + kk], c);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) tile[(size_t)Mfma<T>::row(lane, v) * ldx + li] = c[v];
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---- plain (VALU, unblocked) versions for cross-checking ----------------------------------------------------------
-template <typename T> __device__ void potrf_plain(T *A, int ld, int n, int nrows, int *fail, int fail_base) {
-    const int t = threadIdx.x;
-    for (int j = 0; j < n; ++j) {
-        __syncthreads();
-        T d = A[(size_t)j * ld + j];
-        if (!(d > (T)0)) {
-            if (t == 0 && *fail == 0) *fail = fail_base + j + 1;
-            d = (T)1;
-        }
-        const T piv = sqrt(d);
-        __syncthreads();
-        for (int i = j + t; i < nrows; i += 256) A[(size_t)i * ld + j] = (i == j) ? piv : A[(size_t)i * ld + j] / piv;
-        __syncthreads();
-        const int rem = nrows - j - 1, remc = n - j - 1;
-        for (int e = t; e < rem * remc; e += 256) {
-            const int i = j + 1 + e / remc, c = j + 1 + e % remc;
-            if (c <= i || i >= n) A[(size_t)i * ld + c] -= A[(size_t)i * ld + j] * A[(size_t)c * ld + j];
-        }
-    }
-    __syncthreads();
-}
-// X = L^-1 B, column per thread
-template <typename T> __device__ void trsm_left_plain(const T *L, int ldl, T *Bm, int ldb, int n, int ncols) {
-    for (int c = threadIdx.x; c < ncols; c += 256)
-        for (int i = 0; i < n; ++i) {
-            T v = Bm[(size_t)i * ldb + c];
-            for (int k = 0; k < i; ++k) v -= L[(size_t)i * ldl + k] * Bm[(size_t)k * ldb + c];
-            Bm[(size_t)i * ldb + c] = v / L[(size_t)i * ldl + i];
-        }
-    __syncthreads();
-}
-// T = X L^-T, row per thread (all columns)
-template <typename T> __device__ void trsm_right_plain(const T *L, int ldl, T *X, int ldx, int n, int nrows) {
-    for (int r = threadIdx.x; r < nrows; r += 256)
-        for (int j = 0; j < n; ++j) {
-            T v = X[(size_t)r * ldx + j];
-            for (int k = 0; k < j; ++k) v -= X[(size_t)r * ldx + k] * L[(size_t)j * ldl + k];
-            X[(size_t)r * ldx + j] = v / L[(size_t)j * ldl + j];
-        }
-    __syncthreads();
-}
-
 #ifdef DPGP_PROFILE_CHAIN
 // diagnostic build only (scratch/): per-phase clock stamps of workgroup 0, read back with dpgp_debug_stamps()
 __device__ long long g_chain_stamps[16];
@@ -304,106 +27,8 @@ __device__ long long g_chain_stamps[16];
 extern "C" void dpgp_debug_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * 16); }
 #define ACC_BEGIN() long long t__ = wall_clock64()
 #define ACC_END(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == ((i) == 4 ? 0 : 1)) g_chain_stamps[i] += wall_clock64() - t__; } while (0)
-#else
-#define STAMP(i)
-#define ACC_BEGIN()
-#define ACC_END(i)
 #endif
-
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-resident blocked Cholesky: lower-triangle tiles (I,J), J <= I < nbf, then (nbr - nbf) border tile-rows of nbf tiles.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_tile_index(int I, int J, int nbf) {
-    return I < nbf ? I * (I + 1) / 2 + J : nbf * (nbf + 1) / 2 + (I - nbf) * nbf + J;
-}
-static inline int lds_tile_count(int nbf, int nbr) { return nbf * (nbf + 1) / 2 + (nbr - nbf) * nbf; }
-
-// tiles: LDS array of TSZ-element tiles; dinv: one more LDS tile.  On exit the tiles hold L (and the solved border rows).
-template <typename T>
-__device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail) {
-    typedef typename Mfma<T>::acc_t acc_t;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
-    if (wv == 0) diag_tile<T, true, true>(tiles, LDT, dinv, (T *)nullptr, fail, 0);
-    __syncthreads();
-    for (int k = 0; k < nbf; ++k) {
-        // panel: P_I = A_Ik * Linv_kk^T, in place
-        { ACC_BEGIN();
-        for (int I = k + 1 + wv; I < nbr; I += 4) {
-            T *tile = tiles + lds_tile_index(I, k, nbf) * TSZ;
-            acc_t c = {0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) c = Mfma<T>::mma(tile[li * LDT + 4 * ks + kk], dinv[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
-        }
-        ACC_END(5); }
-        __syncthreads();
-        // trailing update A_IJ -= P_I P_J^T (k < J < nbf, J <= I < nbr).  Wave 0 takes the next diagonal tile first and
-        // factors it right away; waves 1-3 share the rest of the update.
-        if (wv == 0) {
-            if (k + 1 < nbf) {
-                T *tile = tiles + lds_tile_index(k + 1, k + 1, nbf) * TSZ;
-                const T *pI = tiles + lds_tile_index(k + 1, k, nbf) * TSZ;
-                acc_t c;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) c[v] = tile[Mfma<T>::row(lane, v) * LDT + li];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) c = Mfma<T>::mma(-pI[li * LDT + 4 * ks + kk], pI[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                ACC_BEGIN();
-                diag_tile<T, true, true>(tile, LDT, dinv, (T *)nullptr, fail, 16 * (k + 1));
-                ACC_END(4);
-            }
-        } else {
-            ACC_BEGIN();
-            int cnt = 0;
-            for (int I = k + 1; I < nbr; ++I) {
-                const int jmax = min(I, nbf - 1);
-                for (int J = k + 1; J <= jmax; ++J) {
-                    if (I == k + 1 && J == k + 1) continue;
-                    if ((cnt++ % 3) != wv - 1) continue;
-                    T *tile = tiles + lds_tile_index(I, J, nbf) * TSZ;
-                    const T *pI = tiles + lds_tile_index(I, k, nbf) * TSZ, *pJ = tiles + lds_tile_index(J, k, nbf) * TSZ;
-                    acc_t c;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) c[v] = tile[Mfma<T>::row(lane, v) * LDT + li];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        c = Mfma<T>::mma(-pI[li * LDT + 4 * ks + kk], pJ[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
-                }
-            }
-            ACC_END(6);
-        }
-        __syncthreads();
-    }
-}
-
-// lower tiles of Wm^T Wm for a lower-triangular Wm (nb x nb tiles, global): out_IJ = sum_{k >= I} W_kI^T W_kJ
-template <typename T> __device__ void wtw_lower_blocked(const T *Wm, int ldw, T *out, int ldo, int nb) {
-    typedef typename Mfma<T>::acc_t acc_t;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
-    int cnt = 0;
-    for (int I = 0; I < nb; ++I)
-        for (int J = 0; J <= I; ++J, ++cnt) {
-            if ((cnt & 3) != wv) continue;
-            acc_t c = {0, 0, 0, 0};
-            for (int k = I; k < nb; ++k) {
-                const T *wr = Wm + (size_t)(16 * k) * ldw;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    c = Mfma<T>::mma(wr[(size_t)(4 * ks + kk) * ldw + 16 * I + li], wr[(size_t)(4 * ks + kk) * ldw + 16 * J + li], c);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) out[(size_t)(16 * I + Mfma<T>::row(lane, v)) * ldo + 16 * J + li] = c[v];
-        }
-    __syncthreads();
-}
+#include "linalg_dev.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // Per-output workspace (elements of TL), see la_chain_ws_elems:
@@ -413,54 +38,15 @@ template <typename T> __device__ void wtw_lower_blocked(const T *Wm, int ldw, T 
 //   KI [Mp x Mp]      : K_uu^-1, lower triangle                                            (chain_k -> chain_b)
 //   dinv [Mp/16][256] : inverted diagonal tiles of L_uu
 // ---------------------------------------------------------------------------------------------------------------
-size_t la_chain_ws_elems(int M) {
-    const int Mp = dpgp_round_up(M, 16);
-    return (size_t)3 * Mp * Mp + (size_t)(Mp + 16) * Mp + (size_t)(Mp / 16) * 256;
-}
+size_t la_chain_ws_elems(int M) { return la_chain_ws_elems_inline(M); }
 
-// ---- chain_k: everything that depends on K_uu only (dp_gp_lvm.py:115-116) -----------------------------------------
+// ---- chain_k as a kernel of its own (plain cross-check path and callers without a psi2 launch) ----------------------
 template <typename TL>
 __global__ __launch_bounds__(256) void chain_k_kernel(int M, int Mp, TL *__restrict__ ws, size_t ws_stride,
                                                       double *__restrict__ logdet_k, int *__restrict__ info_k,
                                                       int plain) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    double *scratch = reinterpret_cast<double *>(smem_raw);
-    int &fail = *reinterpret_cast<int *>(smem_raw + 64);
-    TL *lds = reinterpret_cast<TL *>(smem_raw + LA_LDS_HDR);
-    const int d = blockIdx.x, t = threadIdx.x, nb = Mp / 16;
-    TL *K0 = ws + (size_t)d * ws_stride, *Kb = K0 + (size_t)Mp * Mp, *Wb = Kb + (size_t)Mp * Mp,
-       *KI = Wb + (size_t)(Mp + 16) * Mp, *dinv = KI + (size_t)Mp * Mp;
-    if (t == 0) fail = 0;
-    for (int e = t; e < Mp * Mp; e += 256) {
-        const int i = e / Mp, j = e - i * Mp;
-        Kb[e] = (i < M && j < M) ? K0[e] : ((i == j) ? (TL)1 : (TL)0);
-        Wb[e] = (i == j) ? (TL)1 : (TL)0;
-    }
-    __syncthreads();
-    if (plain) potrf_plain<TL>(Kb, Mp, Mp, Mp, &fail, 0);
-    else potrf_blocked<TL>(Kb, Mp, nb, nb, lds, dinv, &fail, 0);
-    __syncthreads();
-    double ld = 0.0;
-    for (int i = t; i < M; i += 256) ld += log((double)Kb[(size_t)i * Mp + i]);
-    ld = block_sum(ld, scratch);
-    if (t == 0) {
-        logdet_k[d] = ld;
-        info_k[d] = fail;
-    }
-    // W = L^-1, K^-1 = W^T W (lower)
-    if (plain) {
-        trsm_left_plain<TL>(Kb, Mp, Wb, Mp, Mp, Mp);
-        for (int e = t; e < Mp * Mp; e += 256) {
-            const int i = e / Mp, j = e - i * Mp;
-            if (j > i) continue;
-            TL a = 0;
-            for (int k = i; k < Mp; ++k) a += Wb[(size_t)k * Mp + i] * Wb[(size_t)k * Mp + j];
-            KI[e] = a;
-        }
-    } else {
-        trsm_left_blocked<TL>(Kb, Mp, dinv, Wb, Mp, nb, nb, lds);
-        wtw_lower_blocked<TL>(Wb, Mp, KI, Mp, nb);
-    }
+    chain_k_body<TL>(blockIdx.x, M, Mp, ws, ws_stride, logdet_k, info_k, plain, smem_raw);
 }
 
 // ---- chain_b: everything after Psi2 (dp_gp_lvm.py:118-145 in the B = K + beta Psi2 form) -----------------------------
@@ -588,9 +174,6 @@ __global__ __launch_bounds__(256) void chain_b_kernel(int D, int N, int M, int M
     }
 }
 
-static size_t la_lds_bytes(int Mp, size_t elem) {     // global-memory blocked routines: dinv + one panel of nb+1 tiles
-    return LA_LDS_HDR + elem * (size_t)TSZ * (size_t)(Mp / 16 + 2);
-}
 static size_t chain_b_lds_bytes(int Mp, size_t elem) {   // LDS-resident B: dinv + lower triangle + border row
     const int nb = Mp / 16;
     return LA_LDS_HDR + elem * (size_t)TSZ * (size_t)(1 + lds_tile_count(nb, nb + 1));

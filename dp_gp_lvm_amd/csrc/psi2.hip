@@ -18,16 +18,36 @@
 // (identical work per wave, z operands shared), their accumulators are summed through LDS at the end.
 // Output: partial slabs part[split][b][Mp][Mp], lower block-triangle of 16x16 tiles only.
 #include "internal.h"
+#include "linalg_dev.h"
 
 #define PSI2_NT 32   // n per LDS tile
+
+// Optional extra task slice in front of the psi2 workgroups (blockIdx.z == 0): the K_uu branch of the ELBO
+// (chain_k_body of linalg_dev.h: Cholesky, log-det and inverse of K_uu for output dim blockIdx.x).  It is part of the SAME
+// dispatch, ahead of the psi2 workgroups, because a separate dispatch on another stream is only served once the ~1500 psi2
+// workgroups have all been placed (measured: it then finishes AFTER psi2 and lands on the critical path).
+struct ChainKTask {
+    void *ws;            // per-output Cholesky workspaces (float or double elements), nullptr = no task slice
+    size_t ws_stride;
+    double *logdet_k;
+    int *info_k;
+    int M, Mp, elem;     // elem = 4 (float) or 8 (double)
+};
+__device__ __attribute__((noinline)) void chain_k_task(const ChainKTask &tk, unsigned char *smem_raw) {
+    if (blockIdx.y != 0) return;
+    if (tk.elem == 8)
+        chain_k_body<double>(blockIdx.x, tk.M, tk.Mp, (double *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
+    else
+        chain_k_body<float>(blockIdx.x, tk.M, tk.Mp, (float *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
+}
 
 // Workgroup coordinates.  grid = (B, n-splits, patches); the patch index is the SLOWEST dimension and enumerates the
 // off-diagonal patches (16 tiles of work) before the diagonal ones (10 tiles), so the long workgroups are dispatched
 // first and the short ones fill the tail.
-__device__ __forceinline__ void psi2_block_coords(int nps, int &b, int &sp, int &pi, int &pj) {
+__device__ __forceinline__ void psi2_block_coords(int nps, int zoff, int &b, int &sp, int &pi, int &pj) {
     b = blockIdx.x;
     sp = blockIdx.y;
-    const int p = blockIdx.z, noff = nps * (nps - 1) / 2;
+    const int p = blockIdx.z - zoff, noff = nps * (nps - 1) / 2;
     if (p < noff) {                    // strict lower triangle: p = pi (pi - 1) / 2 + pj, pj < pi
         int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
         while (i * (i - 1) / 2 > p) --i;
@@ -547,10 +567,16 @@ template <typename TIN, int KB>
 __global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
                                                        const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                                        const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
-                                                       float *__restrict__ part, int Mp, int n_per_split) {
+                                                       float *__restrict__ part, int Mp, int n_per_split,
+                                                       ChainKTask task) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int zoff = task.ws ? 1 : 0;
+    if (zoff && blockIdx.z == 0) {
+        chain_k_task(task, smem_raw);
+        return;
+    }
     int b, sp, pi, pj;
-    psi2_block_coords((Mp + 63) / 64, b, sp, pi, pj);
+    psi2_block_coords((Mp + 63) / 64, zoff, b, sp, pi, pj);
     if (pi == pj)
         psi2_patch_f16<TIN, KB, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
     else
@@ -561,10 +587,16 @@ template <typename TIN, typename T, int KS, int PT>
 __global__ __launch_bounds__(256) void psi2_mfma_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
                                                         const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                                         const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
-                                                        T *__restrict__ part, int Mp, int n_per_split) {
+                                                        T *__restrict__ part, int Mp, int n_per_split,
+                                                        ChainKTask task) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int zoff = task.ws ? 1 : 0;
+    if (zoff && blockIdx.z == 0) {
+        chain_k_task(task, smem_raw);
+        return;
+    }
     int b, sp, pi, pj;
-    psi2_block_coords((Mp + 16 * PT - 1) / (16 * PT), b, sp, pi, pj);
+    psi2_block_coords((Mp + 16 * PT - 1) / (16 * PT), zoff, b, sp, pi, pj);
     if (pi == pj)
         psi2_patch<TIN, T, KS, PT, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
     else
@@ -665,39 +697,41 @@ int psi2_nsplit(int B, int N, int M) {
 
 template <typename TIN, typename T, int KS>
 static int launch_psi2_ks(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                          const TIN *alpha, T *part, int ns, hipStream_t st) {
+                          const TIN *alpha, T *part, int ns, const ChainKTask &task, hipStream_t st) {
     constexpr int PT = Psi2Cfg<T>::PT, PS = 16 * PT;
     const int Mp = dpgp_round_up(M, 16);
     const int nps = dpgp_ceil_div(Mp, PS);
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
-    dim3 grid(B, ns, nps * (nps + 1) / 2);
+    dim3 grid(B, ns, nps * (nps + 1) / 2 + (task.ws ? 1 : 0));
     size_t lds = psi2_lds_bytes<T, KS>();
+    if (task.ws && la_lds_bytes(task.Mp, task.elem) > lds) lds = la_lds_bytes(task.Mp, task.elem);
     auto kern = psi2_mfma_kernel<TIN, T, KS, PT>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
     }
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper, task);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
 
 template <typename TIN, int KB>
 static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                              const TIN *alpha, float *part, int ns, hipStream_t st) {
+                              const TIN *alpha, float *part, int ns, const ChainKTask &task, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16);
     const int nps = dpgp_ceil_div(Mp, 64);
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
-    dim3 grid(B, ns, nps * (nps + 1) / 2);
+    dim3 grid(B, ns, nps * (nps + 1) / 2 + (task.ws ? 1 : 0));
     size_t lds = sizeof(float) * (size_t)Psi2F16Lds<KB>::ELEMS;
+    if (task.ws && la_lds_bytes(task.Mp, task.elem) > lds) lds = la_lds_bytes(task.Mp, task.elem);
     auto kern = psi2_f16_kernel<TIN, KB>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
     }
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper, task);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -705,16 +739,16 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
 // the f16-split kernel exists for fp32 results only
 template <typename TIN, typename T> struct Psi2F16Dispatch {
     static int run(int, int, int, int, const TIN *, const TIN *, const TIN *, const TIN *, const TIN *, T *, int,
-                   hipStream_t) {
+                   const ChainKTask &, hipStream_t) {
         return -13;
     }
 };
 template <typename TIN> struct Psi2F16Dispatch<TIN, float> {
     static int run(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                   const TIN *alpha, float *part, int ns, hipStream_t st) {
+                   const TIN *alpha, float *part, int ns, const ChainKTask &task, hipStream_t st) {
         switch (dpgp_ceil_div(Q, 4)) {
 #define CASE(k) \
-    case k: return launch_psi2_f16_kb<TIN, k>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, st);
+    case k: return launch_psi2_f16_kb<TIN, k>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, st);
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         }
@@ -724,8 +758,11 @@ template <typename TIN> struct Psi2F16Dispatch<TIN, float> {
 
 template <typename TIN, typename T>
 int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                        const TIN *alpha, T *part, int ns, int algo, hipStream_t st) {
+                        const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,
+                        double *logdet_k, int *info_k) {
     const int Mp = dpgp_round_up(M, 16);
+    ChainKTask task = {chain_ws, la_chain_ws_elems_inline(M), logdet_k, info_k, M, Mp, chain_elem};
+    if (algo == DPGP_ALGO_PLAIN && chain_ws) return -16;     // the plain path launches chain_k on its own
     if (algo == DPGP_ALGO_PLAIN) {
         // slabs 1.. are expected to exist by the consumer: zero them, slab 0 carries the result
         if (ns > 1 && hipMemsetAsync(part + (size_t)B * Mp * Mp, 0, sizeof(T) * (size_t)(ns - 1) * B * Mp * Mp, st) !=
@@ -739,22 +776,25 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
     }
     // fp32 results: f16-split operands on the matrix pipe unless the exact-fp32 MFMA kernel is asked for
     if (sizeof(T) == 4 && algo != DPGP_ALGO_MFMA_F32)
-        return Psi2F16Dispatch<TIN, T>::run(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, st);
+        return Psi2F16Dispatch<TIN, T>::run(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, st);
     const int KS = dpgp_ceil_div(Q + 2, 4);
     switch (KS) {
 #define CASE(k) \
-    case k: return launch_psi2_ks<TIN, T, k>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, st);
+    case k: return launch_psi2_ks<TIN, T, k>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, st);
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     }
     return -4;
 }
 template int launch_psi2_partial<float, float>(int, int, int, int, const float *, const float *, const float *,
-                                               const float *, const float *, float *, int, int, hipStream_t);
+                                               const float *, const float *, float *, int, int, hipStream_t, void *, int,
+                                               double *, int *);
 template int launch_psi2_partial<double, double>(int, int, int, int, const double *, const double *, const double *,
-                                                 const double *, const double *, double *, int, int, hipStream_t);
+                                                 const double *, const double *, double *, int, int, hipStream_t, void *,
+                                                 int, double *, int *);
 template int launch_psi2_partial<double, float>(int, int, int, int, const double *, const double *, const double *,
-                                                const double *, const double *, float *, int, int, hipStream_t);
+                                                const double *, const double *, float *, int, int, hipStream_t, void *,
+                                                int, double *, int *);
 
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
@@ -782,7 +822,8 @@ static int psi2_api(int B, int N, int M, int Q, const T *z, const T *mu, const T
     if (ws_bytes < dpgp_psi2_workspace_bytes(B, N, M, Q, sizeof(T))) return -12;
     if (algo < 0 || algo > DPGP_ALGO_MFMA_F32) return -13;
     const int ns = psi2_nsplit(B, N, M), Mp = dpgp_round_up(M, 16);
-    int rc = launch_psi2_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, (T *)ws, ns, algo, (hipStream_t)stream);
+    int rc = launch_psi2_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, (T *)ws, ns, algo, (hipStream_t)stream,
+                                       nullptr, 0, nullptr, nullptr);
     if (rc) return rc;
     size_t tot = (size_t)B * M * M;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_finish_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

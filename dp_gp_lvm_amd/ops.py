@@ -188,11 +188,9 @@ def kl_qx(mu, s):
 
 
 class ElboWorkspace:
-    """Caller-owned scratch + outputs of the fused ELBO for one (D,N,M,Q,prec): allocate once, evaluate many times.
-    With ``overlap=True`` it also owns a side stream and two events so that the K_uu branch (gram, Cholesky, inverse)
-    overlaps the psi2 kernel (dpgp_exec_t of include/dpgp.h)."""
+    """Caller-owned scratch + outputs of the fused ELBO for one (D,N,M,Q,prec): allocate once, evaluate many times."""
 
-    def __init__(self, d, n, m, q, prec='mixed', device='cuda', overlap=True):
+    def __init__(self, d, n, m, q, prec='mixed', device='cuda'):
         self.shape, self.prec = (d, n, m, q), prec
         l = _lib.lib()
         self.nbytes = l.dpgp_elbo_workspace_bytes(d, n, m, q, _lib.PREC[prec])
@@ -201,23 +199,6 @@ class ElboWorkspace:
         self.sums = torch.empty(2, dtype=torch.float64, device=device)
         self.info = torch.empty(d, dtype=torch.int32, device=device)
         self.exec = _lib.ExecResources()
-        self._events = []
-        self.aux = None
-        if overlap:
-            with torch.cuda.device(device):
-                # high priority: the side branch is short and latency-bound; its workgroups must not queue behind the
-                # ~1500 psi2 workgroups that otherwise own every CU slot
-                self.aux = torch.cuda.Stream(device=device, priority=-1)
-                self._events = [l.dpgp_event_create(), l.dpgp_event_create()]
-            self.exec.aux_stream = self.aux.cuda_stream
-            self.exec.ev_fork, self.exec.ev_join = self._events
-
-    def __del__(self):
-        try:
-            for e in self._events:
-                _lib.lib().dpgp_event_destroy(e)
-        except Exception:
-            pass
 
 
 def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None, events=None,

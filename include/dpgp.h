@@ -121,20 +121,13 @@ int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const d
                    const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                    int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
                    void *stream);
-/* same, with optional execution resources owned by the caller (the library creates no streams or events itself):
- *   aux_stream + ev_fork + ev_join : a second hipStream_t and two hipEvent_t.  When all three are given, everything that
- *       depends on K_uu only (gram, Cholesky, log-det, inverse) is forked onto aux_stream and overlaps the psi2 kernel;
- *       it is joined back into `stream` before the final per-output Cholesky.  NULL: everything runs in order on `stream`.
- *   ev_psi2_begin / ev_psi2_end    : hipEvent_t recorded on `stream` immediately before / after the psi2 kernel so that
- *       a harness can time the dominant kernel inside its timed region; either may be NULL.
+/* same, with optional extras (exec may be NULL = dpgp_elbo_fhat):
+ *   ev_psi2_begin / ev_psi2_end : caller-created hipEvent_t recorded on `stream` immediately before / after the psi2
+ *       launch so that a harness can time the dominant kernel inside its timed region; either may be NULL.
  *   model_scal / model_pack / model_out : fold the model-level tail into the last launch.  model_scal = the scal array
  *       written by dpgp_model_prepare for the same D; then model_pack[2] (if given) receives what dpgp_model_pack would
- *       write and model_out[5] (if given; single-GPU case) what dpgp_model_finalize would write.  NULL: not done.
- * exec itself may be NULL (= dpgp_elbo_fhat).                                                                        */
+ *       write and model_out[5] (if given; single-GPU case) what dpgp_model_finalize would write.  NULL: not done.     */
 typedef struct dpgp_exec {
-    void *aux_stream;
-    void *ev_fork;
-    void *ev_join;
     void *ev_psi2_begin;
     void *ev_psi2_end;
     const double *model_scal;
