@@ -327,34 +327,53 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
     for (int J = 0; J < 8; ++J) acc[J] = 0.0f;
     _Float16 *am = &aimg[wv][0];
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    // q(X) rows and y of a 16-row tile are fetched one tile ahead (registers), so that their global-load latency overlaps
+    // the previous tile's MFMA / exp work; the per-row constant c_n is reduced from per-(row,q) pieces through LDS.
+    constexpr int NPF = (16 * DPGP_MAX_Q + 63) / 64;
+    float *cq = &red[wv * 4][0];                          // [16][Q] scratch of this wave (red is only used at the very end)
+    TIN pf_s[NPF], pf_m[NPF], pf_y = (TIN)0;
+    auto prefetch = [&](int n0) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = 64 * u + lane, r = e / Q, q = e - r * Q, n = n0 + r;
+            const bool ok = (e < 16 * Q) && (n < nend);
+            pf_s[u] = ok ? s[(size_t)n * Q + q] : (TIN)1;
+            pf_m[u] = ok ? mu[(size_t)n * Q + q] : (TIN)0;
+        }
+        pf_y = (lane < 16 && n0 + lane < nend) ? y[(size_t)(n0 + lane) * ldy + b] : (TIN)0;
+    };
+    prefetch(nbeg + 16 * wv);
     for (int n0 = nbeg + 16 * wv; n0 < nend; n0 += 64) {
         // ---- n-side image of rows n0 .. n0+15 ----
-        for (int e = lane; e < 16 * Q; e += 64) {
-            const int r = e / Q, q = e - r * Q, n = n0 + r;
-            float a = 0.0f, bb = 0.0f;
-            if (n < nend) {
-                const float g = gq[q];
-                const float w1 = g / (g * (float)s[(size_t)n * Q + q] + 1.0f);
-                a = (float)(-0.5 * DPGP_LOG2E) * w1;
-                bb = (float)DPGP_LOG2E * w1 * ((float)mu[(size_t)n * Q + q] - zc[q]);
-            }
-            const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
-            const _Float16 bh = (_Float16)bb, bl = (_Float16)(bb - (float)bh);
-            _Float16 *dst = am + r * SL + 6 * q;
-            dst[0] = ah; dst[1] = ah; dst[2] = al; dst[3] = bh; dst[4] = bh; dst[5] = bl;
-        }
-        if (lane < 16) {
-            const int n = n0 + lane;
-            float c = 0.0f, yn = 0.0f;
-            if (n < nend) {
-                for (int q = 0; q < Q; ++q) {
-                    const float g = gq[q], den = g * (float)s[(size_t)n * Q + q] + 1.0f;
-                    const float mcq = (float)mu[(size_t)n * Q + q] - zc[q];
-                    c += (g / den) * mcq * mcq + dpgp_log(den);
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int e = 64 * u + lane;
+            if (e < 16 * Q) {
+                const int r = e / Q, q = e - r * Q, n = n0 + r;
+                float a = 0.0f, bb = 0.0f, cc = 0.0f;
+                if (n < nend) {
+                    const float g = gq[q], den = g * (float)pf_s[u] + 1.0f;
+                    const float w1 = g / den, mcq = (float)pf_m[u] - zc[q];
+                    a = (float)(-0.5 * DPGP_LOG2E) * w1;
+                    bb = (float)DPGP_LOG2E * w1 * mcq;
+                    cc = w1 * mcq * mcq + dpgp_log(den);
                 }
-                c = fmaxf((float)(-0.5 * DPGP_LOG2E) * c, -60000.0f);
-                yn = (float)y[(size_t)n * ldy + b];
+                const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
+                const _Float16 bh = (_Float16)bb, bl = (_Float16)(bb - (float)bh);
+                _Float16 *dst = am + r * SL + 6 * q;
+                dst[0] = ah; dst[1] = ah; dst[2] = al; dst[3] = bh; dst[4] = bh; dst[5] = bl;
+                cq[e] = cc;
             }
+        }
+        const float yn = (float)pf_y;
+        prefetch(n0 + 64);                                  // next tile of this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 16) {
+            float c = 0.0f;
+            for (int q = 0; q < Q; ++q) c += cq[lane * Q + q];
+            c = fmaxf((float)(-0.5 * DPGP_LOG2E) * c, -60000.0f);
             const _Float16 ch = (_Float16)c;
             am[lane * SL + 6 * Q] = ch;
             am[lane * SL + 6 * Q + 1] = (_Float16)(c - (float)ch);

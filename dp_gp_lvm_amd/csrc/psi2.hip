@@ -412,19 +412,29 @@ __device__ __forceinline__ void psi2_patch_f16(int N, int M, int Q, int B, const
     constexpr int NCOL = DIAG ? PS : 2 * PS;
     constexpr int CPL = (NCOL + 63) / 64;
 
+    // q(X) rows of the first chunk; every later chunk is fetched one chunk ahead (global-load latency off the critical path)
+    constexpr int NPA = (NR * XLD + 63) / 64;
+    TIN pf_s[NPA], pf_m[NPA];
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+        const int e = 64 * u + lane, r = e / XLD, k = e - r * XLD, n = nbeg + wv + 4 * r;
+        const bool ok = (e < NR * XLD) && (k < Q) && (n < nend);
+        pf_s[u] = ok ? s[(size_t)n * Q + k] : (TIN)1;
+        pf_m[u] = ok ? mu[(size_t)n * Q + k] : (TIN)0;
+    }
     for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {
         // ---- phase A: per-(row,q) factors ----
 #pragma unroll
-        for (int e0 = 0; e0 < NR * XLD; e0 += 64) {
-            const int e = e0 + lane;
+        for (int u = 0; u < NPA; ++u) {
+            const int e = 64 * u + lane;
             if (e < NR * XLD) {
                 const int r = e / XLD, k = e - r * XLD, n = nc + 4 * r;
                 float vx = 0, vw = 0, vt = 0, vc = 0;
                 if (k < Q) {
                     if (n < nend) {
                         const float g = gq[k];
-                        const float sv = (float)s[(size_t)n * Q + k];
-                        const float mc = (float)mu[(size_t)n * Q + k] - zc[k];
+                        const float sv = (float)pf_s[u];
+                        const float mc = (float)pf_m[u] - zc[k];
                         const float den = 2.0f * g * sv + 1.0f;
                         const float w = g / den;
                         vx = (float)(-0.5 * DPGP_LOG2E) * w;
@@ -437,6 +447,13 @@ __device__ __forceinline__ void psi2_patch_f16(int N, int M, int Q, int B, const
                 }
                 xa[e] = vx; w4[e] = vw; tm[e] = vt; cn[e] = vc;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < NPA; ++u) {      // issue the next chunk's loads now; they land during phases B and C
+            const int e = 64 * u + lane, r = e / XLD, k = e - r * XLD, n = nc + 4 * NR + 4 * r;
+            const bool ok = (e < NR * XLD) && (k < Q) && (n < nend);
+            pf_s[u] = ok ? s[(size_t)n * Q + k] : (TIN)1;
+            pf_m[u] = ok ? mu[(size_t)n * Q + k] : (TIN)0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);
