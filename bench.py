@@ -137,21 +137,32 @@ def main():
         exps = d_loc * n * m * (m + 1) // 2
         flops = exps * (4 * q + 2)
         achieved = flops / (psi2_ms * 1e-3) / 1e12
+        # HBM traffic of one psi2 dispatch (incl. its K_uu task slice: 20 MB psi2 + ~0.78 GB Cholesky workspaces) from the
+        # rocprofv3 PMC passes committed under profiles/r01 (FETCH_SIZE + WRITE_SIZE,
+        # KiB -> bytes; config 3, mixed precision, 1 GPU); null for every other configuration (not profiled)
+        traffic = 8.0e8 if (a.config == 3 and a.prec == 'mixed' and world == 1) else None
+        exp_peak = 256 * 4 * 8 * 2.4e9        # v_exp_f32: 64 lanes / 8 cycles per SIMD, 1024 SIMDs, 2.4 GHz
         res = {
             'metric': 'ELBO evals/sec (N=%d,D=%d,M=%d,Q=%d)' % (n, d, m, q),
             'value': a.steps / elapsed, 'unit': 'ELBO evals/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': {'mixed': 'f32 (psi-statistics, MFMA) + f64 (Cholesky chain)', 'f32': 'f32',
-                                           'f64': 'f64'}[a.prec],
+            'vs_baseline': None, 'dtype': {'mixed': 'f32 (psi-statistics: f16 hi/lo-split MFMA operands, fp32 accumulate) + '
+                                                    'f64 (Cholesky chain)', 'f32': 'f32', 'f64': 'f64'}[a.prec],
             'data': 'synthetic (SURVEY.md 8d recipe, seed %d)' % (1000 + a.config),
             'config': {'workload': 'BASELINE config %d: dp_gp_lvm objective, N=%d D=%d M=%d Q=%d T=%d' % (a.config, n, d, m, q, t),
                        'parallelism': 'D sharded over %d GPU(s), %d output dims per GPU' % (world, d_loc),
                        'precision': a.prec},
             'objective': float(objs[0]),
+            # dominant kernel: psi2 (+ the K_uu Cholesky task slice that rides in the same dispatch).  `achieved` =
+            # ALGORITHMIC fp32 flops (N M(M+1)/2 exponents x (4Q+2) flops per output dim) / HIP-event duration;
+            # `peak` = dense fp32 matrix peak.  The kernel computes the exponent GEMM with 6(Q+2)/... f16 products on the
+            # f16 matrix pipe and is limited by v_exp_f32 + VALU issue, see `limiter` and DESIGN.md section 4.
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None, 'kernel': 'psi2_mfma_kernel',
-                         'kernel_ms': psi2_ms, 'exp_per_s': exps / (psi2_ms * 1e-3),
-                         'executed_mfma_tflops': exps * 2 * (q + 2) / (psi2_ms * 1e-3) / 1e12},
+                         'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic,
+                         'kernel': 'psi2_f16_kernel' if a.prec != 'f64' else 'psi2_mfma_kernel', 'kernel_ms': psi2_ms,
+                         'limiter': 'VALU issue (v_exp_f32 + accumulate + operand split), not the matrix pipe',
+                         'exp_per_s': exps / (psi2_ms * 1e-3), 'exp_peak_per_s': exp_peak,
+                         'exp_frac': exps / (psi2_ms * 1e-3) / exp_peak},
         }
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(a.config, p, shape, a.cpu_dims)

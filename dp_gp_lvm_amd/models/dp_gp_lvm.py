@@ -108,6 +108,7 @@ def dp_gp_lvm(y_train,
         rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
     else:
         dist, rank, world = None, 0, 1
+    sharded = process_group is not None          # (a 1-rank group still goes through pack -> all_reduce -> finalize)
     d_lo, d_hi = shard_bounds(num_dimensions, rank, world)
     d_local = d_hi - d_lo
     assert d_local > 0, 'more ranks than output dimensions'
@@ -139,8 +140,8 @@ def dp_gp_lvm(y_train,
         # single GPU: the last kernel of the fused ELBO also packs and finalises; sharded: it packs, then one all-reduce
         _, sums, _ = ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
                                    jitter=GP_DEFAULT_JITTER, prec=precision, workspace=workspace, events=events,
-                                   model_tail=(buf['scal'], red, out if world == 1 else None))
-        if world > 1:
+                                   model_tail=(buf['scal'], red, None if sharded else out))
+        if sharded:
             dist.all_reduce(red, op=dist.ReduceOp.SUM, group=process_group)    # the only exchange: 2 fp64 scalars
             _lib.check(lib.dpgp_model_finalize(red.data_ptr(), sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
                                                out.data_ptr(), st), 'dpgp_model_finalize')

@@ -115,3 +115,41 @@ def test_not_positive_definite_is_reported_not_fatal(dev):
     assert info[bad] > m and (np.delete(info, bad) == 0).all()
     assert np.isnan(terms[bad, [1, 2, 4]]).all()
     np.testing.assert_array_equal(np.delete(terms, bad, axis=0), np.delete(ref, bad, axis=0))
+
+
+def test_config4_shape_against_c_oracle(dev):
+    """BASELINE config 4 shape (N=10000, M=512, Q=20) on 2 of its 256 output dims: exercises the 8x8-patch psi2 grid,
+    three K-steps of f16 MFMA, and the global-memory (non-LDS) blocked Cholesky.  No reference-generated golden exists at
+    this size (the reference's temporary would be 107 PB), so the checker is the C oracle, itself pinned to
+    the reference at every other shape."""
+    from oracle.c_oracle import COracle
+    sel = np.array([3, 200])
+    p = make_problem(4, d_slice=sel)
+    c = COracle(fast=True)
+    ref, info_ref = c.fhat_terms(p['y'], p['z'], p['mu'], p['s'], p['gamma'], p['alpha'], p['beta'],
+                                 nthreads=min(16, c.max_threads))
+    assert not info_ref.any()
+    for prec in ('mixed', 'f64'):
+        terms, sums, info = run(p, dev, prec)
+        assert not info.any()
+        check_terms(terms, ref, prec, 'config 4 ' + prec)
+
+
+def test_sharded_model_single_rank_group(dev):
+    """The D-sharded code path of the model object (pack -> all_reduce -> finalize) with a 1-rank process group on the GPU."""
+    import os
+    import torch.distributed as dist
+    from conftest import golden as _g
+    from test_gpu_model import build
+    g = _g('dpgplvm_50_10_25_3_T8')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 1000))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        model = build(g, dev, 'f64', process_group=dist.group.WORLD)
+        np.testing.assert_allclose(float(model.objective), float(g['objective']), rtol=1e-9)
+    finally:
+        if created:
+            dist.destroy_process_group()
