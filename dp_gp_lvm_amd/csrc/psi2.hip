@@ -580,6 +580,280 @@ __device__ __forceinline__ void psi2_patch_f16(int N, int M, int Q, int B, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant with the P rows ALSO on the matrix pipe (the default).  Phase B above costs ~78 VALU instructions per row;
+// here P[n,m] = c'_n + sum_q ( a_nq z_mq^2 + b_nq z_mq ),  a = -1/4 w log2e,  b = w (mu-c) log2e,
+// c'_n = -log2e sum_q ( 1/2 w (mu-c)^2 + 1/4 log den ), is one [16 n] x [K] x [K x 16 m] product per column tile with
+// f16 hi/lo-split operands (K = 6Q + 2 slots, the slot layout of psi1T_y_f16_kernel), i.e. ~20 VALU instructions per
+// row for clamping / splitting / storing the result.  Chunks are 16 rows (one MFMA tile).
+// LDS (4-byte units): zs | zc | gq | bimg (128 columns x SL f16) | 4 x wave { xa[16][XLD] | aimg[16][SL] f16 |
+// cq[16][QS] | pw[16][PLD] + 2 constants }.
+// ---------------------------------------------------------------------------------------------------------------
+struct Psi2PLayout {
+    int SL, QS, off_bimg, off_wave, wsz, o_aimg, o_cq, o_pw, elems;
+};
+template <int KB> __host__ __device__ inline Psi2PLayout psi2p_layout(int Q) {
+    typedef Psi2F16Lds<KB> G;
+    Psi2PLayout L;
+    L.SL = 32 * ((6 * Q + 2 + 31) / 32);                       // f16 slots per image row
+    L.QS = (Q + 3) & ~3;
+    L.off_bimg = 2 * G::PS * G::ZLD + 2 * (DPGP_MAX_Q + 2);
+    L.off_wave = L.off_bimg + 128 * L.SL / 2;
+    L.o_aimg = 16 * G::XLD;
+    L.o_cq = L.o_aimg + 16 * L.SL / 2;
+    L.o_pw = L.o_cq + 16 * L.QS;
+    L.wsz = L.o_pw + 16 * G::PLD + 4;
+    const int fill = L.off_wave + 4 * L.wsz, red = L.off_wave + 4 * G::PT * 4 * 64;
+    L.elems = fill > red ? fill : red;
+    return L;
+}
+
+template <typename TIN, int KB, bool DIAG>
+__device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                                const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                                const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
+                                                float *__restrict__ part, int Mp, int n_per_split, int b, int sp,
+                                                int pi, int pj, unsigned char *smem_raw) {
+    typedef Psi2F16Lds<KB> G;
+    constexpr int PT = G::PT, PS = G::PS, KF = G::KF, XLD = G::XLD, ZLD = G::ZLD, PLD = G::PLD, NR = 16;
+    const Psi2PLayout L = psi2p_layout<KB>(Q);
+    const int SL = L.SL, QS = L.QS, kf1 = SL / 32;
+    float *zs = reinterpret_cast<float *>(smem_raw);     // [2*PS][ZLD] centred z rows: m-block then m'-block
+    float *zc = zs + 2 * PS * ZLD;
+    float *gq = zc + DPGP_MAX_Q + 2;
+    _Float16 *bimg = reinterpret_cast<_Float16 *>(zs + L.off_bimg);          // [128][SL] column-side image of P
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
+    const int m_base = pi * PS, mp_base = pj * PS;
+    float *wp = zs + L.off_wave + wv * L.wsz;
+    float *xa = wp;                                                           // [16][XLD] X[n,q]
+    _Float16 *aimg = reinterpret_cast<_Float16 *>(wp + L.o_aimg);             // [16][SL]  row-side image of P
+    float *cq = wp + L.o_cq;                                                  // [16][QS]  per-(row,q) pieces of c'_n
+    unsigned *pw = reinterpret_cast<unsigned *>(wp + L.o_pw);                 // [16][PLD] packed (Ph, Pl) + 2 constants
+    constexpr int CONST_ONE = NR * PLD, CONST_ZERO = NR * PLD + 1;
+    constexpr int NCOL = DIAG ? PS : 2 * PS;
+
+    if (t < Q) gq[t] = (float)gamma[(size_t)b * Q + t];
+    block_column_means(z, M, Q, zc, reinterpret_cast<double *>(zs + L.off_wave));
+    for (int e = t; e < 2 * PS * ZLD; e += 256) {
+        int r = e / ZLD, k = e - r * ZLD;
+        int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
+        zs[e] = (k < Q && m < M) ? (float)z[(size_t)m * Q + k] - zc[k] : 0.0f;
+    }
+    for (int e = t; e < 128 * SL / 2; e += 256) reinterpret_cast<unsigned *>(bimg)[e] = 0u;
+    for (int e = lane; e < 16 * SL / 2; e += 64) reinterpret_cast<unsigned *>(aimg)[e] = 0u;
+    if (lane == 0) { pw[CONST_ONE] = DPGP_H2_ONES; pw[CONST_ZERO] = 0u; }
+    __syncthreads();
+    for (int e = t; e < NCOL * 2 * Q; e += 256) {        // (column, term): z^2 and z, split, slots {h, l, h}
+        const int c = e / (2 * Q), tt = e - c * 2 * Q, q = tt >> 1;
+        const float zz = zs[c * ZLD + q];
+        const float v = (tt & 1) ? zz : zz * zz;
+        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+        _Float16 *dst = bimg + c * SL + 3 * tt;
+        dst[0] = h; dst[1] = l; dst[2] = h;
+    }
+    for (int c = t; c < NCOL; c += 256) {
+        bimg[c * SL + 6 * Q] = (_Float16)1.0f;
+        bimg[c * SL + 6 * Q + 1] = (_Float16)1.0f;
+    }
+    __syncthreads();
+
+    // ---- per-lane constants of the exponent GEMM (as in psi2_patch_f16) ----
+    float zA[PT][KF][2];
+    unsigned bh[PT][KF], bl[PT][KF];
+#pragma unroll
+    for (int ks = 0; ks < KF; ++ks) {
+        const int q0 = 2 * (kk + 4 * ks);
+#pragma unroll
+        for (int I = 0; I < PT; ++I) {
+            zA[I][ks][0] = (q0 < Q) ? zs[(16 * I + li) * ZLD + q0] : 0.0f;
+            zA[I][ks][1] = (q0 + 1 < Q) ? zs[(16 * I + li) * ZLD + q0 + 1] : 0.0f;
+            const float b0 = (q0 < Q) ? zs[(PS + 16 * I + li) * ZLD + q0] : 0.0f;
+            const float b1 = (q0 + 1 < Q) ? zs[(PS + 16 * I + li) * ZLD + q0 + 1] : 0.0f;
+            const _Float16 h0 = (_Float16)b0, h1 = (_Float16)b1;
+            dpgp_h2 hv = {h0, h1};
+            bh[I][ks] = __builtin_bit_cast(unsigned, hv);
+            bl[I][ks] = pack_h2(b0 - (float)h0, b1 - (float)h1);
+        }
+    }
+    constexpr int pb_off = DIAG ? 0 : PS;
+    const int rmulA = (kk == 0) ? PLD : 0, rmulB = (kk == 1) ? PLD : 0;
+    int offA[PT], offB[PT];
+#pragma unroll
+    for (int I = 0; I < PT; ++I) {
+        offA[I] = (kk == 0) ? 16 * I + li : (kk == 1 ? CONST_ONE : CONST_ZERO);
+        offB[I] = (kk == 1) ? pb_off + 16 * I + li : (kk == 0 ? CONST_ONE : CONST_ZERO);
+    }
+
+    f32x4 acc[PT][PT];
+#pragma unroll
+    for (int I = 0; I < PT; ++I)
+#pragma unroll
+        for (int J = 0; J < PT; ++J) acc[I][J] = (f32x4){0, 0, 0, 0};
+
+    const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    constexpr int NPA = (NR * XLD + 63) / 64;
+    TIN pf_s[NPA], pf_m[NPA];
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+        const int e = 64 * u + lane, r = e / XLD, k = e - r * XLD, n = nbeg + wv + 4 * r;
+        const bool ok = (e < NR * XLD) && (k < Q) && (n < nend);
+        pf_s[u] = ok ? s[(size_t)n * Q + k] : (TIN)1;
+        pf_m[u] = ok ? mu[(size_t)n * Q + k] : (TIN)0;
+    }
+    for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {
+        // ---- phase A: per-(row,q) factors: X for the exponent GEMM, the split (a, b) image and the c' pieces for P ----
+#pragma unroll
+        for (int u = 0; u < NPA; ++u) {
+            const int e = 64 * u + lane;
+            if (e < NR * XLD) {
+                const int r = e / XLD, k = e - r * XLD, n = nc + 4 * r;
+                float vx = 0.0f;
+                if (k < Q) {
+                    float a = 0.0f, bb = 0.0f, cc = (k == 0) ? -30000.0f : 0.0f;    // rows past the end: P = -30000
+                    if (n < nend) {
+                        const float g = gq[k];
+                        const float mc = (float)pf_m[u] - zc[k];
+                        const float den = 2.0f * g * (float)pf_s[u] + 1.0f;
+                        const float w = g / den;
+                        vx = (float)(-0.5 * DPGP_LOG2E) * w;
+                        a = (float)(-0.25 * DPGP_LOG2E) * w;
+                        bb = (float)DPGP_LOG2E * w * mc;
+                        cc = (float)(-DPGP_LOG2E) * (0.5f * w * mc * mc + 0.25f * dpgp_log(den));
+                    }
+                    const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
+                    const _Float16 bhh = (_Float16)bb, bll = (_Float16)(bb - (float)bhh);
+                    _Float16 *dst = aimg + r * SL + 6 * k;
+                    dst[0] = ah; dst[1] = ah; dst[2] = al; dst[3] = bhh; dst[4] = bhh; dst[5] = bll;
+                    cq[r * QS + k] = cc;
+                }
+                xa[e] = vx;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NPA; ++u) {      // next chunk's q(X) rows: in flight during the rest of this chunk
+            const int e = 64 * u + lane, r = e / XLD, k = e - r * XLD, n = nc + 4 * NR + 4 * r;
+            const bool ok = (e < NR * XLD) && (k < Q) && (n < nend);
+            pf_s[u] = ok ? s[(size_t)n * Q + k] : (TIN)1;
+            pf_m[u] = ok ? mu[(size_t)n * Q + k] : (TIN)0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 16) {
+            float c = 0.0f;
+            for (int q = 0; q < Q; ++q) c += cq[lane * QS + q];
+            c = fmaxf(c, -30000.0f);
+            const _Float16 ch = (_Float16)c;
+            aimg[lane * SL + 6 * Q] = ch;
+            aimg[lane * SL + 6 * Q + 1] = (_Float16)(c - (float)ch);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase B: P rows of this chunk on the matrix pipe, stored as packed (hi, lo) f16 ----
+        for (int J = 0; J < NCOL / 16; ++J) {
+            f32x4 c = {0, 0, 0, 0};
+            for (int ks = 0; ks < kf1; ++ks) {
+                const dpgp_h8 av = *reinterpret_cast<const dpgp_h8 *>(aimg + li * SL + 32 * ks + 8 * kk);
+                const dpgp_h8 bv = *reinterpret_cast<const dpgp_h8 *>(bimg + (16 * J + li) * SL + 32 * ks + 8 * kk);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float pc = fminf(fmaxf(c[v], -30000.0f), 30000.0f);
+                const _Float16 ph = (_Float16)pc;
+                dpgp_h2 hv = {ph, (_Float16)(pc - (float)ph)};
+                pw[(4 * kk + v) * PLD + 16 * J + li] = __builtin_bit_cast(unsigned, hv);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase C: per row, exponent tile on the f16 matrix pipe, psi2 += exp2(E) ----
+#pragma unroll 1
+        for (int r = 0; r < NR; ++r) {
+            float xk[KF][2];
+#pragma unroll
+            for (int ks = 0; ks < KF; ++ks) {
+                xk[ks][0] = xa[r * XLD + 2 * (kk + 4 * ks)];
+                xk[ks][1] = xa[r * XLD + 2 * (kk + 4 * ks) + 1];
+            }
+            unsigned spA[PT], spB[PT];
+#pragma unroll
+            for (int I = 0; I < PT; ++I) {
+                spA[I] = pw[r * rmulA + offA[I]];
+                spB[I] = pw[r * rmulB + offB[I]];
+            }
+#pragma unroll
+            for (int I = 0; I < PT; ++I) {
+                dpgp_u4 aop[KF];
+#pragma unroll
+                for (int ks = 0; ks < KF; ++ks) {
+                    unsigned hi, lo;
+                    split_products(xk[ks][0], zA[I][ks][0], xk[ks][1], zA[I][ks][1], hi, lo);
+                    aop[ks] = (dpgp_u4){hi, hi, lo, ks == 0 ? spA[I] : 0u};
+                }
+                f32x4 c[PT];
+#pragma unroll
+                for (int J = 0; J < PT; ++J) c[J] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KF; ++ks)
+#pragma unroll
+                    for (int J = 0; J < PT; ++J)
+                        if (!(DIAG && J > I)) {
+                            const dpgp_u4 bop = {bh[J][ks], bl[J][ks], bh[J][ks], ks == 0 ? spB[J] : 0u};
+                            c[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dpgp_h8, aop[ks]),
+                                                                          __builtin_bit_cast(dpgp_h8, bop), c[J], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int J = 0; J < PT; ++J)
+                    if (!(DIAG && J > I)) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[I][J][v] += dpgp_exp2(c[J][v]);
+                    }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+
+    // ---- epilogue ----
+    float *red = zs + L.off_wave;
+    const float al = (float)alpha[b];
+    const float al2 = al * al;
+    float *out = part + ((size_t)sp * B + b) * (size_t)Mp * Mp;
+#pragma unroll
+    for (int I = 0; I < PT; ++I) {
+        __syncthreads();
+#pragma unroll
+        for (int J = 0; J < PT; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[((wv * PT + J) * 4 + v) * 64 + lane] = acc[I][J][v];
+        __syncthreads();
+        for (int e = t; e < PT * 256; e += 256) {
+            const int J = e >> 8, v = (e >> 6) & 3, l = e & 63;
+            if (DIAG && J > I) continue;
+            float sum = 0;
+#pragma unroll
+            for (int w_ = 0; w_ < 4; ++w_) sum += red[((w_ * PT + J) * 4 + v) * 64 + l];
+            const int row = 16 * I + Mfma<float>::row(l, v), col = 16 * J + (l & 15);
+            const int m = m_base + row, mp = mp_base + col;
+            if (m < Mp && mp < Mp) {
+                float val = 0;
+                if (m < M && mp < M) {
+                    const float *z1 = zs + row * ZLD, *z2 = zs + (PS + col) * ZLD;
+                    float bsum = 0;
+                    for (int q = 0; q < Q; ++q) {
+                        const float d = z1[q] - z2[q];
+                        bsum += gq[q] * d * d;
+                    }
+                    val = al2 * sum * dpgp_exp2((float)(-0.25 * DPGP_LOG2E) * bsum);
+                }
+                out[(size_t)m * Mp + mp] = val;
+            }
+        }
+    }
+}
+
 template <typename TIN, int KB>
 __global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
                                                        const TIN *__restrict__ mu, const TIN *__restrict__ s,
@@ -594,10 +868,17 @@ __global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, in
     }
     int b, sp, pi, pj;
     psi2_block_coords((Mp + 63) / 64, zoff, b, sp, pi, pj);
+#ifdef PSI2_P_VALU       // diagnostic build: P rows by the direct squared-distance form on the VALU
     if (pi == pj)
         psi2_patch_f16<TIN, KB, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
     else
         psi2_patch_f16<TIN, KB, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
+#else
+    if (pi == pj)
+        psi2_patch_f16p<TIN, KB, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
+    else
+        psi2_patch_f16p<TIN, KB, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
+#endif
 }
 
 template <typename TIN, typename T, int KS, int PT>
@@ -738,9 +1019,13 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
                               const TIN *alpha, float *part, int ns, const ChainKTask &task, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16);
     const int nps = dpgp_ceil_div(Mp, 64);
-    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
+    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);      // 4 waves x 16-row chunks
     dim3 grid(B, ns, nps * (nps + 1) / 2 + (task.ws ? 1 : 0));
+#ifdef PSI2_P_VALU
     size_t lds = sizeof(float) * (size_t)Psi2F16Lds<KB>::ELEMS;
+#else
+    size_t lds = sizeof(float) * (size_t)psi2p_layout<KB>(Q).elems;
+#endif
     if (task.ws && la_lds_bytes(task.Mp, task.elem) > lds) lds = la_lds_bytes(task.Mp, task.elem);
     auto kern = psi2_f16_kernel<TIN, KB>;
     if (lds > 48 * 1024) {
