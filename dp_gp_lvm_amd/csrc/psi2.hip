@@ -317,13 +317,19 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
     dpgp_h2 h = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, h);
 }
-// hi/lo split of two fp32 products x0*z0, x1*z1 into packed f16 pairs (compiles to v_fma_mix* / v_cvt_pk_f16_f32)
+// hi/lo split of two fp32 products x0*z0, x1*z1 into packed f16 pairs, four instructions:
+//   hi.lo16 = f16(x0*z0), hi.hi16 = f16(x1*z1)                    (single rounding of the exact products)
+//   lo.lo16 = f16(x0*z0 - hi.lo16), lo.hi16 = f16(x1*z1 - hi.hi16) (exact FMA, the f16 addend read through op_sel)
+// hipcc's own lowering of the C++ form needs eight (it computes hi twice: v_mul + v_cvt_pk for the pack and
+// v_fma_mixlo for the subtraction).  Plain VALU RAW dependencies only: the hardware interlocks them (no wait states).
 __device__ __forceinline__ void split_products(float x0, float z0, float x1, float z1, unsigned &hi, unsigned &lo) {
-    const _Float16 h0 = (_Float16)(x0 * z0), h1 = (_Float16)(x1 * z1);
-    const float l0 = __builtin_fmaf(x0, z0, -(float)h0), l1 = __builtin_fmaf(x1, z1, -(float)h1);
-    dpgp_h2 hv = {h0, h1};
-    hi = __builtin_bit_cast(unsigned, hv);
-    lo = pack_h2(l0, l1);
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(z0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(z1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(z0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(z1), "v"(h));
+    hi = h;
+    lo = l;
 }
 
 template <int KB> struct Psi2F16Lds {
