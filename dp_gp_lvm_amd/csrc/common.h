@@ -31,6 +31,7 @@ inline hipError_t &dpgp_last_error_slot() {
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // One 16x16x4 matrix-core step D = A(16x4) * B(4x16) + C for one wavefront.

@@ -317,19 +317,27 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
     dpgp_h2 h = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, h);
 }
-// hi/lo split of two fp32 products x0*z0, x1*z1 into packed f16 pairs, four instructions:
-//   hi.lo16 = f16(x0*z0), hi.hi16 = f16(x1*z1)                    (single rounding of the exact products)
-//   lo.lo16 = f16(x0*z0 - hi.lo16), lo.hi16 = f16(x1*z1 - hi.hi16) (exact FMA, the f16 addend read through op_sel)
-// hipcc's own lowering of the C++ form needs eight (it computes hi twice: v_mul + v_cvt_pk for the pack and
-// v_fma_mixlo for the subtraction).  Plain VALU RAW dependencies only: the hardware interlocks them (no wait states).
-__device__ __forceinline__ void split_products(float x0, float z0, float x1, float z1, unsigned &hi, unsigned &lo) {
+// hi/lo split of two fp32 products x0*z0, x1*z1 into packed f16 pairs:
+//   p = x * z (packed fp32 multiply);  hi = (f16(p0), f16(p1))  (v_cvt_pk_f16_f32, round to nearest)
+//   lo = (f16(x0*z0 - hi0), f16(x1*z1 - hi1))                   (exact fp32 FMA reading the f16 addend through op_sel)
+// Five instructions of the cheap VOP3 class (measured on gfx950, scratch/ubench/issue2.hip: ~4.5 cycles each with two
+// waves per SIMD); the four-instruction v_fma_mixlo/mixhi_f16 form runs at the transcendental rate (8.5 cycles each).
+// Plain VALU RAW dependencies only: the hardware interlocks them (no wait states).
+typedef float dpgp_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_products(dpgp_f2 x, dpgp_f2 z, unsigned &hi, unsigned &lo) {
+    dpgp_f2 p;
     unsigned h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(z0));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(z1));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(z0), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(z1), "v"(h));
+    float l0, l1;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(x), "v"(z));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(p[0]), "v"(p[1]));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(x[0]), "v"(z[0]), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(x[1]), "v"(z[1]), "v"(h));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(l0), "v"(l1));
     hi = h;
     lo = l;
+}
+__device__ __forceinline__ void split_products(float x0, float z0, float x1, float z1, unsigned &hi, unsigned &lo) {
+    split_products((dpgp_f2){x0, x1}, (dpgp_f2){z0, z1}, hi, lo);
 }
 
 template <int KB> struct Psi2F16Lds {
@@ -608,8 +616,8 @@ template <int KB> __host__ __device__ inline Psi2PLayout psi2p_layout(int Q) {
     L.o_aimg = 16 * G::XLD;
     L.o_cq = L.o_aimg + 16 * L.SL / 2;
     L.o_pw = L.o_cq + 16 * L.QS;
-    L.wsz = L.o_pw + 16 * G::PLD + 4;
-    const int fill = L.off_wave + 4 * L.wsz, red = L.off_wave + 4 * G::PT * 4 * 64;
+    L.wsz = L.o_pw + 16 * G::PLD + 36;                         // + the constant word (1,1) at [0] and [32]
+    const int fill = L.off_wave + 4 * L.wsz, red = L.off_wave + 4 * 2 * 16 * 64;
     L.elems = fill > red ? fill : red;
     return L;
 }
@@ -635,7 +643,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
     _Float16 *aimg = reinterpret_cast<_Float16 *>(wp + L.o_aimg);             // [16][SL]  row-side image of P
     float *cq = wp + L.o_cq;                                                  // [16][QS]  per-(row,q) pieces of c'_n
     unsigned *pw = reinterpret_cast<unsigned *>(wp + L.o_pw);                 // [16][PLD] packed (Ph, Pl) + 2 constants
-    constexpr int CONST_ONE = NR * PLD, CONST_ZERO = NR * PLD + 1;
+    constexpr int CONST_ONE = NR * PLD;
     constexpr int NCOL = DIAG ? PS : 2 * PS;
 
     if (t < Q) gq[t] = (float)gamma[(size_t)b * Q + t];
@@ -647,7 +655,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
     }
     for (int e = t; e < 128 * SL / 2; e += 256) reinterpret_cast<unsigned *>(bimg)[e] = 0u;
     for (int e = lane; e < 16 * SL / 2; e += 64) reinterpret_cast<unsigned *>(aimg)[e] = 0u;
-    if (lane == 0) { pw[CONST_ONE] = DPGP_H2_ONES; pw[CONST_ZERO] = 0u; }
+    if (lane < 2) pw[CONST_ONE + 32 * lane] = DPGP_H2_ONES;
     __syncthreads();
     for (int e = t; e < NCOL * 2 * Q; e += 256) {        // (column, term): z^2 and z, split, slots {h, l, h}
         const int c = e / (2 * Q), tt = e - c * 2 * Q, q = tt >> 1;
@@ -663,38 +671,42 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
     }
     __syncthreads();
 
-    // ---- per-lane constants of the exponent GEMM (as in psi2_patch_f16) ----
-    float zA[PT][KF][2];
-    unsigned bh[PT][KF], bl[PT][KF];
+    // ---- per-lane constants of the exponent GEMM: 32x32x16 tiles, lane = (row li5, K-half k2), K-step ks holds the two
+    //      latent dims q0 = 2 (k2 + 2 ks), q0 + 1 in the slot layout of the header comment ----
+    const int li5 = lane & 31, k2 = lane >> 5;
+    dpgp_f2 zA[2][KB];
+    unsigned bh[2][KB], bl[2][KB];
 #pragma unroll
-    for (int ks = 0; ks < KF; ++ks) {
-        const int q0 = 2 * (kk + 4 * ks);
+    for (int ks = 0; ks < KB; ++ks) {
+        const int q0 = 2 * (k2 + 2 * ks);
 #pragma unroll
-        for (int I = 0; I < PT; ++I) {
-            zA[I][ks][0] = (q0 < Q) ? zs[(16 * I + li) * ZLD + q0] : 0.0f;
-            zA[I][ks][1] = (q0 + 1 < Q) ? zs[(16 * I + li) * ZLD + q0 + 1] : 0.0f;
-            const float b0 = (q0 < Q) ? zs[(PS + 16 * I + li) * ZLD + q0] : 0.0f;
-            const float b1 = (q0 + 1 < Q) ? zs[(PS + 16 * I + li) * ZLD + q0 + 1] : 0.0f;
+        for (int I = 0; I < 2; ++I) {
+            zA[I][ks][0] = (q0 < Q) ? zs[(32 * I + li5) * ZLD + q0] : 0.0f;
+            zA[I][ks][1] = (q0 + 1 < Q) ? zs[(32 * I + li5) * ZLD + q0 + 1] : 0.0f;
+            const float b0 = (q0 < Q) ? zs[(PS + 32 * I + li5) * ZLD + q0] : 0.0f;
+            const float b1 = (q0 + 1 < Q) ? zs[(PS + 32 * I + li5) * ZLD + q0 + 1] : 0.0f;
             const _Float16 h0 = (_Float16)b0, h1 = (_Float16)b1;
             dpgp_h2 hv = {h0, h1};
             bh[I][ks] = __builtin_bit_cast(unsigned, hv);
             bl[I][ks] = pack_h2(b0 - (float)h0, b1 - (float)h1);
         }
     }
+    // spare slots of K-step 0: lanes k2 = 0 carry A = (Ph, Pl) of P[n,m], B = (1,1); lanes k2 = 1 carry A = (1,1),
+    // B = (Ph, Pl) of P[n,m'].  The constant word sits at pw[CONST_ONE] and pw[CONST_ONE + 32] so that both row tiles
+    // are one two-word read at a fixed distance.
     constexpr int pb_off = DIAG ? 0 : PS;
-    const int rmulA = (kk == 0) ? PLD : 0, rmulB = (kk == 1) ? PLD : 0;
-    int offA[PT], offB[PT];
-#pragma unroll
-    for (int I = 0; I < PT; ++I) {
-        offA[I] = (kk == 0) ? 16 * I + li : (kk == 1 ? CONST_ONE : CONST_ZERO);
-        offB[I] = (kk == 1) ? pb_off + 16 * I + li : (kk == 0 ? CONST_ONE : CONST_ZERO);
-    }
+    const unsigned *pwA = pw + ((k2 == 0) ? li5 : CONST_ONE);
+    const unsigned *pwB = pw + ((k2 == 1) ? pb_off + li5 : CONST_ONE);
+    const int stepA = (k2 == 0) ? PLD : 0, stepB = (k2 == 1) ? PLD : 0;
+    const float *xaq = xa + 2 * k2;
 
-    f32x4 acc[PT][PT];
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int I = 0; I < PT; ++I)
+    for (int I = 0; I < 2; ++I)
 #pragma unroll
-        for (int J = 0; J < PT; ++J) acc[I][J] = (f32x4){0, 0, 0, 0};
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[I][J][v] = 0.0f;
 
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
     constexpr int NPA = (NR * XLD + 63) / 64;
@@ -775,49 +787,77 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- phase C: per row, exponent tile on the f16 matrix pipe, psi2 += exp2(E) ----
-#pragma unroll 1
-        for (int r = 0; r < NR; ++r) {
-            float xk[KF][2];
+        // ---- phase C: per row, the 64 x 64 exponent patch as 32x32x16 f16 MFMA tiles, psi2 += exp2(E) ----
+        // Software pipeline over the tiles T0 = (0,0), T1 = (0,1), T2 = (1,0), T3 = (1,1) of consecutive rows: the MFMA
+        // chain of a tile is issued two exp stages before its results are read, so a wave never waits on the matrix pipe
+        // (2 waves per SIMD are too few to hide that latency by switching).  Diagonal patches skip T1.
+        {
+            dpgp_f2 xk[KB];
+            unsigned spA[2], spB[2], spBn[2];
+            dpgp_u4 a0[KB], a1[KB];
+            f32x16 c0, c1, c2, c3;
+            auto load_row = [&](int r, unsigned (&sb)[2]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ks = 0; ks < KF; ++ks) {
-                xk[ks][0] = xa[r * XLD + 2 * (kk + 4 * ks)];
-                xk[ks][1] = xa[r * XLD + 2 * (kk + 4 * ks) + 1];
-            }
-            unsigned spA[PT], spB[PT];
+                for (int ks = 0; ks < KB; ++ks) xk[ks] = *reinterpret_cast<const dpgp_f2 *>(xaq + r * XLD + 4 * ks);
 #pragma unroll
-            for (int I = 0; I < PT; ++I) {
-                spA[I] = pw[r * rmulA + offA[I]];
-                spB[I] = pw[r * rmulB + offB[I]];
-            }
+                for (int I = 0; I < 2; ++I) {
+                    spA[I] = pwA[r * stepA + 32 * I];
+                    sb[I] = pwB[r * stepB + 32 * I];
+                }
+            };
+            auto split = [&](int I, dpgp_u4 (&aop)[KB]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int I = 0; I < PT; ++I) {
-                dpgp_u4 aop[KF];
-#pragma unroll
-                for (int ks = 0; ks < KF; ++ks) {
+                for (int ks = 0; ks < KB; ++ks) {
                     unsigned hi, lo;
-                    split_products(xk[ks][0], zA[I][ks][0], xk[ks][1], zA[I][ks][1], hi, lo);
+                    split_products(xk[ks], zA[I][ks], hi, lo);
                     aop[ks] = (dpgp_u4){hi, hi, lo, ks == 0 ? spA[I] : 0u};
                 }
-                f32x4 c[PT];
+            };
+            auto issue = [&](const dpgp_u4 (&aop)[KB], int J, const unsigned (&sb)[2]) __attribute__((always_inline)) {
+                f32x16 c;
 #pragma unroll
-                for (int J = 0; J < PT; ++J) c[J] = (f32x4){0, 0, 0, 0};
+                for (int v = 0; v < 16; ++v) c[v] = 0.0f;
 #pragma unroll
-                for (int ks = 0; ks < KF; ++ks)
+                for (int ks = 0; ks < KB; ++ks) {
+                    const dpgp_u4 bop = {bh[J][ks], bl[J][ks], bh[J][ks], ks == 0 ? sb[J] : 0u};
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dpgp_h8, aop[ks]),
+                                                               __builtin_bit_cast(dpgp_h8, bop), c, 0, 0, 0);
+                }
+                return c;
+            };
+            auto expacc = [&](f32x16 &a, const f32x16 &c) __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int J = 0; J < PT; ++J)
-                        if (!(DIAG && J > I)) {
-                            const dpgp_u4 bop = {bh[J][ks], bl[J][ks], bh[J][ks], ks == 0 ? spB[J] : 0u};
-                            c[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dpgp_h8, aop[ks]),
-                                                                          __builtin_bit_cast(dpgp_h8, bop), c[J], 0, 0, 0);
-                        }
-#pragma unroll
-                for (int J = 0; J < PT; ++J)
-                    if (!(DIAG && J > I)) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) acc[I][J][v] += dpgp_exp2(c[J][v]);
-                    }
+                for (int v = 0; v < 16; ++v) a[v] += dpgp_exp2(c[v]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            load_row(0, spB);
+            split(0, a0);
+            split(1, a1);
+            c0 = issue(a0, 0, spB);
+            if (!DIAG) c1 = issue(a0, 1, spB);
+#pragma unroll 1
+            for (int r = 0; r < NR - 1; ++r) {
+                c2 = issue(a1, 0, spB);
+                load_row(r + 1, spBn);
+                expacc(acc[0][0], c0);
+                c3 = issue(a1, 1, spB);
+                if (!DIAG) expacc(acc[0][1], c1);
+                split(0, a0);
+                c0 = issue(a0, 0, spBn);
+                expacc(acc[1][0], c2);
+                if (!DIAG) c1 = issue(a0, 1, spBn);
+                split(1, a1);
+                expacc(acc[1][1], c3);
+                spB[0] = spBn[0];
+                spB[1] = spBn[1];
             }
+            c2 = issue(a1, 0, spB);
+            expacc(acc[0][0], c0);
+            c3 = issue(a1, 1, spB);
+            if (!DIAG) expacc(acc[0][1], c1);
+            expacc(acc[1][0], c2);
+            expacc(acc[1][1], c3);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -827,21 +867,24 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
     const float al = (float)alpha[b];
     const float al2 = al * al;
     float *out = part + ((size_t)sp * B + b) * (size_t)Mp * Mp;
+    // 32x32 result tile: register v of lane l holds (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
 #pragma unroll
-    for (int I = 0; I < PT; ++I) {
+    for (int I = 0; I < 2; ++I) {
         __syncthreads();
 #pragma unroll
-        for (int J = 0; J < PT; ++J)
+        for (int J = 0; J < 2; ++J)
+            if (!(DIAG && J > I)) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) red[((wv * PT + J) * 4 + v) * 64 + lane] = acc[I][J][v];
+                for (int v = 0; v < 16; ++v) red[((wv * 2 + J) * 16 + v) * 64 + lane] = acc[I][J][v];
+            }
         __syncthreads();
-        for (int e = t; e < PT * 256; e += 256) {
-            const int J = e >> 8, v = (e >> 6) & 3, l = e & 63;
+        for (int e = t; e < 2 * 1024; e += 256) {
+            const int J = e >> 10, v = (e >> 6) & 15, l = e & 63;
             if (DIAG && J > I) continue;
             float sum = 0;
 #pragma unroll
-            for (int w_ = 0; w_ < 4; ++w_) sum += red[((w_ * PT + J) * 4 + v) * 64 + l];
-            const int row = 16 * I + Mfma<float>::row(l, v), col = 16 * J + (l & 15);
+            for (int w_ = 0; w_ < 4; ++w_) sum += red[((w_ * 2 + J) * 16 + v) * 64 + l];
+            const int row = 32 * I + 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), col = 32 * J + (l & 31);
             const int m = m_base + row, mp = mp_base + col;
             if (m < Mp && mp < Mp) {
                 float val = 0;
