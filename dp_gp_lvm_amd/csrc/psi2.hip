@@ -32,22 +32,20 @@ struct ChainKTask {
     double *logdet_k;
     int *info_k;
     int M, Mp, elem;     // elem = 4 (float) or 8 (double)
+    int last;            // f16 kernel: tasks at the end of the grid instead of in front (see psi2_task_1d)
 };
-__device__ __attribute__((noinline)) void chain_k_task(const ChainKTask &tk, unsigned char *smem_raw) {
-    if (blockIdx.y != 0) return;
+__device__ __attribute__((noinline)) void chain_k_task(const ChainKTask &tk, int d, unsigned char *smem_raw) {
     if (tk.elem == 8)
-        chain_k_body<double>(blockIdx.x, tk.M, tk.Mp, (double *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
+        chain_k_body<double>(d, tk.M, tk.Mp, (double *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
     else
-        chain_k_body<float>(blockIdx.x, tk.M, tk.Mp, (float *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
+        chain_k_body<float>(d, tk.M, tk.Mp, (float *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
 }
 
 // Workgroup coordinates.  grid = (B, n-splits, patches); the patch index is the SLOWEST dimension and enumerates the
 // off-diagonal patches (16 tiles of work) before the diagonal ones (10 tiles), so the long workgroups are dispatched
 // first and the short ones fill the tail.
-__device__ __forceinline__ void psi2_block_coords(int nps, int zoff, int &b, int &sp, int &pi, int &pj) {
-    b = blockIdx.x;
-    sp = blockIdx.y;
-    const int p = blockIdx.z - zoff, noff = nps * (nps - 1) / 2;
+__device__ __forceinline__ void psi2_patch_coords(int nps, int p, int &pi, int &pj) {
+    const int noff = nps * (nps - 1) / 2;
     if (p < noff) {                    // strict lower triangle: p = pi (pi - 1) / 2 + pj, pj < pi
         int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
         while (i * (i - 1) / 2 > p) --i;
@@ -57,6 +55,31 @@ __device__ __forceinline__ void psi2_block_coords(int nps, int zoff, int &b, int
     } else {
         pi = pj = p - noff;
     }
+}
+__device__ __forceinline__ void psi2_block_coords(int nps, int zoff, int &b, int &sp, int &pi, int &pj) {
+    b = blockIdx.x;
+    sp = blockIdx.y;
+    psi2_patch_coords(nps, blockIdx.z - zoff, pi, pj);
+}
+// One-dimensional grid of the f16 kernel: C = B K_uu tasks (if fused) and P = B * ns * patches psi2 items (item j =
+// b + B (sp + ns patch), long off-diagonal patches first).  The K_uu tasks are latency bound (one small Cholesky each, hardly
+// any VALU work) and a psi2 workgroup needs a second psi2 workgroup on its compute unit to keep the vector units busy (one
+// wave per SIMD reaches ~2/3 of the issue rate).  Measured placements of the K_uu tasks (config 3 / config 2, evals/s):
+//   en bloc in front 515 / 2499;  en bloc at the end 545 / 2064;  interleaved with psi2 items in runs of 8: 457 / 2452
+//   (next to a psi2 workgroup a K_uu task takes ~600 us instead of ~100 us, whatever its s_setprio).
+// In front, B >= ~256 tasks hold every slot of the GPU for ~100 us with idle vector units; at the end they fill the slots
+// the psi2 tail leaves empty anyway, but add their full latency when there are only few of them.  Hence: at the end iff
+// B >= 256.
+__device__ __forceinline__ bool psi2_task_1d(int id, int C, bool chain_last, int &task) {
+    if (chain_last) {
+        const int P = (int)gridDim.x - C;
+        if (id < P) { task = id; return false; }
+        task = id - P;
+        return true;
+    }
+    if (id < C) { task = id; return true; }
+    task = id - C;
+    return false;
 }
 
 // LDS geometry shared by the kernel and the host-side size computation
@@ -603,6 +626,40 @@ __device__ __forceinline__ void psi2_patch_f16(int N, int M, int Q, int B, const
 // LDS (4-byte units): zs | zc | gq | bimg (128 columns x SL f16) | 4 x wave { xa[16][XLD] | aimg[16][SL] f16 |
 // cq[16][QS] | pw[16][PLD] + 2 constants }.
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef PSI2_PROFILE            // diagnostic build only (scratch/): phase clocks (10 ns units) of wave 0 of one workgroup
+__device__ long long g_psi2_stamps[16];
+__device__ long long g_psi2_wg[3 * 8192];     // per workgroup: start, end (10 ns units), XCC/SE/CU id
+extern "C" void dpgp_debug_psi2_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_psi2_stamps), sizeof(long long) * 16); }
+extern "C" void dpgp_debug_psi2_wg(long long *out, int n) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_psi2_wg), sizeof(long long) * 3 * n); }
+#define P2_WG(i) do { if (threadIdx.x == 0) { const int id__ = blockIdx.x; \
+        if (id__ < 8192) { g_psi2_wg[3 * id__ + (i)] = wall_clock64(); if ((i) == 0) { unsigned hw__, xc__; \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc__)); \
+        g_psi2_wg[3 * id__ + 2] = ((long long)xc__ << 32) | hw__; } } } } while (0)
+#define P2_ON (blockIdx.x == (PSI2_PROFILE) && threadIdx.x == 0)
+#define P2_MARK(i) do { if (P2_ON) g_psi2_stamps[i] = wall_clock64(); } while (0)
+#define P2_BEGIN() long long t2__ = wall_clock64()
+#define P2_RESTART() t2__ = wall_clock64()
+#define P2_END(i) do { if (P2_ON) g_psi2_stamps[i] += wall_clock64() - t2__; } while (0)
+#else
+#define P2_MARK(i)
+#define P2_WG(i)
+#define P2_BEGIN()
+#define P2_RESTART()
+#define P2_END(i)
+#endif
+// (hi, lo) f16 words of two fp32 values (phase B of the P-on-MFMA kernel): w = hi | lo << 16 with hi = f16(p),
+// lo = f16(p - hi); six instructions per pair.
+__device__ __forceinline__ void split_pair_words(float p0, float p1, unsigned &w0, unsigned &w1) {
+    unsigned h, l;
+    float l0, l1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(p0), "v"(p1));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(p0), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(p1), "v"(h));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(l0), "v"(l1));
+    w0 = __builtin_amdgcn_perm(l, h, 0x05040100u);
+    w1 = __builtin_amdgcn_perm(l, h, 0x07060302u);
+}
+
 struct Psi2PLayout {
     int SL, QS, off_bimg, off_wave, wsz, o_aimg, o_cq, o_pw, elems;
 };
@@ -610,7 +667,7 @@ template <int KB> __host__ __device__ inline Psi2PLayout psi2p_layout(int Q) {
     typedef Psi2F16Lds<KB> G;
     Psi2PLayout L;
     L.SL = 32 * ((6 * Q + 2 + 31) / 32);                       // f16 slots per image row
-    L.QS = (Q + 3) & ~3;
+    L.QS = G::KQ;                                              // row stride of the c' pieces (zero padded)
     L.off_bimg = 2 * G::PS * G::ZLD + 2 * (DPGP_MAX_Q + 2);
     L.off_wave = L.off_bimg + 128 * L.SL / 2;
     L.o_aimg = 16 * G::XLD;
@@ -646,7 +703,12 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
     constexpr int CONST_ONE = NR * PLD;
     constexpr int NCOL = DIAG ? PS : 2 * PS;
 
-    if (t < Q) gq[t] = (float)gamma[(size_t)b * Q + t];
+    P2_MARK(0);
+    P2_WG(0);
+#ifdef PSI2_PROFILE
+    if (P2_ON) { g_psi2_stamps[2] = 0; g_psi2_stamps[3] = 0; g_psi2_stamps[4] = 0; }
+#endif
+    if (t < G::KQ) gq[t] = (t < Q) ? (float)gamma[(size_t)b * Q + t] : 0.0f;
     block_column_means(z, M, Q, zc, reinterpret_cast<double *>(zs + L.off_wave));
     for (int e = t; e < 2 * PS * ZLD; e += 256) {
         int r = e / ZLD, k = e - r * ZLD;
@@ -718,7 +780,12 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
         pf_s[u] = ok ? s[(size_t)n * Q + k] : (TIN)1;
         pf_m[u] = ok ? mu[(size_t)n * Q + k] : (TIN)0;
     }
+    P2_MARK(1);
     for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {
+        P2_BEGIN();
+#ifdef PSI2_DIAG_SKIP_AB      // timing experiment only (wrong results): phases A and B for the first chunk only
+        if (nc != nbeg + wv) goto phase_c;
+#endif
         // ---- phase A: per-(row,q) factors: X for the exponent GEMM, the split (a, b) image and the c' pieces for P ----
 #pragma unroll
         for (int u = 0; u < NPA; ++u) {
@@ -740,9 +807,14 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
                     }
                     const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
                     const _Float16 bhh = (_Float16)bb, bll = (_Float16)(bb - (float)bhh);
-                    _Float16 *dst = aimg + r * SL + 6 * k;
-                    dst[0] = ah; dst[1] = ah; dst[2] = al; dst[3] = bhh; dst[4] = bhh; dst[5] = bll;
+                    unsigned *dst = reinterpret_cast<unsigned *>(aimg + r * SL + 6 * k);     // slots {ah, ah, al, bh, bh, bl}
+                    const dpgp_h2 w0 = {ah, ah}, w1 = {al, bhh}, w2 = {bhh, bll};
+                    dst[0] = __builtin_bit_cast(unsigned, w0);
+                    dst[1] = __builtin_bit_cast(unsigned, w1);
+                    dst[2] = __builtin_bit_cast(unsigned, w2);
                     cq[r * QS + k] = cc;
+                } else if (k < QS) {
+                    cq[r * QS + k] = 0.0f;
                 }
                 xa[e] = vx;
             }
@@ -759,34 +831,55 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < 16) {
             float c = 0.0f;
-            for (int q = 0; q < Q; ++q) c += cq[lane * QS + q];
+#pragma unroll
+            for (int q4 = 0; q4 < G::KQ / 4; ++q4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(cq + lane * G::KQ + 4 * q4);
+                c += (v[0] + v[1]) + (v[2] + v[3]);
+            }
             c = fmaxf(c, -30000.0f);
             const _Float16 ch = (_Float16)c;
-            aimg[lane * SL + 6 * Q] = ch;
-            aimg[lane * SL + 6 * Q + 1] = (_Float16)(c - (float)ch);
+            const dpgp_h2 cw = {ch, (_Float16)(c - (float)ch)};
+            *reinterpret_cast<unsigned *>(aimg + lane * SL + 6 * Q) = __builtin_bit_cast(unsigned, cw);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        P2_END(2);
+        P2_RESTART();
         // ---- phase B: P rows of this chunk on the matrix pipe, stored as packed (hi, lo) f16 ----
-        for (int J = 0; J < NCOL / 16; ++J) {
-            f32x4 c = {0, 0, 0, 0};
-            for (int ks = 0; ks < kf1; ++ks) {
+        {
+            constexpr int NJ = NCOL / 16;
+            f32x4 pc[NJ];
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) pc[J] = (f32x4){0, 0, 0, 0};
+            for (int ks = 0; ks < kf1; ++ks) {       // K-step outermost: NJ independent accumulation chains in flight
                 const dpgp_h8 av = *reinterpret_cast<const dpgp_h8 *>(aimg + li * SL + 32 * ks + 8 * kk);
-                const dpgp_h8 bv = *reinterpret_cast<const dpgp_h8 *>(bimg + (16 * J + li) * SL + 32 * ks + 8 * kk);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+#pragma unroll
+                for (int J = 0; J < NJ; ++J) {
+                    const dpgp_h8 bv = *reinterpret_cast<const dpgp_h8 *>(bimg + (16 * J + li) * SL + 32 * ks + 8 * kk);
+                    pc[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, pc[J], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float pc = fminf(fmaxf(c[v], -30000.0f), 30000.0f);
-                const _Float16 ph = (_Float16)pc;
-                dpgp_h2 hv = {ph, (_Float16)(pc - (float)ph)};
-                pw[(4 * kk + v) * PLD + 16 * J + li] = __builtin_bit_cast(unsigned, hv);
-            }
+            for (int J = 0; J < NJ; ++J)
+#pragma unroll
+                for (int v = 0; v < 4; v += 2) {
+                    unsigned w0, w1;
+                    split_pair_words(fminf(fmaxf(pc[J][v], -30000.0f), 30000.0f),
+                                     fminf(fmaxf(pc[J][v + 1], -30000.0f), 30000.0f), w0, w1);
+                    pw[(4 * kk + v) * PLD + 16 * J + li] = w0;
+                    pw[(4 * kk + v + 1) * PLD + 16 * J + li] = w1;
+                }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        P2_END(3);
+        P2_RESTART();
+#ifdef PSI2_DIAG_SKIP_AB
+    phase_c:
+#endif
+#ifndef PSI2_DIAG_SKIP_C      // timing experiment only (wrong results)
         // ---- phase C: per row, the 64 x 64 exponent patch as 32x32x16 f16 MFMA tiles, psi2 += exp2(E) ----
         // Software pipeline over the tiles T0 = (0,0), T1 = (0,1), T2 = (1,0), T3 = (1,1) of consecutive rows: the MFMA
         // chain of a tile is issued two exp stages before its results are read, so a wave never waits on the matrix pipe
@@ -859,8 +952,11 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
             expacc(acc[1][0], c2);
             expacc(acc[1][1], c3);
         }
+#endif
+        P2_END(4);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    P2_MARK(5);
 
     // ---- epilogue ----
     float *red = zs + L.off_wave;
@@ -878,29 +974,43 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
                 for (int v = 0; v < 16; ++v) red[((wv * 2 + J) * 16 + v) * 64 + lane] = acc[I][J][v];
             }
         __syncthreads();
-        for (int e = t; e < 2 * 1024; e += 256) {
-            const int J = e >> 10, v = (e >> 6) & 15, l = e & 63;
-            if (DIAG && J > I) continue;
-            float sum = 0;
+        // thread t sums registers v = wv + 4 i (i = 0..3) of lane l = t & 63 of both column tiles: rows
+        // 32 I + 8 i + 4 (l / 32) + wv, columns 32 J + l % 32; the z rows are zero padded up to KQ
+        const int l = t & 63;
 #pragma unroll
-            for (int w_ = 0; w_ < 4; ++w_) sum += red[((w_ * 2 + J) * 16 + v) * 64 + l];
-            const int row = 32 * I + 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), col = 32 * J + (l & 31);
-            const int m = m_base + row, mp = mp_base + col;
-            if (m < Mp && mp < Mp) {
-                float val = 0;
-                if (m < M && mp < M) {
-                    const float *z1 = zs + row * ZLD, *z2 = zs + (PS + col) * ZLD;
-                    float bsum = 0;
-                    for (int q = 0; q < Q; ++q) {
-                        const float d = z1[q] - z2[q];
-                        bsum += gq[q] * d * d;
+        for (int J = 0; J < 2; ++J) {
+            if (DIAG && J > I) continue;
+            const int col = 32 * J + (l & 31), mp = mp_base + col;
+            float z2[G::KQ], gg[G::KQ];
+#pragma unroll
+            for (int k = 0; k < G::KQ; ++k) {
+                z2[k] = zs[(PS + col) * ZLD + k];
+                gg[k] = gq[k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = wv + 4 * i, row = 32 * I + 8 * i + 4 * (l >> 5) + wv, m = m_base + row;
+                float sum = 0;
+#pragma unroll
+                for (int w_ = 0; w_ < 4; ++w_) sum += red[((w_ * 2 + J) * 16 + v) * 64 + l];
+                if (m < Mp && mp < Mp) {
+                    float val = 0;
+                    if (m < M && mp < M) {
+                        float bsum = 0;
+#pragma unroll
+                        for (int k = 0; k < G::KQ; ++k) {
+                            const float d = zs[row * ZLD + k] - z2[k];
+                            bsum += gg[k] * d * d;
+                        }
+                        val = al2 * sum * dpgp_exp2((float)(-0.25 * DPGP_LOG2E) * bsum);
                     }
-                    val = al2 * sum * dpgp_exp2((float)(-0.25 * DPGP_LOG2E) * bsum);
+                    out[(size_t)m * Mp + mp] = val;
                 }
-                out[(size_t)m * Mp + mp] = val;
             }
         }
     }
+    P2_MARK(6);
+    P2_WG(1);
 }
 
 template <typename TIN, int KB>
@@ -908,15 +1018,18 @@ __global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, in
                                                        const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                                        const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
                                                        float *__restrict__ part, int Mp, int n_per_split,
-                                                       ChainKTask task) {
+                                                       int n_splits, ChainKTask task) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int zoff = task.ws ? 1 : 0;
-    if (zoff && blockIdx.z == 0) {
-        chain_k_task(task, smem_raw);
+    const int nps = (Mp + 63) / 64;
+    int item;
+    if (psi2_task_1d(blockIdx.x, task.ws ? B : 0, task.last != 0, item)) {
+        chain_k_task(task, item, smem_raw);
         return;
     }
     int b, sp, pi, pj;
-    psi2_block_coords((Mp + 63) / 64, zoff, b, sp, pi, pj);
+    b = item % B;
+    sp = (item / B) % n_splits;
+    psi2_patch_coords(nps, item / (B * n_splits), pi, pj);
 #ifdef PSI2_P_VALU       // diagnostic build: P rows by the direct squared-distance form on the VALU
     if (pi == pj)
         psi2_patch_f16<TIN, KB, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
@@ -939,7 +1052,7 @@ __global__ __launch_bounds__(256) void psi2_mfma_kernel(int N, int M, int Q, int
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int zoff = task.ws ? 1 : 0;
     if (zoff && blockIdx.z == 0) {
-        chain_k_task(task, smem_raw);
+        if (blockIdx.y == 0) chain_k_task(task, blockIdx.x, smem_raw);
         return;
     }
     int b, sp, pi, pj;
@@ -1069,7 +1182,9 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
     const int Mp = dpgp_round_up(M, 16);
     const int nps = dpgp_ceil_div(Mp, 64);
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);      // 4 waves x 16-row chunks
-    dim3 grid(B, ns, nps * (nps + 1) / 2 + (task.ws ? 1 : 0));
+    const long long nwg = (long long)B * ns * (nps * (nps + 1) / 2) + (task.ws ? B : 0);   // see psi2_task_1d
+    if (nwg > 0x7fffffffLL) return -1;
+    dim3 grid((unsigned)nwg);
 #ifdef PSI2_P_VALU
     size_t lds = sizeof(float) * (size_t)Psi2F16Lds<KB>::ELEMS;
 #else
@@ -1082,7 +1197,7 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
                                 (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
     }
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper, task);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper, ns, task);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -1112,7 +1227,7 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,
                         double *logdet_k, int *info_k) {
     const int Mp = dpgp_round_up(M, 16);
-    ChainKTask task = {chain_ws, la_chain_ws_elems_inline(M), logdet_k, info_k, M, Mp, chain_elem};
+    ChainKTask task = {chain_ws, la_chain_ws_elems_inline(M), logdet_k, info_k, M, Mp, chain_elem, B >= 256 ? 1 : 0};
     if (algo == DPGP_ALGO_PLAIN && chain_ws) return -16;     // the plain path launches chain_k on its own
     if (algo == DPGP_ALGO_PLAIN) {
         // slabs 1.. are expected to exist by the consumer: zero them, slab 0 carries the result
