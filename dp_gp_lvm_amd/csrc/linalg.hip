@@ -124,16 +124,24 @@ __global__ __launch_bounds__(256) void chain_b_kernel(int D, int N, int M, int M
             }
         }
     }
-    for (int J = 0; J < nb; ++J) {                          // border tile-row: row 0 holds v^T
-        const int j = 16 * J + jj;
+    // border tile-row: row 0 holds v^T = sum of the ns1 partial Psi1^T y slabs (independent loads, 8 in flight: a serial
+    // loop over the slabs costs ~1 us of memory latency per slab, 20 us at ns1 = 16), rows 1..15 are zero
+    for (int e = t; e < 16 * Mp; e += 256) {
+        const int row = e / Mp, j = e - row * Mp;
         TL bv = 0;
-        if (ii == 0 && j < M) {
+        if (row == 0 && j < M) {
             double a = 0.0;
-            for (int k = 0; k < ns1; ++k) a += v_part[((size_t)k * D + d) * M + j];
+            for (int k0 = 0; k0 < ns1; k0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (k0 + k < ns1) ? v_part[((size_t)(k0 + k) * D + d) * M + j] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a += v[k];
+            }
             bv = (TL)a;
         }
-        if (mode == 0) tiles[lds_tile_index(nb, J, nb) * TSZ + ii * LDT + jj] = bv;
-        else Wb[(size_t)(Mp + ii) * Mp + j] = bv;
+        if (mode == 0) tiles[lds_tile_index(nb, j >> 4, nb) * TSZ + row * LDT + (j & 15)] = bv;
+        else Wb[(size_t)(Mp + row) * Mp + j] = bv;
     }
     ip = block_sum(ip, scratch);
     __syncthreads();
