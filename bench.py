@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--config', type=int, default=3, help='BASELINE.json config index (SURVEY.md 8d): 2,3,4,5')
     ap.add_argument('--prec', default='mixed', choices=['mixed', 'f32', 'f64'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the gram GB/s and Cholesky TFLOP/s side measurements')
     ap.add_argument('--cpu-dims', type=int, default=0, help='output dims in the bounded CPU sample (0 = auto)')
     return ap.parse_args()
 
@@ -62,6 +63,55 @@ def cpu_baseline(cfg, p, shape, dims):
                 sample='%d of %d output dims of config %d, all of N=%d M=%d Q=%d, fp64 C/OpenMP port of the reference '
                        'formulas (oracle/dpgp_oracle.c), median of 3 runs of %.2f s, scaled by D/dims'
                        % (dims, d, cfg, n, m, q, t))
+
+
+def secondary(dev, shape, p):
+    """The two kernel-level figures BASELINE.json names next to the headline metric, measured on their own (torch events on
+    the current stream, the one the operators launch on): HBM GB/s of the gram build (K_uu, fp64 as the mixed pipeline
+    writes it, plus one large fp32 gram that is not launch-bound) and TFLOP/s of the batched Cholesky (M^3/3 flops per
+    factorisation; fp64 as in the mixed pipeline; the workload's M and M = 512, the blocked-MFMA regime of config 4)."""
+    import torch
+    from dp_gp_lvm_amd import ops
+    n, d, m, q = shape
+    out = {}
+
+    def timed(fn, reps, setup=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for i in range(reps + 2):
+            if setup:
+                setup()
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            if i >= 2:
+                tot += e0.elapsed_time(e1)
+        return tot / reps
+
+    t64 = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev)
+    z, g, al, be = t64(p['z']), t64(p['gamma']), t64(p['alpha']), t64(p['beta'])
+    ms = timed(lambda: ops.ard_rbf_gram(z, None, g, al, be, include_jitter=True), 20)
+    byts = 8.0 * d * m * m
+    out['gram_kuu'] = {'kernel_ms': ms, 'bytes': byts, 'gbps': byts / ms / 1e6, 'peak_gbps': 8000.0,
+                       'frac': byts / ms / 1e6 / 8000.0, 'what': 'K_uu [D=%d,M=%d,M=%d] fp64 incl. operator call overhead' % (d, m, m)}
+    rng = np.random.default_rng(7)
+    x = torch.as_tensor(rng.standard_normal((4096, q)), dtype=torch.float32, device=dev)
+    g32, a32, b32 = g[:16].float().contiguous(), al[:16].float().contiguous(), be[:16].float().contiguous()
+    ms = timed(lambda: ops.ard_rbf_gram(x, None, g32, a32, b32), 10)
+    byts = 4.0 * 16 * 4096 * 4096
+    out['gram_large'] = {'kernel_ms': ms, 'bytes': byts, 'gbps': byts / ms / 1e6, 'peak_gbps': 8000.0,
+                         'frac': byts / ms / 1e6 / 8000.0, 'what': 'gram [16,4096,4096] fp32'}
+    for key, (bb, mm) in {'cholesky': (d, m), 'cholesky_m512': (64, 512)}.items():
+        a0 = torch.as_tensor(rng.standard_normal((bb, mm, mm)), dtype=torch.float64, device=dev)
+        spd = a0 @ a0.transpose(1, 2) + mm * torch.eye(mm, dtype=torch.float64, device=dev)
+        ms = timed(lambda: ops.potrf_batched(spd), 10)       # the operator factorises a copy of its argument
+        ms_copy = timed(lambda: spd.clone(), 10)
+        ms = max(ms - ms_copy, 1e-6)
+        fl = bb * mm ** 3 / 3.0
+        out[key] = {'kernel_ms': ms, 'flops': fl, 'tflops': fl / ms / 1e9, 'peak_tflops': 78.6, 'frac': fl / ms / 1e9 / 78.6,
+                    'what': 'dpgp_potrf_batched_f64 B=%d M=%d (M^3/3 flops each), copy of the input subtracted' % (bb, mm)}
+    return out
 
 
 def main():
@@ -164,6 +214,8 @@ def main():
                          'exp_per_s': exps / (psi2_ms * 1e-3), 'exp_peak_per_s': exp_peak,
                          'exp_frac': exps / (psi2_ms * 1e-3) / exp_peak},
         }
+        if world == 1 and not a.no_secondary:
+            res['secondary'] = secondary(dev, shape, p)
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(a.config, p, shape, a.cpu_dims)
         print(json.dumps(res))

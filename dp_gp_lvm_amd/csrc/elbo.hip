@@ -10,11 +10,11 @@
 #include "internal.h"
 
 struct ElboLayout {
-    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, off_kl, total;
+    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, off_kl, off_pc, total;
     int ns1, ns2, Mp;
 };
 
-static ElboLayout elbo_layout(int D, int N, int M, int prec) {
+static ElboLayout elbo_layout(int D, int N, int M, int Q, int prec) {
     ElboLayout L;
     L.Mp = dpgp_round_up(M, 16);
     L.ns1 = psi1T_y_nsplit(D, N, M);
@@ -25,6 +25,7 @@ static ElboLayout elbo_layout(int D, int N, int M, int prec) {
     L.off_ld = o; o += dpgp_align256(sizeof(double) * D);
     L.off_ik = o; o += dpgp_align256(sizeof(int) * D);
     L.off_kl = o; o += dpgp_align256(sizeof(double) * DPGP_KL_NBLK);
+    L.off_pc = o; o += dpgp_align256(psi2_consts_bytes(M, Q));
     L.off_v = o;  o += dpgp_align256(sizeof(double) * (size_t)L.ns1 * D * M);
     L.off_p2 = o; o += dpgp_align256(sp * (size_t)L.ns2 * D * L.Mp * L.Mp);
     L.off_la = o; o += dpgp_align256(sl * (size_t)D * la_chain_ws_elems(M));
@@ -34,7 +35,7 @@ static ElboLayout elbo_layout(int D, int N, int M, int prec) {
 
 extern "C" size_t dpgp_elbo_workspace_bytes(int D, int N, int M, int Q, int prec) {
     if (D <= 0 || N <= 0 || M <= 0 || Q <= 0 || prec < 0 || prec > 2) return 0;
-    return elbo_layout(D, N, M, prec).total;
+    return elbo_layout(D, N, M, Q, prec).total;
 }
 
 template <typename TP, typename TL>
@@ -49,12 +50,14 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     TP *p2 = reinterpret_cast<TP *>(ws + L.off_p2);
     TL *la = reinterpret_cast<TL *>(ws + L.off_la);
     double *klp = reinterpret_cast<double *>(ws + L.off_kl);
+    unsigned char *pconst = ws + L.off_pc;
     hipEvent_t ev0 = ex ? (hipEvent_t)ex->ev_psi2_begin : nullptr, ev1 = ex ? (hipEvent_t)ex->ev_psi2_end : nullptr;
     int rc;
     if ((rc = launch_gram<double, TL>(D, M, M, Q, z, nullptr, gamma, alpha, beta, DPGP_FLAG_JITTER, jitter, la, L.Mp,
                                       la_chain_ws_elems(M), st)))
         return rc;
-    if ((rc = launch_kl_yy<double>(N, Q, mu, s, klp, D, y, ldy, yy, st))) return rc;
+    // (the same launch builds the z-only constants of the f16 psi2 kernel)
+    if ((rc = launch_kl_yy<double>(N, Q, mu, s, klp, D, y, ldy, yy, z, M, pconst, st))) return rc;
     if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, st)))
         return rc;
     const bool fused_k = (algo != DPGP_ALGO_PLAIN);
@@ -63,7 +66,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     // psi2 on the matrix cores; the same dispatch carries, ahead of the psi2 workgroups, the D workgroups of the K_uu
     // branch (Cholesky, log-det, inverse of K_uu), which are latency-bound and overlap the psi2 work completely
     if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st,
-                                              fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik)))
+                                              fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst, 1)))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info, la, algo,
@@ -97,7 +100,7 @@ extern "C" int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, in
     if (!sums) return -17;
     if (!info) return -18;
     if (!ws) return -19;
-    const ElboLayout L = elbo_layout(D, N, M, prec);
+    const ElboLayout L = elbo_layout(D, N, M, Q, prec);
     if (ws_bytes < L.total) return -20;
     hipStream_t st = (hipStream_t)stream;
     unsigned char *w = (unsigned char *)ws;

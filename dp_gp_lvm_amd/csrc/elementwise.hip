@@ -1,6 +1,7 @@
 // ARD-RBF gram / diag / psi0 / psi1 / Psi1^T y / KL kernels (HBM- or exp-bound, no matrix cores needed).
 // Reference semantics: /root/reference/src/kernels/rbf_kernel.py:58-161, src/models/expressions/gp_expressions.py:10-24.
 #include "internal.h"
+#include "psi2_consts.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // K1  gram: out[b, i, j] = alpha_b exp(-1/2 sum_q gamma_bq (x0_iq - x1_jq)^2)  (+ noise/jitter on the diagonal)
@@ -474,14 +475,21 @@ __global__ void sum_slabs_kernel(size_t n, int ns, const double *__restrict__ pa
 //   blocks 0..DPGP_KL_NBLK-1 : KL partial sums -> kl_out[DPGP_KL_NBLK] (summed in fixed order by the consumer)
 //   other blocks : (64 consecutive d) x (one of YY_NCH chunks of n); coalesced along d, 4 waves stride over n, partial
 //                  sums written to yy_out[chunk][d] (DPGP_YY_NCH slabs, summed in fixed order by the consumer: deterministic)
+//   blocks >= first_consts_block (optional): 64 rows each of the psi2 kernel's z-only constants (psi2_consts.h)
 // ---------------------------------------------------------------------------------------------------------------
 #define YY_NCH DPGP_YY_NCH
 template <typename TIN>
 __global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__restrict__ mu,
                                                     const TIN *__restrict__ s, double *__restrict__ kl_out, int D,
-                                                    const TIN *__restrict__ y, int ldy, double *__restrict__ yy_out) {
-    __shared__ double scratch[4][64];
+                                                    const TIN *__restrict__ y, int ldy, double *__restrict__ yy_out,
+                                                    const TIN *__restrict__ z, int M, unsigned char *__restrict__ consts,
+                                                    int first_consts_block) {
+    __shared__ double scratch[5][64];
     const int t = threadIdx.x;
+    if ((int)blockIdx.x >= first_consts_block) {      // third role: z-only constants of the psi2 kernel (psi2_consts.h)
+        psi2_consts_rows(z, M, Q, consts, (int)blockIdx.x - first_consts_block, &scratch[0][0]);
+        return;
+    }
     if (blockIdx.x < DPGP_KL_NBLK) {      // KL partials: block k handles every DPGP_KL_NBLK-th run of 256 elements
         if (kl_out == nullptr) return;
         double a0 = 0.0;
@@ -517,19 +525,22 @@ __global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__r
 
 template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
-                 double *yy_out, hipStream_t st) {
+                 double *yy_out, const TIN *z, int M, unsigned char *psi2_consts, hipStream_t st) {
     int blocks = DPGP_KL_NBLK;
     if (yy_out) {
         blocks += dpgp_ceil_div(D, 64) * YY_NCH;
     }
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((kl_yy_kernel<TIN>), dim3(blocks), dim3(256), 0, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out);
+    const int first_consts = blocks;
+    if (psi2_consts) blocks += dpgp_ceil_div(M, 64);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((kl_yy_kernel<TIN>), dim3(blocks), dim3(256), 0, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out, z, M,
+                       psi2_consts, first_consts);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
 template int launch_kl_yy<float>(int, int, const float *, const float *, double *, int, const float *, int, double *,
-                                 hipStream_t);
+                                 const float *, int, unsigned char *, hipStream_t);
 template int launch_kl_yy<double>(int, int, const double *, const double *, double *, int, const double *, int,
-                                  double *, hipStream_t);
+                                  double *, const double *, int, unsigned char *, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI

@@ -20,7 +20,9 @@ int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *
 #define DPGP_KL_NBLK 16
 template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
-                 double *yy_out, hipStream_t st);
+                 double *yy_out, const TIN *z, int M, unsigned char *psi2_consts, hipStream_t st);
+// psi2_consts != nullptr: the same launch also builds the z-only constants of the f16 psi2 kernel (psi2_consts.h) from
+// z[M,Q] into psi2_consts (psi2_consts_bytes(M, Q) bytes)
 
 // ---- psi2.hip --------------------------------------------------------------------------------------------------
 // partial Psi2 slabs: part[ns][B][Mp][Mp] (type T), Mp = round_up(M,16); only the lower block-triangle (16x16 tiles,
@@ -29,10 +31,13 @@ int psi2_nsplit(int B, int N, int M);
 // chain_ws != nullptr (matrix-core algos only): the launch carries an extra slice of B workgroups in front of the psi2
 // workgroups that run the K_uu branch (chain_k_body, linalg_dev.h) on the per-output workspaces chain_ws (elements of
 // chain_elem = 4 or 8 bytes) -> logdet_k[B], info_k[B].
+// consts: psi2_consts_bytes(M, Q) bytes of workspace for the z-only constants of the f16 kernel; consts_ready != 0: they
+// were already built on this stream (launch_kl_yy), otherwise the launch builds them first.
+size_t psi2_consts_bytes(int M, int Q);
 template <typename TIN, typename T>
 int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,
-                        double *logdet_k, int *info_k);
+                        double *logdet_k, int *info_k, unsigned char *consts, int consts_ready);
 
 // ---- linalg.hip ------------------------------------------------------------------------------------------------
 // per-d workspace of the fused Cholesky chain, in elements of TL (layout: linalg.hip)

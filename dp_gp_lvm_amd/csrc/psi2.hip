@@ -17,8 +17,10 @@
 // 32x32 fp64); the 4 waves of a workgroup work on the SAME patch and split the n of every 32-row tile 4 ways
 // (identical work per wave, z operands shared), their accumulators are summed through LDS at the end.
 // Output: partial slabs part[split][b][Mp][Mp], lower block-triangle of 16x16 tiles only.
+#include <type_traits>
 #include "internal.h"
 #include "linalg_dev.h"
+#include "psi2_consts.h"
 
 #define PSI2_NT 32   // n per LDS tile
 
@@ -669,7 +671,8 @@ template <int KB> __host__ __device__ inline Psi2PLayout psi2p_layout(int Q) {
     L.SL = 32 * ((6 * Q + 2 + 31) / 32);                       // f16 slots per image row
     L.QS = G::KQ;                                              // row stride of the c' pieces (zero padded)
     L.off_bimg = 2 * G::PS * G::ZLD + 2 * (DPGP_MAX_Q + 2);
-    L.off_wave = L.off_bimg + 128 * L.SL / 2;
+    L.off_wave = L.off_bimg + (KB >= 5 ? 0 : 128 * L.SL / 2);  // many latent dims: the column image stays in global memory
+                                                               // (L2), with it in LDS only one workgroup fits a CU
     L.o_aimg = 16 * G::XLD;
     L.o_cq = L.o_aimg + 16 * L.SL / 2;
     L.o_pw = L.o_cq + 16 * L.QS;
@@ -680,7 +683,7 @@ template <int KB> __host__ __device__ inline Psi2PLayout psi2p_layout(int Q) {
 }
 
 template <typename TIN, int KB, bool DIAG>
-__device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, const TIN *__restrict__ z,
+__device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
                                                 const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                                 const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
                                                 float *__restrict__ part, int Mp, int n_per_split, int b, int sp,
@@ -708,29 +711,27 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
 #ifdef PSI2_PROFILE
     if (P2_ON) { g_psi2_stamps[2] = 0; g_psi2_stamps[3] = 0; g_psi2_stamps[4] = 0; }
 #endif
+    // ---- prologue: gamma of this output dim; the z-only constants (psi2_consts.h) are copied, not rebuilt ----
+    const Psi2Consts C = psi2_consts_layout(M, Q);           // C.ZLD == ZLD, C.SL == SL
+    const float *zs_g = reinterpret_cast<const float *>(consts + C.off_zs);
+    const _Float16 *bimg_g = reinterpret_cast<const _Float16 *>(consts + C.off_bimg);
     if (t < G::KQ) gq[t] = (t < Q) ? (float)gamma[(size_t)b * Q + t] : 0.0f;
-    block_column_means(z, M, Q, zc, reinterpret_cast<double *>(zs + L.off_wave));
-    for (int e = t; e < 2 * PS * ZLD; e += 256) {
-        int r = e / ZLD, k = e - r * ZLD;
-        int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
-        zs[e] = (k < Q && m < M) ? (float)z[(size_t)m * Q + k] - zc[k] : 0.0f;
+    if (t < 32) zc[t] = reinterpret_cast<const float *>(consts)[t];
+    for (int e = t; e < 2 * PS * (ZLD / 4); e += 256) {
+        const int r = e / (ZLD / 4), k4 = e - r * (ZLD / 4);
+        const int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
+        reinterpret_cast<f32x4 *>(zs)[e] = reinterpret_cast<const f32x4 *>(zs_g + (size_t)m * ZLD)[k4];
     }
-    for (int e = t; e < 128 * SL / 2; e += 256) reinterpret_cast<unsigned *>(bimg)[e] = 0u;
+    if (KB < 5) {
+        const int v16 = SL / 8;                              // 16-byte vectors per image row
+        for (int e = t; e < NCOL * v16; e += 256) {
+            const int c = e / v16, k = e - c * v16;
+            const int m = (c < PS) ? (m_base + c) : (mp_base + c - PS);
+            reinterpret_cast<dpgp_u4 *>(bimg)[e] = reinterpret_cast<const dpgp_u4 *>(bimg_g + (size_t)m * SL)[k];
+        }
+    }
     for (int e = lane; e < 16 * SL / 2; e += 64) reinterpret_cast<unsigned *>(aimg)[e] = 0u;
     if (lane < 2) pw[CONST_ONE + 32 * lane] = DPGP_H2_ONES;
-    __syncthreads();
-    for (int e = t; e < NCOL * 2 * Q; e += 256) {        // (column, term): z^2 and z, split, slots {h, l, h}
-        const int c = e / (2 * Q), tt = e - c * 2 * Q, q = tt >> 1;
-        const float zz = zs[c * ZLD + q];
-        const float v = (tt & 1) ? zz : zz * zz;
-        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
-        _Float16 *dst = bimg + c * SL + 3 * tt;
-        dst[0] = h; dst[1] = l; dst[2] = h;
-    }
-    for (int c = t; c < NCOL; c += 256) {
-        bimg[c * SL + 6 * Q] = (_Float16)1.0f;
-        bimg[c * SL + 6 * Q + 1] = (_Float16)1.0f;
-    }
     __syncthreads();
 
     // ---- per-lane constants of the exponent GEMM: 32x32x16 tiles, lane = (row li5, K-half k2), K-step ks holds the two
@@ -772,13 +773,17 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
 
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
     constexpr int NPA = (NR * XLD + 63) / 64;
-    TIN pf_s[NPA], pf_m[NPA];
+    // q(X) rows of the next chunk stay in flight in registers during this chunk.  Raw input type: a conversion here would
+    // wait for the loads on the spot (measured +70 us at config 3); only with many latent dims, where 256 VGPRs are short,
+    // they are narrowed to fp32 at once.
+    typedef typename std::conditional<(KB >= 5), float, TIN>::type PF;
+    PF pf_s[NPA], pf_m[NPA];
 #pragma unroll
     for (int u = 0; u < NPA; ++u) {
         const int e = 64 * u + lane, r = e / XLD, k = e - r * XLD, n = nbeg + wv + 4 * r;
         const bool ok = (e < NR * XLD) && (k < Q) && (n < nend);
-        pf_s[u] = ok ? s[(size_t)n * Q + k] : (TIN)1;
-        pf_m[u] = ok ? mu[(size_t)n * Q + k] : (TIN)0;
+        pf_s[u] = ok ? (PF)s[(size_t)n * Q + k] : (PF)1;
+        pf_m[u] = ok ? (PF)mu[(size_t)n * Q + k] : (PF)0;
     }
     P2_MARK(1);
     for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {
@@ -823,8 +828,8 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
         for (int u = 0; u < NPA; ++u) {      // next chunk's q(X) rows: in flight during the rest of this chunk
             const int e = 64 * u + lane, r = e / XLD, k = e - r * XLD, n = nc + 4 * NR + 4 * r;
             const bool ok = (e < NR * XLD) && (k < Q) && (n < nend);
-            pf_s[u] = ok ? s[(size_t)n * Q + k] : (TIN)1;
-            pf_m[u] = ok ? mu[(size_t)n * Q + k] : (TIN)0;
+            pf_s[u] = ok ? (PF)s[(size_t)n * Q + k] : (PF)1;
+            pf_m[u] = ok ? (PF)mu[(size_t)n * Q + k] : (PF)0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -852,6 +857,29 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
             f32x4 pc[NJ];
 #pragma unroll
             for (int J = 0; J < NJ; ++J) pc[J] = (f32x4){0, 0, 0, 0};
+            if constexpr (KB >= 5) {
+                // column image from global memory (L2 resident, shared by all workgroups), K-steps double buffered
+                auto bload = [&](dpgp_h8 (&bq)[NJ], int ks) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int J = 0; J < NJ; ++J) {
+                        const int m = (J < PS / 16) ? (m_base + 16 * J + li) : (mp_base + 16 * (J - PS / 16) + li);
+                        bq[J] = *reinterpret_cast<const dpgp_h8 *>(bimg_g + (size_t)m * SL + 32 * ks + 8 * kk);
+                    }
+                };
+                auto bmma = [&](const dpgp_h8 (&bq)[NJ], int ks) __attribute__((always_inline)) {
+                    const dpgp_h8 av = *reinterpret_cast<const dpgp_h8 *>(aimg + li * SL + 32 * ks + 8 * kk);
+#pragma unroll
+                    for (int J = 0; J < NJ; ++J) pc[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bq[J], pc[J], 0, 0, 0);
+                };
+                dpgp_h8 b0[NJ], b1[NJ];
+                bload(b0, 0);
+                for (int ks = 0; ks < kf1; ks += 2) {
+                    if (ks + 1 < kf1) bload(b1, ks + 1);
+                    bmma(b0, ks);
+                    if (ks + 2 < kf1) bload(b0, ks + 2);
+                    if (ks + 1 < kf1) bmma(b1, ks + 1);
+                }
+            } else
             for (int ks = 0; ks < kf1; ++ks) {       // K-step outermost: NJ independent accumulation chains in flight
                 const dpgp_h8 av = *reinterpret_cast<const dpgp_h8 *>(aimg + li * SL + 32 * ks + 8 * kk);
 #pragma unroll
@@ -924,6 +952,22 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
                 for (int v = 0; v < 16; ++v) a[v] += dpgp_exp2(c[v]);
                 __builtin_amdgcn_sched_barrier(0);
             };
+            if constexpr (KB >= 5) {
+                // many latent dims: the operand registers of two row tiles plus four result tiles no longer fit 256 VGPRs
+                // (the pipelined form spills ~200 dwords per chunk); one row tile at a time, results read right away
+#pragma unroll 1
+                for (int r = 0; r < NR; ++r) {
+                    load_row(r, spB);
+#pragma unroll
+                    for (int I = 0; I < 2; ++I) {
+                        split(I, a0);
+                        c0 = issue(a0, 0, spB);
+                        if (!(DIAG && I == 0)) c1 = issue(a0, 1, spB);
+                        expacc(acc[I][0], c0);
+                        if (!(DIAG && I == 0)) expacc(acc[I][1], c1);
+                    }
+                }
+            } else {
             load_row(0, spB);
             split(0, a0);
             split(1, a1);
@@ -951,6 +995,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
             if (!DIAG) expacc(acc[0][1], c1);
             expacc(acc[1][0], c2);
             expacc(acc[1][1], c3);
+            }
         }
 #endif
         P2_END(4);
@@ -1015,6 +1060,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
 
 template <typename TIN, int KB>
 __global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                                       const unsigned char *__restrict__ consts,
                                                        const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                                        const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
                                                        float *__restrict__ part, int Mp, int n_per_split,
@@ -1037,9 +1083,11 @@ __global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, in
         psi2_patch_f16<TIN, KB, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
 #else
     if (pi == pj)
-        psi2_patch_f16p<TIN, KB, true>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
+        psi2_patch_f16p<TIN, KB, true>(N, M, Q, B, consts, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj,
+                                        smem_raw);
     else
-        psi2_patch_f16p<TIN, KB, false>(N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj, smem_raw);
+        psi2_patch_f16p<TIN, KB, false>(N, M, Q, B, consts, mu, s, gamma, alpha, part, Mp, n_per_split, b, sp, pi, pj,
+                                        smem_raw);
 #endif
 }
 
@@ -1176,11 +1224,24 @@ static int launch_psi2_ks(int B, int N, int M, int Q, const TIN *z, const TIN *m
     return DPGP_OK;
 }
 
+template <typename TIN>
+__global__ __launch_bounds__(256) void psi2_consts_kernel(const TIN *__restrict__ z, int M, int Q, unsigned char *__restrict__ dst) {
+    __shared__ double scratch[5 * 64];
+    psi2_consts_rows(z, M, Q, dst, (int)blockIdx.x, scratch);
+}
+size_t psi2_consts_bytes(int M, int Q) { return psi2_consts_layout(M, Q).bytes; }
+
 template <typename TIN, int KB>
 static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                              const TIN *alpha, float *part, int ns, const ChainKTask &task, hipStream_t st) {
+                              const TIN *alpha, float *part, int ns, const ChainKTask &task, unsigned char *consts,
+                              int consts_ready, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16);
     const int nps = dpgp_ceil_div(Mp, 64);
+    if (!consts) return -18;
+    if (!consts_ready) {
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_consts_kernel<TIN>), dim3(dpgp_ceil_div(M, 64)), dim3(256), 0, st, z, M, Q, consts);
+        DPGP_LAUNCH_CHECK();
+    }
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);      // 4 waves x 16-row chunks
     const long long nwg = (long long)B * ns * (nps * (nps + 1) / 2) + (task.ws ? B : 0);   // see psi2_task_1d
     if (nwg > 0x7fffffffLL) return -1;
@@ -1197,7 +1258,8 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
                                 (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
     }
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, mu, s, gamma, alpha, part, Mp, nper, ns, task);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, N, M, Q, B, z, (const unsigned char *)consts, mu, s, gamma, alpha,
+                       part, Mp, nper, ns, task);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -1205,16 +1267,17 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
 // the f16-split kernel exists for fp32 results only
 template <typename TIN, typename T> struct Psi2F16Dispatch {
     static int run(int, int, int, int, const TIN *, const TIN *, const TIN *, const TIN *, const TIN *, T *, int,
-                   const ChainKTask &, hipStream_t) {
+                   const ChainKTask &, unsigned char *, int, hipStream_t) {
         return -13;
     }
 };
 template <typename TIN> struct Psi2F16Dispatch<TIN, float> {
     static int run(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                   const TIN *alpha, float *part, int ns, const ChainKTask &task, hipStream_t st) {
+                   const TIN *alpha, float *part, int ns, const ChainKTask &task, unsigned char *consts, int consts_ready,
+                   hipStream_t st) {
         switch (dpgp_ceil_div(Q, 4)) {
 #define CASE(k) \
-    case k: return launch_psi2_f16_kb<TIN, k>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, st);
+    case k: return launch_psi2_f16_kb<TIN, k>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, consts, consts_ready, st);
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         }
@@ -1225,7 +1288,7 @@ template <typename TIN> struct Psi2F16Dispatch<TIN, float> {
 template <typename TIN, typename T>
 int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,
-                        double *logdet_k, int *info_k) {
+                        double *logdet_k, int *info_k, unsigned char *consts, int consts_ready) {
     const int Mp = dpgp_round_up(M, 16);
     ChainKTask task = {chain_ws, la_chain_ws_elems_inline(M), logdet_k, info_k, M, Mp, chain_elem, B >= 256 ? 1 : 0};
     if (algo == DPGP_ALGO_PLAIN && chain_ws) return -16;     // the plain path launches chain_k on its own
@@ -1242,7 +1305,7 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
     }
     // fp32 results: f16-split operands on the matrix pipe unless the exact-fp32 MFMA kernel is asked for
     if (sizeof(T) == 4 && algo != DPGP_ALGO_MFMA_F32)
-        return Psi2F16Dispatch<TIN, T>::run(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, st);
+        return Psi2F16Dispatch<TIN, T>::run(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, consts, consts_ready, st);
     const int KS = dpgp_ceil_div(Q + 2, 4);
     switch (KS) {
 #define CASE(k) \
@@ -1254,13 +1317,13 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
 }
 template int launch_psi2_partial<float, float>(int, int, int, int, const float *, const float *, const float *,
                                                const float *, const float *, float *, int, int, hipStream_t, void *, int,
-                                               double *, int *);
+                                               double *, int *, unsigned char *, int);
 template int launch_psi2_partial<double, double>(int, int, int, int, const double *, const double *, const double *,
                                                  const double *, const double *, double *, int, int, hipStream_t, void *,
-                                                 int, double *, int *);
+                                                 int, double *, int *, unsigned char *, int);
 template int launch_psi2_partial<double, float>(int, int, int, int, const double *, const double *, const double *,
                                                 const double *, const double *, float *, int, int, hipStream_t, void *,
-                                                int, double *, int *);
+                                                int, double *, int *, unsigned char *, int);
 
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
@@ -1268,7 +1331,7 @@ template int launch_psi2_partial<double, float>(int, int, int, int, const double
 extern "C" size_t dpgp_psi2_workspace_bytes(int B, int N, int M, int Q, int elem_size) {
     if (B <= 0 || N <= 0 || M <= 0 || Q <= 0) return 0;
     int Mp = dpgp_round_up(M, 16);
-    return dpgp_align256((size_t)elem_size * psi2_nsplit(B, N, M) * B * Mp * Mp);
+    return dpgp_align256((size_t)elem_size * psi2_nsplit(B, N, M) * B * Mp * Mp) + psi2_consts_bytes(M, Q);
 }
 
 template <typename T>
@@ -1288,8 +1351,9 @@ static int psi2_api(int B, int N, int M, int Q, const T *z, const T *mu, const T
     if (ws_bytes < dpgp_psi2_workspace_bytes(B, N, M, Q, sizeof(T))) return -12;
     if (algo < 0 || algo > DPGP_ALGO_MFMA_F32) return -13;
     const int ns = psi2_nsplit(B, N, M), Mp = dpgp_round_up(M, 16);
+    unsigned char *consts = (unsigned char *)ws + dpgp_align256(sizeof(T) * (size_t)ns * B * Mp * Mp);
     int rc = launch_psi2_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, (T *)ws, ns, algo, (hipStream_t)stream,
-                                       nullptr, 0, nullptr, nullptr);
+                                       nullptr, 0, nullptr, nullptr, consts, 0);
     if (rc) return rc;
     size_t tot = (size_t)B * M * M;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_finish_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
