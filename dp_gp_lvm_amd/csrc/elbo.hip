@@ -58,7 +58,8 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
         return rc;
     // (the same launch builds the z-only constants of the f16 psi2 kernel)
     if ((rc = launch_kl_yy<double>(N, Q, mu, s, klp, D, y, ldy, yy, z, M, pconst, st))) return rc;
-    if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, st)))
+    if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1,
+                                                 st)))
         return rc;
     const bool fused_k = (algo != DPGP_ALGO_PLAIN);
     if (!fused_k && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, st))) return rc;

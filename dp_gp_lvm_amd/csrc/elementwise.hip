@@ -279,42 +279,41 @@ __global__ __launch_bounds__(256) void psi1T_y_kernel(int N, int M, int Q, int B
 // grid (ns, ceil(M/128), B); each wave takes every 4th 16-row tile of the split and owns a 2 KB LDS operand image.
 // ---------------------------------------------------------------------------------------------------------------
 typedef _Float16 p1_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 p1_h2 __attribute__((ext_vector_type(2)));
 typedef float p1_f4 __attribute__((ext_vector_type(4)));
 
 template <typename TIN, int KF1>
 __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
+                                                          const unsigned char *__restrict__ consts,
                                                           const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                                           const TIN *__restrict__ gamma,
                                                           const TIN *__restrict__ alpha, const TIN *__restrict__ y,
                                                           int ldy, double *__restrict__ part, int n_per_split) {
     constexpr int SL = 32 * KF1;                          // K slots (f16) per row of an operand image
+    constexpr int QP = 4 * ((32 * KF1 - 2) / 6 / 4 + 1);  // row stride of the per-(row,q) arrays: >= Q, multiple of 4
+    constexpr int QPC = QP < 32 ? QP : 32;                // (Q <= DPGP_MAX_Q = 30)
     __shared__ __align__(16) _Float16 bimg[128 * SL];     // m-side image of this 128-column chunk
     __shared__ __align__(16) _Float16 aimg[4][16 * SL];   // n-side image, one per wave
     __shared__ float yv[4][16];
-    __shared__ float zc[DPGP_MAX_Q + 2], gq[DPGP_MAX_Q + 2];
+    __shared__ float zc[32], gq[32];
     __shared__ __align__(16) float red[16][128];
     const int b = blockIdx.z, mc = blockIdx.y * 128, sp = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
-    if (t < Q) gq[t] = (float)gamma[(size_t)b * Q + t];
-    block_column_means(z, M, Q, zc, reinterpret_cast<double *>(&red[0][0]));
-    for (int e = t; e < 128 * SL; e += 256) bimg[e] = (_Float16)0.0f;
-    for (int e = t; e < 4 * 16 * SL; e += 256) (&aimg[0][0])[e] = (_Float16)0.0f;
-    __syncthreads();
-    for (int e = t; e < 128 * 2 * Q; e += 256) {          // (m, term)
-        const int m = e / (2 * Q), tt = e - m * 2 * Q, q = tt >> 1;
-        float v = 0.0f;
-        if (mc + m < M) {
-            const float zz = (float)z[(size_t)(mc + m) * Q + q] - zc[q];
-            v = (tt & 1) ? zz : zz * zz;
-        }
-        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
-        _Float16 *dst = bimg + m * SL + 3 * tt;
-        dst[0] = h; dst[1] = l; dst[2] = h;
+    // the z-only constants (column means, m-side image: the same image as the psi2 kernel's, psi2_consts.h) are copied
+    const Psi2Consts C = psi2_consts_layout(M, Q);        // C.SL == SL
+    const _Float16 *bimg_g = reinterpret_cast<const _Float16 *>(consts + C.off_bimg);
+    if (t < 32) {
+        gq[t] = (t < Q) ? (float)gamma[(size_t)b * Q + t] : 0.0f;
+        zc[t] = reinterpret_cast<const float *>(consts)[t];
     }
-    for (int m = t; m < 128; m += 256) {
-        bimg[m * SL + 6 * Q] = (_Float16)1.0f;
-        bimg[m * SL + 6 * Q + 1] = (_Float16)1.0f;
+    typedef unsigned p1_u4 __attribute__((ext_vector_type(4)));
+    for (int e = t; e < 128 * (SL / 8); e += 256) {       // 16-byte vectors; rows up to round_up(M, 64) exist
+        const int m = e / (SL / 8), k = e - m * (SL / 8);
+        p1_u4 v = {0u, 0u, 0u, 0u};
+        if (mc + m < C.Mp64) v = reinterpret_cast<const p1_u4 *>(bimg_g + (size_t)(mc + m) * SL)[k];
+        reinterpret_cast<p1_u4 *>(bimg)[e] = v;
     }
+    for (int e = t; e < 4 * 16 * SL / 2; e += 256) reinterpret_cast<unsigned *>(&aimg[0][0])[e] = 0u;
     __syncthreads();
     // m-side operands of this lane: 8 column tiles x KF1 K-steps, resident in registers
     p1_h8 bop[8][KF1];
@@ -329,15 +328,16 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
     _Float16 *am = &aimg[wv][0];
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
     // q(X) rows and y of a 16-row tile are fetched one tile ahead (registers), so that their global-load latency overlaps
-    // the previous tile's MFMA / exp work; the per-row constant c_n is reduced from per-(row,q) pieces through LDS.
-    constexpr int NPF = (16 * DPGP_MAX_Q + 63) / 64;
-    float *cq = &red[wv * 4][0];                          // [16][Q] scratch of this wave (red is only used at the very end)
+    // the previous tile's MFMA / exp work; the per-row constant c_n is reduced from per-(row,q) pieces through LDS
+    // (element e of a tile = (row e / QPC, latent dim e % QPC), zero padded: vector reads, no division by Q).
+    constexpr int NPF = (16 * QPC + 63) / 64;
+    float *cq = &red[wv * 4][0];                          // [16][QPC] scratch of this wave (red is only used at the very end)
     TIN pf_s[NPF], pf_m[NPF], pf_y = (TIN)0;
     auto prefetch = [&](int n0) {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
-            const int e = 64 * u + lane, r = e / Q, q = e - r * Q, n = n0 + r;
-            const bool ok = (e < 16 * Q) && (n < nend);
+            const int e = 64 * u + lane, r = e / QPC, q = e - r * QPC, n = n0 + r;
+            const bool ok = (e < 16 * QPC) && (q < Q) && (n < nend);
             pf_s[u] = ok ? s[(size_t)n * Q + q] : (TIN)1;
             pf_m[u] = ok ? mu[(size_t)n * Q + q] : (TIN)0;
         }
@@ -349,20 +349,25 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const int e = 64 * u + lane;
-            if (e < 16 * Q) {
-                const int r = e / Q, q = e - r * Q, n = n0 + r;
+            if (e < 16 * QPC) {
+                const int r = e / QPC, q = e - r * QPC, n = n0 + r;
                 float a = 0.0f, bb = 0.0f, cc = 0.0f;
-                if (n < nend) {
-                    const float g = gq[q], den = g * (float)pf_s[u] + 1.0f;
-                    const float w1 = g / den, mcq = (float)pf_m[u] - zc[q];
-                    a = (float)(-0.5 * DPGP_LOG2E) * w1;
-                    bb = (float)DPGP_LOG2E * w1 * mcq;
-                    cc = w1 * mcq * mcq + dpgp_log(den);
+                if (q < Q) {
+                    if (n < nend) {
+                        const float g = gq[q], den = g * (float)pf_s[u] + 1.0f;
+                        const float w1 = g / den, mcq = (float)pf_m[u] - zc[q];
+                        a = (float)(-0.5 * DPGP_LOG2E) * w1;
+                        bb = (float)DPGP_LOG2E * w1 * mcq;
+                        cc = w1 * mcq * mcq + dpgp_log(den);
+                    }
+                    const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
+                    const _Float16 bh = (_Float16)bb, bl = (_Float16)(bb - (float)bh);
+                    unsigned *dst = reinterpret_cast<unsigned *>(am + r * SL + 6 * q);      // slots {ah, ah, al, bh, bh, bl}
+                    const p1_h2 w0 = {ah, ah}, w1_ = {al, bh}, w2 = {bh, bl};
+                    dst[0] = __builtin_bit_cast(unsigned, w0);
+                    dst[1] = __builtin_bit_cast(unsigned, w1_);
+                    dst[2] = __builtin_bit_cast(unsigned, w2);
                 }
-                const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
-                const _Float16 bh = (_Float16)bb, bl = (_Float16)(bb - (float)bh);
-                _Float16 *dst = am + r * SL + 6 * q;
-                dst[0] = ah; dst[1] = ah; dst[2] = al; dst[3] = bh; dst[4] = bh; dst[5] = bl;
                 cq[e] = cc;
             }
         }
@@ -373,11 +378,15 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < 16) {
             float c = 0.0f;
-            for (int q = 0; q < Q; ++q) c += cq[lane * Q + q];
+#pragma unroll
+            for (int q4 = 0; q4 < QPC / 4; ++q4) {
+                const p1_f4 v = *reinterpret_cast<const p1_f4 *>(cq + lane * QPC + 4 * q4);
+                c += (v[0] + v[1]) + (v[2] + v[3]);
+            }
             c = fmaxf((float)(-0.5 * DPGP_LOG2E) * c, -60000.0f);
             const _Float16 ch = (_Float16)c;
-            am[lane * SL + 6 * Q] = ch;
-            am[lane * SL + 6 * Q + 1] = (_Float16)(c - (float)ch);
+            const p1_h2 cw = {ch, (_Float16)(c - (float)ch)};
+            *reinterpret_cast<unsigned *>(am + lane * SL + 6 * Q) = __builtin_bit_cast(unsigned, cw);
             yv[wv][lane] = yn;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -389,17 +398,21 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
         float y4[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) y4[v] = yv[wv][4 * kk + v];
+        p1_f4 c[8];
 #pragma unroll
-        for (int J = 0; J < 8; ++J) {
-            p1_f4 c = {0, 0, 0, 0};
+        for (int J = 0; J < 8; ++J) c[J] = (p1_f4){0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < KF1; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop[ks], bop[J][ks], c, 0, 0, 0);
+        for (int ks = 0; ks < KF1; ++ks)                    // K-step outermost: 8 independent accumulation chains in flight
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[J] = fmaf(y4[v], dpgp_exp2(c[v]), acc[J]);
-        }
+            for (int J = 0; J < 8; ++J) c[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop[ks], bop[J][ks], c[J], 0, 0, 0);
+#pragma unroll
+        for (int J = 0; J < 8; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[J] = fmaf(y4[v], dpgp_exp2(c[J][v]), acc[J]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next tile overwrites the image just read
     }
     // ---- sum the 4 row groups of each wave and the 4 waves ----
+    __syncthreads();                                        // cq aliases red
 #pragma unroll
     for (int J = 0; J < 8; ++J) red[wv * 4 + kk][16 * J + li] = acc[J];
     __syncthreads();
@@ -414,11 +427,11 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
 template <typename TIN, int KF1>
 static int launch_psi1T_y_f16_kf(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s,
                                  const TIN *gamma, const TIN *alpha, const TIN *y, int ldy, double *part, int ns,
-                                 hipStream_t st) {
+                                 const unsigned char *consts, hipStream_t st) {
     int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);
     dim3 grid(ns, dpgp_ceil_div(M, 128), B);
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1T_y_f16_kernel<TIN, KF1>), grid, dim3(256), 0, st, N, M, Q, B, z, mu, s, gamma, alpha, y, ldy,
-                       part, nper);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1T_y_f16_kernel<TIN, KF1>), grid, dim3(256), 0, st, N, M, Q, B, z, consts, mu, s, gamma, alpha, y,
+                       ldy, part, nper);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -433,11 +446,17 @@ int psi1T_y_nsplit(int B, int N, int M) {
 
 template <typename TIN, typename T>
 int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                           const TIN *alpha, const TIN *y, int ldy, double *part, int ns, hipStream_t st) {
+                           const TIN *alpha, const TIN *y, int ldy, double *part, int ns, unsigned char *consts,
+                           int consts_ready, hipStream_t st) {
     if (sizeof(T) == 4) {        // fp32 results: f16-split operands on the matrix pipe
+        if (!consts) return -18;
+        if (!consts_ready) {
+            int rc = launch_psi2_consts<TIN>(z, M, Q, consts, st);
+            if (rc) return rc;
+        }
         switch (dpgp_ceil_div(6 * Q + 2, 32)) {
 #define CASE(k) \
-    case k: return launch_psi1T_y_f16_kf<TIN, k>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, part, ns, st);
+    case k: return launch_psi1T_y_f16_kf<TIN, k>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, part, ns, consts, st);
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
 #undef CASE
         }
@@ -452,13 +471,13 @@ int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *
 }
 template int launch_psi1T_y_partial<float, float>(int, int, int, int, const float *, const float *, const float *,
                                                   const float *, const float *, const float *, int, double *, int,
-                                                  hipStream_t);
+                                                  unsigned char *, int, hipStream_t);
 template int launch_psi1T_y_partial<double, double>(int, int, int, int, const double *, const double *, const double *,
                                                     const double *, const double *, const double *, int, double *, int,
-                                                    hipStream_t);
+                                                    unsigned char *, int, hipStream_t);
 template int launch_psi1T_y_partial<double, float>(int, int, int, int, const double *, const double *, const double *,
                                                    const double *, const double *, const double *, int, double *, int,
-                                                   hipStream_t);
+                                                   unsigned char *, int, hipStream_t);
 
 template <typename T>
 __global__ void sum_slabs_kernel(size_t n, int ns, const double *__restrict__ part, T *__restrict__ out) {
@@ -625,7 +644,8 @@ extern "C" int dpgp_psi1_f64(int B, int N, int M, int Q, const double *z, const 
 
 extern "C" size_t dpgp_psi1T_y_workspace_bytes(int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return dpgp_align256(sizeof(double) * (size_t)psi1T_y_nsplit(B, N, M) * B * M);
+    // partial slabs + the z-only operand constants of the f16 kernel (sized for the largest Q: no Q in this signature)
+    return dpgp_align256(sizeof(double) * (size_t)psi1T_y_nsplit(B, N, M) * B * M) + psi2_consts_bytes(M, DPGP_MAX_Q);
 }
 template <typename T>
 static int psi1T_y_api(int B, int N, int M, int Q, const T *z, const T *mu, const T *s, const T *gamma, const T *alpha,
@@ -635,7 +655,8 @@ static int psi1T_y_api(int B, int N, int M, int Q, const T *z, const T *mu, cons
     CHECK_ARG(ldy >= B, 11); CHECK_ARG(out, 12); CHECK_ARG(ws, 13);
     CHECK_ARG(ws_bytes >= dpgp_psi1T_y_workspace_bytes(B, N, M), 14);
     int ns = psi1T_y_nsplit(B, N, M);
-    int rc = launch_psi1T_y_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, (double *)ws, ns,
+    unsigned char *consts = (unsigned char *)ws + dpgp_align256(sizeof(double) * (size_t)ns * B * M);
+    int rc = launch_psi1T_y_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, y, ldy, (double *)ws, ns, consts, 0,
                                           (hipStream_t)stream);
     if (rc) return rc;
     size_t tot = (size_t)B * M;

@@ -13,7 +13,8 @@ int launch_gram(int B, int N0, int N1, int Q, const TIN *x0, const TIN *x1, cons
 int psi1T_y_nsplit(int B, int N, int M);
 template <typename TIN, typename T>
 int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
-                           const TIN *alpha, const TIN *y, int ldy, double *part, int ns, hipStream_t st);
+                           const TIN *alpha, const TIN *y, int ldy, double *part, int ns, unsigned char *psi2_consts,
+                           int consts_ready, hipStream_t st);   // consts: as for launch_psi2_partial (f16 kernel only)
 
 // yy_out: DPGP_YY_NCH partial slabs [DPGP_YY_NCH][D];  kl_out: DPGP_KL_NBLK partial sums (their total is 2 KL + N Q)
 #define DPGP_YY_NCH 16
@@ -34,6 +35,7 @@ int psi2_nsplit(int B, int N, int M);
 // consts: psi2_consts_bytes(M, Q) bytes of workspace for the z-only constants of the f16 kernel; consts_ready != 0: they
 // were already built on this stream (launch_kl_yy), otherwise the launch builds them first.
 size_t psi2_consts_bytes(int M, int Q);
+template <typename TIN> int launch_psi2_consts(const TIN *z, int M, int Q, unsigned char *consts, hipStream_t st);
 template <typename TIN, typename T>
 int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,

@@ -23,6 +23,9 @@
 #include "psi2_consts.h"
 
 #define PSI2_NT 32   // n per LDS tile
+#ifndef PSI2_PF_NARROW_KB
+#define PSI2_PF_NARROW_KB 5   // from this many groups of 4 latent dims on, the prefetched q(X) rows are held as fp32
+#endif
 
 // Optional extra task slice in front of the psi2 workgroups (blockIdx.z == 0): the K_uu branch of the ELBO
 // (chain_k_body of linalg_dev.h: Cholesky, log-det and inverse of K_uu for output dim blockIdx.x).  It is part of the SAME
@@ -776,7 +779,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
     // q(X) rows of the next chunk stay in flight in registers during this chunk.  Raw input type: a conversion here would
     // wait for the loads on the spot (measured +70 us at config 3); only with many latent dims, where 256 VGPRs are short,
     // they are narrowed to fp32 at once.
-    typedef typename std::conditional<(KB >= 5), float, TIN>::type PF;
+    typedef typename std::conditional<(KB >= PSI2_PF_NARROW_KB), float, TIN>::type PF;
     PF pf_s[NPA], pf_m[NPA];
 #pragma unroll
     for (int u = 0; u < NPA; ++u) {
@@ -1230,6 +1233,13 @@ __global__ __launch_bounds__(256) void psi2_consts_kernel(const TIN *__restrict_
     psi2_consts_rows(z, M, Q, dst, (int)blockIdx.x, scratch);
 }
 size_t psi2_consts_bytes(int M, int Q) { return psi2_consts_layout(M, Q).bytes; }
+template <typename TIN> int launch_psi2_consts(const TIN *z, int M, int Q, unsigned char *consts, hipStream_t st) {
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_consts_kernel<TIN>), dim3(dpgp_ceil_div(M, 64)), dim3(256), 0, st, z, M, Q, consts);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+template int launch_psi2_consts<float>(const float *, int, int, unsigned char *, hipStream_t);
+template int launch_psi2_consts<double>(const double *, int, int, unsigned char *, hipStream_t);
 
 template <typename TIN, int KB>
 static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
@@ -1239,8 +1249,8 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
     const int nps = dpgp_ceil_div(Mp, 64);
     if (!consts) return -18;
     if (!consts_ready) {
-        DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_consts_kernel<TIN>), dim3(dpgp_ceil_div(M, 64)), dim3(256), 0, st, z, M, Q, consts);
-        DPGP_LAUNCH_CHECK();
+        const int rc = launch_psi2_consts<TIN>(z, M, Q, consts, st);
+        if (rc) return rc;
     }
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);      // 4 waves x 16-row chunks
     const long long nwg = (long long)B * ns * (nps * (nps + 1) / 2) + (task.ws ? B : 0);   // see psi2_task_1d
