@@ -190,7 +190,7 @@ static size_t chain_b_lds_bytes(int Mp, size_t elem) {   // LDS-resident B: dinv
 template <typename TL>
 int launch_chain_k(int D, int M, TL *ws, double *logdet_k, int *info_k, int algo, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16);
-    size_t lds = la_lds_bytes(Mp, sizeof(TL));
+    size_t lds = chain_k_lds_bytes(Mp, sizeof(TL));
     auto kern = chain_k_kernel<TL>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

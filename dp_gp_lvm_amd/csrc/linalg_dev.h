@@ -294,11 +294,12 @@ __device__ __forceinline__ int lds_tile_index(int I, int J, int nbf) {
 static inline int lds_tile_count(int nbf, int nbr) { return nbf * (nbf + 1) / 2 + (nbr - nbf) * nbf; }
 
 // tiles: LDS array of TSZ-element tiles; dinv: one more LDS tile.  On exit the tiles hold L (and the solved border rows).
+// dinv_glob (optional): [nbf][256] global array that receives the inverted diagonal tiles.
 template <typename T>
-__device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail) {
+__device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail, T *dinv_glob = nullptr) {
     typedef typename Mfma<T>::acc_t acc_t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
-    if (wv == 0) diag_tile<T, true, true>(tiles, LDT, dinv, (T *)nullptr, fail, 0);
+    if (wv == 0) diag_tile<T, true, true>(tiles, LDT, dinv, dinv_glob, fail, 0);
     __syncthreads();
     for (int k = 0; k < nbf; ++k) {
         // panel: P_I = A_Ik * Linv_kk^T, in place
@@ -330,7 +331,8 @@ __device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 ACC_BEGIN();
-                diag_tile<T, true, true>(tile, LDT, dinv, (T *)nullptr, fail, 16 * (k + 1));
+                diag_tile<T, true, true>(tile, LDT, dinv, dinv_glob ? dinv_glob + (k + 1) * 256 : (T *)nullptr, fail,
+                                         16 * (k + 1));
                 ACC_END(4);
             }
         } else {
@@ -354,6 +356,88 @@ __device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail) {
                 }
             }
             ACC_END(6);
+        }
+        __syncthreads();
+    }
+}
+
+// In-place inverse of the LDS-resident Cholesky factor: tiles (lower, nb x nb) hold L on entry and the lower triangle of
+// (L L^T)^-1 = L^-T L^-1 on exit.  dinv_glob: the inverted diagonal tiles saved by potrf_lds; dinv: one LDS tile.
+//   1. W = L^-1 row by row (rows above already hold W):  L'_ik = Linv_ii L_ik (k < i);  W_ij = delta_ij Linv_ii -
+//      sum_{k=j}^{i-1} L'_ik W_kj, collected in registers and written once the whole row has been read;
+//   2. out_ij = sum_{k >= i} W_ki^T W_kj row by row (row i of W is not read again by later rows).
+// Every product is the tile primitive C += X Y^T of Mfma<T>::mma on 16x16 LDS tiles (Y read transposed where needed).
+template <typename T>
+__device__ void potri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {
+    typedef typename Mfma<T>::acc_t acc_t;
+    constexpr int MAXT = 3;                                   // tiles of one row per wave: nb <= 12
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
+    for (int i = 0; i < nb; ++i) {
+        dinv[(t >> 4) * LDT + (t & 15)] = dinv_glob[i * 256 + t];
+        __syncthreads();
+        for (int k = wv; k < i; k += 4) {                     // L'_ik = Linv_ii L_ik, in place
+            T *tile = tiles + lds_tile_index(i, k, nb) * TSZ;
+            acc_t c = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) c = Mfma<T>::mma(dinv[li * LDT + 4 * ks + kk], tile[(4 * ks + kk) * LDT + li], c);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
+        }
+        __syncthreads();
+        acc_t cw[MAXT];
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int j = wv + 4 * u;
+            if (j > i) continue;
+            acc_t c = {0, 0, 0, 0};
+            if (j == i) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) c[v] = dinv[Mfma<T>::row(lane, v) * LDT + li];
+            } else {
+                for (int k = j; k < i; ++k) {
+                    const T *lt = tiles + lds_tile_index(i, k, nb) * TSZ, *wt = tiles + lds_tile_index(k, j, nb) * TSZ;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        c = Mfma<T>::mma(-lt[li * LDT + 4 * ks + kk], wt[(4 * ks + kk) * LDT + li], c);
+                }
+            }
+            cw[u] = c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int j = wv + 4 * u;
+            if (j > i) continue;
+            T *tile = tiles + lds_tile_index(i, j, nb) * TSZ;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = cw[u][v];
+        }
+        __syncthreads();
+    }
+    // diagonal tiles of W carry garbage above the diagonal? no: Linv_ii is lower triangular with explicit zeros (diag_tile)
+    for (int i = 0; i < nb; ++i) {
+        acc_t cw[MAXT];
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int j = wv + 4 * u;
+            if (j > i) continue;
+            acc_t c = {0, 0, 0, 0};
+            for (int k = i; k < nb; ++k) {
+                const T *wi = tiles + lds_tile_index(k, i, nb) * TSZ, *wj = tiles + lds_tile_index(k, j, nb) * TSZ;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    c = Mfma<T>::mma(wi[(4 * ks + kk) * LDT + li], wj[(4 * ks + kk) * LDT + li], c);
+            }
+            cw[u] = c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int j = wv + 4 * u;
+            if (j > i) continue;
+            T *tile = tiles + lds_tile_index(i, j, nb) * TSZ;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = cw[u][v];
         }
         __syncthreads();
     }
@@ -389,6 +473,19 @@ static inline size_t la_chain_ws_elems_inline(int M) {
 static inline size_t la_lds_bytes(int Mp, size_t elem) {     // global-memory blocked routines: dinv + one panel of nb+1 tiles
     return LA_LDS_HDR + elem * (size_t)TSZ * (size_t)(Mp / 16 + 2);
 }
+// chain_k keeps K_uu in LDS (dinv + the lower-triangle tiles) when that leaves room for two workgroups per CU next to
+// the psi2 workgroups of the same dispatch (80 KB each) and a row of tiles fits the per-wave register arrays of potri_lds
+#define LA_CHAIN_K_LDS_MAX (80 * 1024)
+__host__ __device__ inline size_t chain_k_resident_bytes(int Mp, size_t elem) {
+    const int nb = Mp / 16;
+    return LA_LDS_HDR + elem * (size_t)TSZ * (size_t)(1 + nb * (nb + 1) / 2);
+}
+__host__ __device__ inline bool chain_k_resident(int Mp, size_t elem) {
+    return Mp / 16 <= 12 && chain_k_resident_bytes(Mp, elem) <= LA_CHAIN_K_LDS_MAX;
+}
+static inline size_t chain_k_lds_bytes(int Mp, size_t elem) {
+    return chain_k_resident(Mp, elem) ? chain_k_resident_bytes(Mp, elem) : la_lds_bytes(Mp, elem);
+}
 
 // ---- chain_k: everything that depends on K_uu only (dp_gp_lvm.py:115-116) for output dim d; one 256-thread workgroup.
 // smem_raw: >= la_lds_bytes(Mp) bytes of (dynamic) LDS.  Called from chain_k_kernel and, as an extra task slice, from the
@@ -403,6 +500,52 @@ __device__ void chain_k_body(int d, int M, int Mp, TL *__restrict__ ws, size_t w
     TL *K0 = ws + (size_t)d * ws_stride, *Kb = K0 + (size_t)Mp * Mp, *Wb = Kb + (size_t)Mp * Mp,
        *KI = Wb + (size_t)(Mp + 16) * Mp, *dinv = KI + (size_t)Mp * Mp;
     if (t == 0) fail = 0;
+    if (!plain && chain_k_resident(Mp, sizeof(TL))) {
+        // ---- LDS-resident: K_uu -> LDS, Cholesky, log-det, in-place inverse, K_uu^-1 -> KI; no other global traffic ----
+        typedef TL tl4 __attribute__((ext_vector_type(4)));
+        TL *dl = lds, *tiles = lds + TSZ;
+        const int nlow = nb * (nb + 1) / 2;
+        const int u = t >> 6, r = (t & 63) >> 2, c4 = (t & 3) * 4;
+        for (int t0 = 0; t0 < nlow; t0 += 4) {                // 4 tiles per pass: thread = (tile, row, 4 columns)
+            const int tt = t0 + u;
+            if (tt >= nlow) continue;
+            int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+            while (I * (I + 1) / 2 > tt) --I;
+            const int J = tt - I * (I + 1) / 2, i = 16 * I + r, j = 16 * J + c4;
+            const tl4 k0 = *reinterpret_cast<const tl4 *>(K0 + (size_t)i * Mp + j);
+            TL *dst = tiles + lds_tile_index(I, J, nb) * TSZ + r * LDT + c4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = (i < M && j + e < M) ? k0[e] : ((i == j + e) ? (TL)1 : (TL)0);
+        }
+        __syncthreads();
+        potrf_lds<TL>(tiles, dl, nb, nb, &fail, dinv);
+        __syncthreads();
+        double ld = 0.0;
+        for (int i = t; i < M; i += 256) ld += log((double)tiles[lds_tile_index(i >> 4, i >> 4, nb) * TSZ + (i & 15) * LDT + (i & 15)]);
+        ld = block_sum(ld, scratch);
+        if (t == 0) {
+            logdet_k[d] = ld;
+            info_k[d] = fail;
+        }
+        __threadfence_block();
+        __syncthreads();                                       // dinv (global) written by wave 0 is read by all waves below
+        potri_lds<TL>(tiles, dl, dinv, nb);
+        for (int t0 = 0; t0 < nlow; t0 += 4) {
+            const int tt = t0 + u;
+            if (tt >= nlow) continue;
+            int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+            while (I * (I + 1) / 2 > tt) --I;
+            const int J = tt - I * (I + 1) / 2, i = 16 * I + r, j = 16 * J + c4;
+            const TL *src = tiles + lds_tile_index(I, J, nb) * TSZ + r * LDT + c4;
+            tl4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = src[e];
+            *reinterpret_cast<tl4 *>(KI + (size_t)i * Mp + j) = v;
+        }
+        return;
+    }
     for (int e = t; e < Mp * Mp; e += 256) {
         const int i = e / Mp, j = e - i * Mp;
         Kb[e] = (i < M && j < M) ? K0[e] : ((i == j) ? (TL)1 : (TL)0);

@@ -1215,7 +1215,7 @@ static int launch_psi2_ks(int B, int N, int M, int Q, const TIN *z, const TIN *m
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), PSI2_NT);
     dim3 grid(B, ns, nps * (nps + 1) / 2 + (task.ws ? 1 : 0));
     size_t lds = psi2_lds_bytes<T, KS>();
-    if (task.ws && la_lds_bytes(task.Mp, task.elem) > lds) lds = la_lds_bytes(task.Mp, task.elem);
+    if (task.ws && chain_k_lds_bytes(task.Mp, task.elem) > lds) lds = chain_k_lds_bytes(task.Mp, task.elem);
     auto kern = psi2_mfma_kernel<TIN, T, KS, PT>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1261,7 +1261,7 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
 #else
     size_t lds = sizeof(float) * (size_t)psi2p_layout<KB>(Q).elems;
 #endif
-    if (task.ws && la_lds_bytes(task.Mp, task.elem) > lds) lds = la_lds_bytes(task.Mp, task.elem);
+    if (task.ws && chain_k_lds_bytes(task.Mp, task.elem) > lds) lds = chain_k_lds_bytes(task.Mp, task.elem);
     auto kern = psi2_f16_kernel<TIN, KB>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
