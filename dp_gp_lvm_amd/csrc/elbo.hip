@@ -61,7 +61,10 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1,
                                                  st)))
         return rc;
-    const bool fused_k = (algo != DPGP_ALGO_PLAIN);
+    // the K_uu branch rides in the psi2 dispatch when it is LDS-resident (or the exact-MFMA psi2 kernel runs, which carries
+    // both forms); otherwise it is a launch of its own ahead of psi2
+    const bool f16_psi2 = (sizeof(TP) == 4 && algo != DPGP_ALGO_MFMA_F32);
+    const bool fused_k = (algo != DPGP_ALGO_PLAIN) && (!f16_psi2 || la_chain_k_resident(M, (int)sizeof(TL)));
     if (!fused_k && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, st))) return rc;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     // psi2 on the matrix cores; the same dispatch carries, ahead of the psi2 workgroups, the D workgroups of the K_uu

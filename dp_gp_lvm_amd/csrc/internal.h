@@ -44,6 +44,8 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
 // ---- linalg.hip ------------------------------------------------------------------------------------------------
 // per-d workspace of the fused Cholesky chain, in elements of TL (layout: linalg.hip)
 size_t la_chain_ws_elems(int M);
+// true if the K_uu branch of an M x M problem with elem-byte elements runs LDS-resident (and may ride in the f16 psi2 dispatch)
+bool la_chain_k_resident(int M, int elem);
 // everything that depends on K_uu only (may overlap the psi2 kernel on another stream)
 template <typename TL>
 int launch_chain_k(int D, int M, TL *ws, double *logdet_k, int *info_k, int algo, hipStream_t st);

@@ -39,6 +39,7 @@ extern "C" void dpgp_debug_stamps(long long *out) { (void)hipMemcpyFromSymbol(ou
 //   dinv [Mp/16][256] : inverted diagonal tiles of L_uu
 // ---------------------------------------------------------------------------------------------------------------
 size_t la_chain_ws_elems(int M) { return la_chain_ws_elems_inline(M); }
+bool la_chain_k_resident(int M, int elem) { return chain_k_resident(dpgp_round_up(M, 16), (size_t)elem); }
 
 // ---- chain_k as a kernel of its own (plain cross-check path and callers without a psi2 launch) ----------------------
 template <typename TL>
@@ -46,13 +47,16 @@ __global__ __launch_bounds__(256) void chain_k_kernel(int M, int Mp, TL *__restr
                                                       double *__restrict__ logdet_k, int *__restrict__ info_k,
                                                       int plain) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    chain_k_body<TL>(blockIdx.x, M, Mp, ws, ws_stride, logdet_k, info_k, plain, smem_raw);
+    chain_k_body<TL, 1>(blockIdx.x, M, Mp, ws, ws_stride, logdet_k, info_k, plain, smem_raw);
 }
 
 // ---- chain_b: everything after Psi2 (dp_gp_lvm.py:118-145 in the B = K + beta Psi2 form) -----------------------------
 // mode 0: B lives in LDS (potrf_lds); mode 1: B in global memory (Wb), blocked MFMA; mode 2: plain VALU cross-check.
-template <typename TP, typename TL>
-__global__ __launch_bounds__(256) void chain_b_kernel(int D, int N, int M, int Mp, const TP *__restrict__ psi2_part,
+// OCC = 2: bounded to 256 VGPRs so that two workgroups share a compute unit (more output dims than compute units: one round
+// instead of two); OCC = 1: all 512 registers for the single resident workgroup (the fp64 diagonal tile spills at 256,
+// measured +8 us per factorisation).
+template <typename TP, typename TL, int OCC>
+__global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, int Mp, const TP *__restrict__ psi2_part,
                                                       int ns2, const double *__restrict__ v_part, int ns1,
                                                       const double *__restrict__ alpha,
                                                       const double *__restrict__ beta,
@@ -140,16 +144,22 @@ __global__ __launch_bounds__(256) void chain_b_kernel(int D, int N, int M, int M
             }
             bv = (TL)a;
         }
-        if (mode == 0) tiles[lds_tile_index(nb, j >> 4, nb) * TSZ + row * LDT + (j & 15)] = bv;
-        else Wb[(size_t)(Mp + row) * Mp + j] = bv;
+        if (mode == 0) {
+            if (row == 0) tiles[(size_t)nlow * TSZ + (j >> 4) * LDT + (j & 15)] = bv;     // border vector (linalg_dev.h)
+        } else {
+            Wb[(size_t)(Mp + row) * Mp + j] = bv;
+        }
     }
     ip = block_sum(ip, scratch);
     __syncthreads();
     STAMP(1);
     // ---- L_B = chol(B), border -> L_B^-1 v ----
-    if (mode == 0) potrf_lds<TL>(tiles, dinv, nb, nb + 1, &fail);
-    else if (mode == 1) potrf_blocked<TL>(Wb, Mp, nb, nb + 1, dinv, (TL *)nullptr, &fail, 0);
-    else potrf_plain<TL>(Wb, Mp, Mp, Mp + 1, &fail, 0);
+    if (mode == 0) {
+        potrf_lds<TL, OCC>(tiles, dinv, nb, nb + 1, &fail);
+    } else if constexpr (OCC == 1) {        // (the 2-per-CU instantiation is only launched LDS-resident: keep the global-memory
+        if (mode == 1) potrf_blocked<TL>(Wb, Mp, nb, nb + 1, dinv, (TL *)nullptr, &fail, 0);   // routines' registers out of it)
+        else potrf_plain<TL>(Wb, Mp, Mp, Mp + 1, &fail, 0);
+    }
     __syncthreads();
     STAMP(2);
     double ld = 0.0, cc = 0.0;
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void chain_b_kernel(int D, int N, int M, int M
         const int I = i >> 4, r = i & 15;
         const double lii = mode == 0 ? (double)tiles[lds_tile_index(I, I, nb) * TSZ + r * LDT + r]
                                      : (double)Wb[(size_t)i * Mp + i];
-        const double c = mode == 0 ? (double)tiles[lds_tile_index(nb, I, nb) * TSZ + r] : (double)Wb[(size_t)Mp * Mp + i];
+        const double c = mode == 0 ? (double)tiles[(size_t)nlow * TSZ + I * LDT + r] : (double)Wb[(size_t)Mp * Mp + i];
         ld += log(lii);
         cc += c * c;
     }
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256) void chain_b_kernel(int D, int N, int M, int M
 
 static size_t chain_b_lds_bytes(int Mp, size_t elem) {   // LDS-resident B: dinv + lower triangle + border row
     const int nb = Mp / 16;
-    return LA_LDS_HDR + elem * (size_t)TSZ * (size_t)(1 + lds_tile_count(nb, nb + 1));
+    return LA_LDS_HDR + elem * lds_chol_elems(nb, 1);
 }
 
 template <typename TL>
@@ -216,7 +226,9 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
         mode = need <= LA_LDS_LIMIT ? 0 : 1;
         if (mode == 0) lds = need;
     }
-    auto kern = chain_b_kernel<TP, TL>;
+    // 2 workgroups per CU pay off once there are more output dims than CUs (and only fit with the LDS-resident 80 KB form)
+    const bool two = (mode == 0) && D > 256 && lds <= 80 * 1024;
+    auto kern = two ? chain_b_kernel<TP, TL, 2> : chain_b_kernel<TP, TL, 1>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
@@ -226,6 +238,16 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
+#ifdef DPGP_PROFILE_CHAIN
+extern "C" int dpgp_debug_chain_b_occupancy(int Mp, int extra) {
+    int nb = 0;
+    const size_t lds = chain_b_lds_bytes(Mp, 8) + extra;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_b_kernel<float, double, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_b_kernel<float, double, 2>, 256, lds);
+    return nb * 1000000 + (int)lds;
+}
+#endif
 #define INST_CHAIN_B(TP, TL)                                                                                        \
     template int launch_chain_b<TP, TL>(int, int, int, const TP *, int, const double *, int, const double *,      \
                                         const double *, const double *, const double *, const int *, double *, int *, \

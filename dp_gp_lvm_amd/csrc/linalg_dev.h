@@ -286,31 +286,47 @@ template <typename T> __device__ void trsm_right_plain(const T *L, int ldl, T *X
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// LDS-resident blocked Cholesky: lower-triangle tiles (I,J), J <= I < nbf, then (nbr - nbf) border tile-rows of nbf tiles.
+// LDS-resident blocked Cholesky: lower-triangle tiles (I,J), J <= I < nbf, followed by (nbr - nbf) border VECTORS: one row of
+// nbf * LDT elements each (border vector b, tile column J at b[J * LDT .. J * LDT + 15]).  A border vector rides through the
+// factorisation as row 0 of an otherwise zero tile row (on exit it holds L^-1 v), but only that row is stored: with a full
+// tile row the 128 x 128 fp64 case needs 90 KB of LDS and only one workgroup fits a compute unit; this way it is 80 KB.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_tile_index(int I, int J, int nbf) {
-    return I < nbf ? I * (I + 1) / 2 + J : nbf * (nbf + 1) / 2 + (I - nbf) * nbf + J;
+__device__ __forceinline__ int lds_tile_index(int I, int J, int nbf) { return I * (I + 1) / 2 + J; }     // J <= I < nbf
+static inline size_t lds_chol_elems(int nbf, int nborder) {      // dinv tile + lower tiles + border vectors
+    return (size_t)TSZ * (size_t)(1 + nbf * (nbf + 1) / 2) + (size_t)nborder * nbf * LDT;
 }
-static inline int lds_tile_count(int nbf, int nbr) { return nbf * (nbf + 1) / 2 + (nbr - nbf) * nbf; }
 
-// tiles: LDS array of TSZ-element tiles; dinv: one more LDS tile.  On exit the tiles hold L (and the solved border rows).
-// dinv_glob (optional): [nbf][256] global array that receives the inverted diagonal tiles.
-template <typename T>
+// tiles: LDS array of TSZ-element tiles followed by the border vectors; dinv: one more LDS tile.  On exit the tiles hold L
+// and the border vectors L^-1 v.  dinv_glob (optional): [nbf][256] global array that receives the inverted diagonal tiles.
+// OCC only separates instantiations: a kernel bounded to 2 workgroups per CU (256 VGPRs) must not share this function's
+// register allocation with an unbounded one (the fp64 diagonal tile wants ~330 registers and spills when held to 256).
+template <typename T, int OCC = 1>
 __device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail, T *dinv_glob = nullptr) {
     typedef typename Mfma<T>::acc_t acc_t;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
+    T *border = tiles + (size_t)(nbf * (nbf + 1) / 2) * TSZ;
     if (wv == 0) diag_tile<T, true, true>(tiles, LDT, dinv, dinv_glob, fail, 0);
     __syncthreads();
     for (int k = 0; k < nbf; ++k) {
         // panel: P_I = A_Ik * Linv_kk^T, in place
         { ACC_BEGIN();
         for (int I = k + 1 + wv; I < nbr; I += 4) {
-            T *tile = tiles + lds_tile_index(I, k, nbf) * TSZ;
             acc_t c = {0, 0, 0, 0};
+            if (I < nbf) {
+                T *tile = tiles + lds_tile_index(I, k, nbf) * TSZ;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) c = Mfma<T>::mma(tile[li * LDT + 4 * ks + kk], dinv[li * LDT + 4 * ks + kk], c);
+                for (int ks = 0; ks < 4; ++ks) c = Mfma<T>::mma(tile[li * LDT + 4 * ks + kk], dinv[li * LDT + 4 * ks + kk], c);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
+                for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
+            } else {
+                T *bk = border + ((I - nbf) * nbf + k) * LDT;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    c = Mfma<T>::mma(li == 0 ? bk[4 * ks + kk] : (T)0, dinv[li * LDT + 4 * ks + kk], c);
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (Mfma<T>::row(lane, v) == 0) bk[li] = c[v];
+            }
         }
         ACC_END(5); }
         __syncthreads();
@@ -343,16 +359,30 @@ __device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail, T *din
                 for (int J = k + 1; J <= jmax; ++J) {
                     if (I == k + 1 && J == k + 1) continue;
                     if ((cnt++ % 3) != wv - 1) continue;
-                    T *tile = tiles + lds_tile_index(I, J, nbf) * TSZ;
-                    const T *pI = tiles + lds_tile_index(I, k, nbf) * TSZ, *pJ = tiles + lds_tile_index(J, k, nbf) * TSZ;
+                    const T *pJ = tiles + lds_tile_index(J, k, nbf) * TSZ;
                     acc_t c;
+                    if (I < nbf) {
+                        T *tile = tiles + lds_tile_index(I, J, nbf) * TSZ;
+                        const T *pI = tiles + lds_tile_index(I, k, nbf) * TSZ;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) c[v] = tile[Mfma<T>::row(lane, v) * LDT + li];
+                        for (int v = 0; v < 4; ++v) c[v] = tile[Mfma<T>::row(lane, v) * LDT + li];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        c = Mfma<T>::mma(-pI[li * LDT + 4 * ks + kk], pJ[li * LDT + 4 * ks + kk], c);
+                        for (int ks = 0; ks < 4; ++ks)
+                            c = Mfma<T>::mma(-pI[li * LDT + 4 * ks + kk], pJ[li * LDT + 4 * ks + kk], c);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
+                        for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
+                    } else {
+                        T *bJ = border + ((I - nbf) * nbf + J) * LDT;
+                        const T *bk = border + ((I - nbf) * nbf + k) * LDT;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) c[v] = (Mfma<T>::row(lane, v) == 0) ? bJ[li] : (T)0;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            c = Mfma<T>::mma(li == 0 ? -bk[4 * ks + kk] : (T)0, pJ[li * LDT + 4 * ks + kk], c);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (Mfma<T>::row(lane, v) == 0) bJ[li] = c[v];
+                    }
                 }
             }
             ACC_END(6);
@@ -490,7 +520,7 @@ static inline size_t chain_k_lds_bytes(int Mp, size_t elem) {
 // ---- chain_k: everything that depends on K_uu only (dp_gp_lvm.py:115-116) for output dim d; one 256-thread workgroup.
 // smem_raw: >= la_lds_bytes(Mp) bytes of (dynamic) LDS.  Called from chain_k_kernel and, as an extra task slice, from the
 // psi2 kernels (so that it is dispatched together with — in front of — the psi2 workgroups and overlaps them).
-template <typename TL>
+template <typename TL, int OCC>      // OCC: see potrf_lds
 __device__ void chain_k_body(int d, int M, int Mp, TL *__restrict__ ws, size_t ws_stride, double *__restrict__ logdet_k,
                              int *__restrict__ info_k, int plain, unsigned char *smem_raw) {
     double *scratch = reinterpret_cast<double *>(smem_raw);
@@ -519,7 +549,7 @@ __device__ void chain_k_body(int d, int M, int Mp, TL *__restrict__ ws, size_t w
             for (int e = 0; e < 4; ++e) dst[e] = (i < M && j + e < M) ? k0[e] : ((i == j + e) ? (TL)1 : (TL)0);
         }
         __syncthreads();
-        potrf_lds<TL>(tiles, dl, nb, nb, &fail, dinv);
+        potrf_lds<TL, OCC>(tiles, dl, nb, nb, &fail, dinv);
         __syncthreads();
         double ld = 0.0;
         for (int i = t; i < M; i += 256) ld += log((double)tiles[lds_tile_index(i >> 4, i >> 4, nb) * TSZ + (i & 15) * LDT + (i & 15)]);
@@ -546,6 +576,9 @@ __device__ void chain_k_body(int d, int M, int Mp, TL *__restrict__ ws, size_t w
         }
         return;
     }
+    // the copy that rides in the 2-per-CU psi2 kernel is only ever launched for the LDS-resident case (the host checks
+    // chain_k_resident): keeping the global-memory routines out of it keeps their registers out of that kernel's budget
+    if constexpr (OCC == 2) return;
     for (int e = t; e < Mp * Mp; e += 256) {
         const int i = e / Mp, j = e - i * Mp;
         Kb[e] = (i < M && j < M) ? K0[e] : ((i == j) ? (TL)1 : (TL)0);

@@ -39,11 +39,14 @@ struct ChainKTask {
     int M, Mp, elem;     // elem = 4 (float) or 8 (double)
     int last;            // f16 kernel: tasks at the end of the grid instead of in front (see psi2_task_1d)
 };
-__device__ __attribute__((noinline)) void chain_k_task(const ChainKTask &tk, int d, unsigned char *smem_raw) {
+// OCC separates the instantiations by the launch bound of the calling kernel (the compiler derives the register budget of
+// a device function from its callers; one shared copy would take the loosest bound and push the f16 kernel past 256 VGPRs)
+template <int OCC>
+__device__ __attribute__((always_inline, flatten)) void chain_k_task(const ChainKTask &tk, int d, unsigned char *smem_raw) {
     if (tk.elem == 8)
-        chain_k_body<double>(d, tk.M, tk.Mp, (double *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
+        chain_k_body<double, OCC>(d, tk.M, tk.Mp, (double *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
     else
-        chain_k_body<float>(d, tk.M, tk.Mp, (float *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
+        chain_k_body<float, OCC>(d, tk.M, tk.Mp, (float *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
 }
 
 // Workgroup coordinates.  grid = (B, n-splits, patches); the patch index is the SLOWEST dimension and enumerates the
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__(256, PSI2_F16_WAVES) void psi2_f16_kernel(int N, in
     const int nps = (Mp + 63) / 64;
     int item;
     if (psi2_task_1d(blockIdx.x, task.ws ? B : 0, task.last != 0, item)) {
-        chain_k_task(task, item, smem_raw);
+        chain_k_task<2>(task, item, smem_raw);
         return;
     }
     int b, sp, pi, pj;
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(256) void psi2_mfma_kernel(int N, int M, int Q, int
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int zoff = task.ws ? 1 : 0;
     if (zoff && blockIdx.z == 0) {
-        if (blockIdx.y == 0) chain_k_task(task, blockIdx.x, smem_raw);
+        if (blockIdx.y == 0) chain_k_task<1>(task, blockIdx.x, smem_raw);
         return;
     }
     int b, sp, pi, pj;
@@ -1248,6 +1251,7 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
     const int Mp = dpgp_round_up(M, 16);
     const int nps = dpgp_ceil_div(Mp, 64);
     if (!consts) return -18;
+    if (task.ws && !chain_k_resident(task.Mp, task.elem)) return -16;    // (callers fuse only the LDS-resident K_uu branch)
     if (!consts_ready) {
         const int rc = launch_psi2_consts<TIN>(z, M, Q, consts, st);
         if (rc) return rc;
