@@ -52,9 +52,10 @@ __global__ __launch_bounds__(256) void chain_k_kernel(int M, int Mp, TL *__restr
 
 // ---- chain_b: everything after Psi2 (dp_gp_lvm.py:118-145 in the B = K + beta Psi2 form) -----------------------------
 // mode 0: B lives in LDS (potrf_lds); mode 1: B in global memory (Wb), blocked MFMA; mode 2: plain VALU cross-check.
-// OCC = 2: bounded to 256 VGPRs so that two workgroups share a compute unit (more output dims than compute units: one round
-// instead of two); OCC = 1: all 512 registers for the single resident workgroup (the fp64 diagonal tile spills at 256,
-// measured +8 us per factorisation).
+// OCC = 2: bounded to 256 VGPRs so that two workgroups share a compute unit (D = 512: one round instead of two, 135 -> 71 us);
+// launched whenever B is LDS-resident within 80 KB.  It is also the better compile for a single round (D = 64: 69 -> 62 us;
+// the unbounded instantiation of the fp64 diagonal tile takes 328 registers AND spills more).  OCC = 1 carries the
+// global-memory and plain fallbacks.
 template <typename TP, typename TL, int OCC>
 __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, int Mp, const TP *__restrict__ psi2_part,
                                                       int ns2, const double *__restrict__ v_part, int ns1,
@@ -226,8 +227,7 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
         mode = need <= LA_LDS_LIMIT ? 0 : 1;
         if (mode == 0) lds = need;
     }
-    // 2 workgroups per CU pay off once there are more output dims than CUs (and only fit with the LDS-resident 80 KB form)
-    const bool two = (mode == 0) && D > 256 && lds <= 80 * 1024;
+    const bool two = (mode == 0) && lds <= 80 * 1024;
     auto kern = two ? chain_b_kernel<TP, TL, 2> : chain_b_kernel<TP, TL, 1>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
