@@ -27,6 +27,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (spec), gfx950
+MFMA_F16_PEAK_TFLOPS = 2516.6    # same guide: ~2.5 PF dense f16/bf16 (256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz)
 
 
 def parse():
@@ -187,11 +188,21 @@ def main():
         exps = d_loc * n * m * (m + 1) // 2
         flops = exps * (4 * q + 2)
         achieved = flops / (psi2_ms * 1e-3) / 1e12
-        # HBM traffic of one psi2 dispatch (incl. its K_uu task slice: 20 MB psi2 + ~0.78 GB Cholesky workspaces) from the
-        # rocprofv3 PMC passes committed under profiles/r01 (FETCH_SIZE + WRITE_SIZE,
-        # KiB -> bytes; config 3, mixed precision, 1 GPU); null for every other configuration (not profiled)
-        traffic = 8.0e8 if (a.config == 3 and a.prec == 'mixed' and world == 1) else None
+        # HBM traffic of one psi2 dispatch (incl. its K_uu task slice, now LDS-resident) from the rocprofv3 PMC passes
+        # committed under profiles/r01 (FETCH_SIZE 25318 + WRITE_SIZE 67616, KiB -> bytes; config 3, mixed precision,
+        # 1 GPU); null for every other configuration (not profiled)
+        traffic = 95.2e6 if (a.config == 3 and a.prec == 'mixed' and world == 1) else None
         exp_peak = 256 * 4 * 8 * 2.4e9        # v_exp_f32: 64 lanes / 8 cycles per SIMD, 1024 SIMDs, 2.4 GHz
+        # measured issue floor of the hot loop (profiles/r01/ubench_psi2_row_mix_floor.txt: the per-row instruction mix of
+        # a 64 x 64 patch -- 64 v_exp_f32, 32 v_pk_add_f32, 12 MFMA 32x32x16 f16, 30 split, 16 v_mov -- issues in 1209
+        # cycles per row and SIMD with two waves per SIMD, Q <= 12): rows x patches (a diagonal patch has 3 of 4 tiles)
+        floor_ms = None
+        if q <= 12 and a.prec != 'f64':
+            np64 = (m + 63) // 64
+            tile_rows = d_loc * n * (np64 * (np64 - 1) // 2 * 1.0 + np64 * 0.75)
+            floor_ms = tile_rows * 1209.0 / (256 * 4) / 2.4e9 * 1e3
+        f16_path = a.prec != 'f64'
+        peak = MFMA_F16_PEAK_TFLOPS if f16_path else 78.6
         res = {
             'metric': 'ELBO evals/sec (N=%d,D=%d,M=%d,Q=%d)' % (n, d, m, q),
             'value': a.steps / elapsed, 'unit': 'ELBO evals/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -203,16 +214,20 @@ def main():
                        'parallelism': 'D sharded over %d GPU(s), %d output dims per GPU' % (world, d_loc),
                        'precision': a.prec},
             'objective': float(objs[0]),
-            # dominant kernel: psi2 (+ the K_uu Cholesky task slice that rides in the same dispatch).  `achieved` =
-            # ALGORITHMIC fp32 flops (N M(M+1)/2 exponents x (4Q+2) flops per output dim) / HIP-event duration;
-            # `peak` = dense fp32 matrix peak.  The kernel computes the exponent GEMM with 6(Q+2)/... f16 products on the
-            # f16 matrix pipe and is limited by v_exp_f32 + VALU issue, see `limiter` and DESIGN.md section 4.
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic,
-                         'kernel': 'psi2_f16_kernel' if a.prec != 'f64' else 'psi2_mfma_kernel', 'kernel_ms': psi2_ms,
+            # dominant kernel: psi2 (+ the K_uu task slice that rides in the same dispatch).  `achieved` = ALGORITHMIC flops
+            # (N M(M+1)/2 exponents x (4Q+2) flops per output dim) / HIP-event duration; `peak` = dense peak of
+            # the matrix pipe the kernel runs on (f16 operands, fp32 accumulate; fp64 MFMA for --prec f64).  The matrix pipe
+            # is not what limits it: every exponent costs one v_exp_f32 (8 issue cycles per wave) + one accumulate, see
+            # `exp_frac` (vs the v_exp_f32 rate alone) and `issue_floor_frac` (vs the measured issue rate of the loop's
+            # whole instruction mix) and DESIGN.md section 4.
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic,
+                         'kernel': 'psi2_f16_kernel' if f16_path else 'psi2_mfma_kernel', 'kernel_ms': psi2_ms,
                          'limiter': 'VALU issue (v_exp_f32 + accumulate + operand split), not the matrix pipe',
+                         'vs_fp32_matrix_peak': achieved / MFMA_F32_PEAK_TFLOPS,
                          'exp_per_s': exps / (psi2_ms * 1e-3), 'exp_peak_per_s': exp_peak,
-                         'exp_frac': exps / (psi2_ms * 1e-3) / exp_peak},
+                         'exp_frac': exps / (psi2_ms * 1e-3) / exp_peak,
+                         'issue_floor_ms': floor_ms, 'issue_floor_frac': (floor_ms / psi2_ms) if floor_ms else None},
         }
         if world == 1 and not a.no_secondary:
             res['secondary'] = secondary(dev, shape, p)
