@@ -103,7 +103,7 @@ def secondary(dev, shape, p):
     byts = 4.0 * 16 * 4096 * 4096
     out['gram_large'] = {'kernel_ms': ms, 'bytes': byts, 'gbps': byts / ms / 1e6, 'peak_gbps': 8000.0,
                          'frac': byts / ms / 1e6 / 8000.0, 'what': 'gram [16,4096,4096] fp32'}
-    for key, (bb, mm) in {'cholesky': (d, m), 'cholesky_m512': (64, 512)}.items():
+    for key, (bb, mm) in {'cholesky': (d, m), 'cholesky_m512': (256, 512)}.items():     # (config 4: D = 256, M = 512)
         a0 = torch.as_tensor(rng.standard_normal((bb, mm, mm)), dtype=torch.float64, device=dev)
         spd = a0 @ a0.transpose(1, 2) + mm * torch.eye(mm, dtype=torch.float64, device=dev)
         ms = timed(lambda: ops.potrf_batched(spd), 10)       # the operator factorises a copy of its argument

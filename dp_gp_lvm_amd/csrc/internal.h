@@ -59,4 +59,8 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
 //   given, out[0..4] = {objective, f_hat, KL, DP objective, hyper-prior} (single-GPU finalisation) in the same launch
 int launch_sum_terms(int D, const double *terms, const double *kl_part, double *sums, const double *model_scal,
                      double *model_pack, double *model_out, hipStream_t st);
+// ---- potrf_big.hip: batched Cholesky spread over the whole GPU for matrices that do not fit one workgroup's LDS -------
+// a[B][M][M] in/out (lower, zeros above), info[B], ws: potrf_big_ws_elems(B, M) elements of T
+size_t potrf_big_ws_elems(int B, int M);
+template <typename T> int launch_potrf_big(int B, int M, T *a, int *info, T *ws, hipStream_t st);
 #define DPGP_PREP_ROWS 16   // output dims per row-block of dpgp_model_prepare (scal has 2 + ceil(D / 16) entries)

@@ -329,6 +329,34 @@ __global__ __launch_bounds__(256) void potrf_batched_kernel(int M, int Mp, T *__
     if (t == 0) info[b] = fail;
 }
 
+// LDS-resident form of the stand-alone batched potrf (matrices whose lower triangle fits 80 KB: M <= 128 in fp64): tiles
+// in, potrf_lds, tiles out; no workspace traffic, two workgroups per compute unit.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void potrf_batched_lds_kernel(int M, int Mp, T *__restrict__ a, int *__restrict__ info) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    int &fail = *reinterpret_cast<int *>(smem_raw + 64);
+    T *dinv = reinterpret_cast<T *>(smem_raw + LA_LDS_HDR), *tiles = dinv + TSZ;
+    const int b = blockIdx.x, t = threadIdx.x, nb = Mp / 16, nlow = nb * (nb + 1) / 2;
+    T *A = a + (size_t)b * M * M;
+    if (t == 0) fail = 0;
+    for (int e = t; e < nlow * 256; e += 256) {               // (tile, row, column): consecutive threads along a row
+        const int tt = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+        while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+        while (I * (I + 1) / 2 > tt) --I;
+        const int J = tt - I * (I + 1) / 2, i = 16 * I + r, j = 16 * J + c;
+        tiles[tt * TSZ + r * LDT + c] = (i < M && j < M) ? A[(size_t)i * M + j] : ((i == j) ? (T)1 : (T)0);
+    }
+    __syncthreads();
+    potrf_lds<T, 2>(tiles, dinv, nb, nb, &fail);
+    __syncthreads();
+    for (int e = t; e < M * M; e += 256) {
+        const int i = e / M, j = e - i * M;
+        A[e] = (j <= i) ? tiles[lds_tile_index(i >> 4, j >> 4, nb) * TSZ + (i & 15) * LDT + (j & 15)] : (T)0;
+    }
+    if (t == 0) info[b] = fail;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void trsm_batched_kernel(int M, int K, int Mp, int Kp, const T *__restrict__ l,
                                                            T *__restrict__ rhs, T *__restrict__ ws, int plain) {
@@ -368,7 +396,9 @@ __global__ __launch_bounds__(256) void trsm_batched_kernel(int M, int K, int Mp,
 extern "C" size_t dpgp_potrf_workspace_bytes(int B, int M, int elem_size) {
     if (B <= 0 || M <= 0) return 0;
     const int Mp = dpgp_round_up(M, 16);
-    return dpgp_align256((size_t)elem_size * B * Mp * Mp);
+    size_t elems = (size_t)B * Mp * Mp;                                         // single-workgroup routine
+    if (potrf_big_ws_elems(B, M) > elems) elems = potrf_big_ws_elems(B, M);     // multi-workgroup routine (large M)
+    return dpgp_align256((size_t)elem_size * elems);
 }
 extern "C" size_t dpgp_trsm_workspace_bytes(int B, int M, int K, int elem_size) {
     if (B <= 0 || M <= 0 || K <= 0) return 0;
@@ -386,6 +416,18 @@ static int potrf_api(int B, int M, T *a, int *info, void *ws, size_t ws_bytes, i
     if (ws_bytes < dpgp_potrf_workspace_bytes(B, M, sizeof(T))) return -6;
     if (algo < 0 || algo > DPGP_ALGO_MFMA_F32) return -7;
     const int Mp = dpgp_round_up(M, 16);
+    if (algo != DPGP_ALGO_PLAIN && chain_k_resident(Mp, sizeof(T))) {
+        const size_t lds = chain_k_resident_bytes(Mp, sizeof(T));
+        auto kern = potrf_batched_lds_kernel<T>;
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                hipSuccess)
+            return DPGP_ERR_LAUNCH;
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, M, Mp, a, info);
+        DPGP_LAUNCH_CHECK();
+        return DPGP_OK;
+    }
+    if (algo != DPGP_ALGO_PLAIN) return launch_potrf_big<T>(B, M, a, info, (T *)ws, (hipStream_t)stream);
     size_t lds = la_lds_bytes(Mp, sizeof(T));
     auto kern = potrf_batched_kernel<T>;
     if (lds > 48 * 1024 &&

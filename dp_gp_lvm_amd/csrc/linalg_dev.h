@@ -398,7 +398,7 @@ __device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail, T *din
 //   2. out_ij = sum_{k >= i} W_ki^T W_kj row by row (row i of W is not read again by later rows).
 // Every product is the tile primitive C += X Y^T of Mfma<T>::mma on 16x16 LDS tiles (Y read transposed where needed).
 template <typename T>
-__device__ void potri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {
+__device__ void trtri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {       // step 1 alone: tiles <- L^-1
     typedef typename Mfma<T>::acc_t acc_t;
     constexpr int MAXT = 3;                                   // tiles of one row per wave: nb <= 12
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
@@ -444,7 +444,14 @@ __device__ void potri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {
         }
         __syncthreads();
     }
-    // diagonal tiles of W carry garbage above the diagonal? no: Linv_ii is lower triangular with explicit zeros (diag_tile)
+}
+template <typename T>
+__device__ void potri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {
+    typedef typename Mfma<T>::acc_t acc_t;
+    constexpr int MAXT = 3;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
+    trtri_lds<T>(tiles, dinv, dinv_glob, nb);
+    // (the diagonal tiles of W are lower triangular with explicit zeros above the diagonal: diag_tile)
     for (int i = 0; i < nb; ++i) {
         acc_t cw[MAXT];
 #pragma unroll

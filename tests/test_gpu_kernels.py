@@ -130,6 +130,25 @@ def test_potrf_trsm(dev, m, dt, algo):
     close(x, x_ref, tol, 'trsm')
 
 
+@pytest.mark.parametrize('m', [200, 256, 300, 512])
+@pytest.mark.parametrize('dt', [torch.float64, torch.float32])
+def test_potrf_large_multi_workgroup(dev, m, dt):
+    """M beyond one workgroup's LDS: the right-looking 64-block factorisation spread over the GPU (potrf_big.hip)."""
+    rng = np.random.default_rng(m)
+    b = 5
+    a = rng.standard_normal((b, m, m + 3))
+    a = a @ a.transpose(0, 2, 1) + 0.5 * m * np.eye(m)
+    l_ref = np.linalg.cholesky(a)
+    tol = dict(rtol=1e-11, atol_rel=1e-13) if dt == torch.float64 else dict(rtol=5e-4, atol_rel=5e-6)
+    l, info = ops.potrf_batched(T(a, dt, dev))
+    assert int(info.abs().max()) == 0
+    close(l, l_ref, tol, 'potrf (multi-workgroup)')
+    bad = np.eye(m)[None].repeat(2, axis=0)
+    bad[1, 150, 150] = -1.0
+    _, info = ops.potrf_batched(T(bad, dt, dev))
+    assert info.tolist() == [0, 151]
+
+
 @pytest.mark.parametrize('algo', ['auto', 'plain'])
 def test_potrf_reports_non_positive_definite(dev, algo):
     a = np.eye(40)[None].repeat(2, axis=0)
