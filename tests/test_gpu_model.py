@@ -57,6 +57,24 @@ def test_objective_matches_reference_model(dev, fixture, prec):
     np.testing.assert_allclose(gat.cpu().numpy(), g['gamma_atoms'], rtol=1e-12)
 
 
+@pytest.mark.parametrize('fixture', ['grad_ref_40_6_12_3_T4', 'grad_ref_60_10_15_4_T5'])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_objective_at_the_gradient_fixture_points(dev, fixture, prec):
+    """The HIP forward pass at the points where tests/golden/grad_ref_*.npz hold the reference's own gradients (groundwork
+    for the backward pass: the forward value must agree there first).  The fixtures store the reference's RAW variables."""
+    g = golden(fixture)
+    sp = lambda x: np.logaddexp(0.0, x)                                     # utils/types.py:57
+    model = dp_gp_lvm(g['y'], num_latent_dims=g['x_mean'].shape[1], num_inducing_points=g['x_u'].shape[0],
+                      truncation_level=g['dp_logits'].shape[1], alpha_prior_params=np.array([float(g['s_1']), float(g['s_2'])]),
+                      device=dev, precision=prec,
+                      initial_values=dict(x_mean=g['x_mean'], x_var=sp(g['x_var_raw']), x_u=g['x_u'], phi_logits=g['dp_logits'],
+                                          gamma_atoms=sp(g['gamma_atoms_raw']), alpha_atoms=sp(g['alpha_atoms_raw']),
+                                          beta_atoms=sp(g['beta_atoms_raw']), gamma_1=sp(g['gamma_1_raw']),
+                                          gamma_2=sp(g['gamma_2_raw']), w_1=float(sp(g['w_1_raw'])),
+                                          w_2=float(sp(g['w_2_raw']))))
+    np.testing.assert_allclose(float(model.objective), float(g['objective']), rtol=RTOL[prec])
+
+
 def test_model_kernel_object_matches_reference(dev):
     """model.kernel is a Kernel with batch D whose operators reproduce the reference's K_uu / psi1 / psi2."""
     g = golden('dpgplvm_50_10_25_3_T8')

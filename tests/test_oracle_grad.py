@@ -1,0 +1,63 @@
+"""CPU tests of the gradient oracle (oracle/dpgp_oracle_torch.py) against the gradient fixtures that
+oracle/gen_golden_grad.py produced by differentiating the reference's own objective (tests/golden/grad_ref_*.npz).
+Groundwork for the backward pass of the fused ELBO: the HIP gradients will be checked against this
+oracle, which is pinned here."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dpgp_oracle as orc
+from oracle import dpgp_oracle_torch as ot
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, 'grad_ref_*.npz')))
+
+
+def softplus(x):
+    return np.logaddexp(0.0, x)
+
+
+def test_gradient_fixtures_exist():
+    assert len(FIXTURES) >= 2
+
+
+@pytest.mark.parametrize('path', FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_torch_oracle_reproduces_reference_objective_and_gradients(path):
+    g = np.load(path)
+    obj, grads = ot.objective_and_gradients(g['y'], {k: g[k] for k in ot.NAMES}, s_1=float(g['s_1']), s_2=float(g['s_2']),
+                                            mask_size=int(g['mask_size']))
+    np.testing.assert_allclose(obj, float(g['objective']), rtol=1e-11)
+    for k in ot.NAMES:
+        ref = g['grad_' + k]
+        np.testing.assert_allclose(grads[k], ref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+@pytest.mark.parametrize('path', FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_numpy_oracle_agrees_at_the_gradient_fixture_points(path):
+    """The forward oracle that checks the HIP path (oracle/dpgp_oracle.py) evaluated at the same raw variables."""
+    g = np.load(path)
+    e = np.exp(g['dp_logits'] - g['dp_logits'].max(axis=1, keepdims=True))
+    phi = e / e.sum(axis=1, keepdims=True)
+    obj = orc.objective(g['y'], g['x_u'], g['x_mean'], softplus(g['x_var_raw']), phi, softplus(g['gamma_atoms_raw']),
+                        softplus(g['alpha_atoms_raw']), softplus(g['beta_atoms_raw']), softplus(g['gamma_1_raw']),
+                        softplus(g['gamma_2_raw']), float(softplus(g['w_1_raw'])), float(softplus(g['w_2_raw'])),
+                        float(g['s_1']), float(g['s_2']))
+    np.testing.assert_allclose(obj, float(g['objective']), rtol=1e-10)
+
+
+@pytest.mark.parametrize('path', FIXTURES[:1], ids=[os.path.basename(p) for p in FIXTURES[:1]])
+def test_gradient_is_consistent_with_finite_differences_of_the_numpy_oracle(path):
+    g = np.load(path)
+    raw = {k: g[k].astype(np.float64) for k in ot.NAMES}
+    _, grads = ot.objective_and_gradients(g['y'], raw, s_1=float(g['s_1']), s_2=float(g['s_2']))
+
+    def f(r):
+        return ot.objective_and_gradients(g['y'], r, s_1=float(g['s_1']), s_2=float(g['s_2']))[0]
+    rs = np.random.default_rng(3)
+    dirs = {k: rs.standard_normal(np.shape(v)) for k, v in raw.items()}
+    h = 1e-6
+    fd = (f({k: raw[k] + h * dirs[k] for k in raw}) - f({k: raw[k] - h * dirs[k] for k in raw})) / (2 * h)
+    an = sum(float(np.sum(grads[k] * dirs[k])) for k in raw)
+    assert abs(fd - an) <= 1e-6 * max(1.0, abs(an))
