@@ -81,6 +81,38 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
                             ex ? (double *)ex->model_pack : nullptr, ex ? (double *)ex->model_out : nullptr, st);
 }
 
+// Backward pass, stage A (grad.hip): adjoints of the per-output dense algebra from the workspace of a finished forward
+// evaluation (same D, N, M, Q, prec; prec must be mixed or f64: the chain is fp64).
+extern "C" int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *alpha, const double *beta, double jitter,
+                                    int prec, void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v,
+                                    double *d_alpha_beta, int *info, void *stream) {
+    if (D <= 0) return -1;
+    if (N <= 0) return -2;
+    if (M <= 0 || M > N) return -3;
+    if (Q <= 0 || Q > DPGP_MAX_Q) return -4;
+    if (!alpha) return -5;
+    if (!beta) return -6;
+    if (!(jitter >= 0.0)) return -7;
+    if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_F64) return -8;
+    if (!ws) return -9;
+    const ElboLayout L = elbo_layout(D, N, M, Q, prec);
+    if (ws_bytes < L.total) return -10;
+    if (!g_psi2) return -11;
+    if (!w_kuu) return -12;
+    if (!g_v) return -13;
+    if (!d_alpha_beta) return -14;
+    if (!info) return -15;
+    unsigned char *w = (unsigned char *)ws;
+    const double *yy = reinterpret_cast<const double *>(w + L.off_yy), *vpart = reinterpret_cast<const double *>(w + L.off_v);
+    double *la = reinterpret_cast<double *>(w + L.off_la);
+    // the f16 psi2 kernel leaves ns2 slabs; (slab count as in elbo_run)
+    if (prec == DPGP_PREC_MIXED)
+        return launch_chain_grad<float>(D, N, M, reinterpret_cast<const float *>(w + L.off_p2), L.ns2, vpart, L.ns1, alpha,
+                                        beta, yy, jitter, la, g_psi2, w_kuu, g_v, d_alpha_beta, info, (hipStream_t)stream);
+    return launch_chain_grad<double>(D, N, M, reinterpret_cast<const double *>(w + L.off_p2), L.ns2, vpart, L.ns1, alpha,
+                                     beta, yy, jitter, la, g_psi2, w_kuu, g_v, d_alpha_beta, info, (hipStream_t)stream);
+}
+
 extern "C" int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z,
                                  const double *mu, const double *s, const double *gamma, const double *alpha,
                                  const double *beta, double jitter, int prec, int algo, double *terms, double *sums,

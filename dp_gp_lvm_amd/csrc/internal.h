@@ -63,4 +63,12 @@ int launch_sum_terms(int D, const double *terms, const double *kl_part, double *
 // a[B][M][M] in/out (lower, zeros above), info[B], ws: potrf_big_ws_elems(B, M) elements of T
 size_t potrf_big_ws_elems(int B, int M);
 template <typename T> int launch_potrf_big(int B, int M, T *a, int *info, T *ws, hipStream_t st);
+// ---- grad.hip: backward pass (first version) ---------------------------------------------------------------------
+// adjoints of the per-output dense algebra, after a forward evaluation on the same chain workspace ws:
+//   GP[D][Mp][Mp] = df/dPsi2 (lower), WK[D][Mp][Mp] = (df/dK_uu) * (K_uu - jitter I) (lower), Gv[D][Mp] = df/d(Psi1^T y),
+//   dab[D][2] = (df/dalpha_d, df/dbeta_d) complete, info[D]
+template <typename TP>
+int launch_chain_grad(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1, const double *alpha,
+                      const double *beta, const double *yy_part, double jitter, double *ws, double *GP, double *WK,
+                      double *Gv, double *dab, int *info, hipStream_t st);
 #define DPGP_PREP_ROWS 16   // output dims per row-block of dpgp_model_prepare (scal has 2 + ceil(D / 16) entries)

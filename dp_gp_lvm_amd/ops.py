@@ -234,3 +234,26 @@ def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='
                                             _stream(), ctypes.cast(ctypes.pointer(w.exec), ctypes.c_void_p)),
                'dpgp_elbo_fhat_ex')
     return w.terms, w.sums, w.info
+
+
+def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8):
+    """Backward pass, stage A: adjoints of the per-output dense algebra from the workspace of a finished ``elbo_fhat`` call
+    (dp_gp_lvm.py:108-145 differentiated; first version, M <= 128, prec mixed / f64).
+    Returns (g_psi2 [D,Mp,Mp], w_kuu [D,Mp,Mp], g_v [D,Mp], d_alpha_beta [D,2], info [D]); see include/dpgp.h."""
+    f64 = torch.float64
+    d, n, m, q = workspace.shape
+    alpha = _prep(alpha, f64, 'alpha').reshape(-1)
+    beta = _prep(beta, f64, 'beta').reshape(-1)
+    assert alpha.numel() == d and beta.numel() == d
+    mp = 16 * ((m + 15) // 16)
+    dev = workspace.ws.device
+    gp = torch.empty((d, mp, mp), dtype=f64, device=dev)
+    wk = torch.empty((d, mp, mp), dtype=f64, device=dev)
+    gv = torch.empty((d, mp), dtype=f64, device=dev)
+    dab = torch.empty((d, 2), dtype=f64, device=dev)
+    info = torch.empty(d, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().dpgp_elbo_grad_chain(d, n, m, q, alpha.data_ptr(), beta.data_ptr(), float(jitter),
+                                               _lib.PREC[workspace.prec], workspace.ws.data_ptr(), workspace.nbytes,
+                                               gp.data_ptr(), wk.data_ptr(), gv.data_ptr(), dab.data_ptr(), info.data_ptr(),
+                                               _stream()), 'dpgp_elbo_grad_chain')
+    return gp, wk, gv, dab, info

@@ -139,6 +139,19 @@ int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, cons
                       int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
                       void *stream, const dpgp_exec_t *exec);
 /* hipEvent helpers for hosts without their own HIP binding */
+/* Backward pass of the fused ELBO, stage A (first version; reference: tf.gradients(objective) as used by every training
+ * script, test/synthetic_data_hard_test.py:143-155; the forward it differentiates: src/models/dp_gp_lvm.py:108-145).
+ * Adjoints of the per-output dense algebra, computed from the workspace `ws` of a FINISHED dpgp_elbo_fhat[_ex] call with
+ * the same D, N, M, Q, prec (prec = DPGP_PREC_MIXED or DPGP_PREC_F64; M <= 128).  Mp = 16 * ceil(M / 16).
+ *   g_psi2[D][Mp][Mp]  d f_hat / d Psi2_d   (lower triangle j <= i valid, symmetric)
+ *   w_kuu [D][Mp][Mp]  (d f_hat / d K_uu,d) .* (K_uu,d - jitter I)   (lower triangle)
+ *   g_v   [D][Mp]      d f_hat / d (Psi1_d^T y_d)
+ *   d_alpha_beta[D][2] d f_hat / d alpha_d (complete: direct + through K_uu, Psi1, Psi2) and d f_hat / d beta_d
+ *   info[D]            0 or the failing minor of B_d = K_uu,d + beta_d Psi2_d                                              */
+int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *alpha, const double *beta, double jitter, int prec,
+                         void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v, double *d_alpha_beta,
+                         int *info, void *stream);
+
 void *dpgp_event_create(void);
 void dpgp_event_destroy(void *event);
 float dpgp_event_elapsed_ms(void *begin, void *end);

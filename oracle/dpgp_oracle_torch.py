@@ -59,17 +59,15 @@ def dp_objective(phi, g1, g2, w1, w2, s1, s2):
     return -(ev_z + ev_v + ev_a + ent)
 
 
-def fhat(y, z, mu, s, gamma, alpha, beta, jitter=GP_DEFAULT_JITTER, chunk=64):
-    """f_hat of dp_gp_lvm.py:108-145 in the B = K_uu + beta Psi2 form:
-        sum_d [ 1/2 N (log beta - log 2 pi) - (log|L_B| - log|L_K|) + 1/2 beta (<K^-1, Psi2> - alpha N) - 1/2 beta y^T y
-                + 1/2 beta^2 || L_B^-1 Psi1^T y ||^2 ]."""
+def psi_pieces(y, z, mu, s, gamma, alpha, jitter=GP_DEFAULT_JITTER, chunk=64):
+    """K_uu + jitter I [D,M,M] (rbf_kernel.py:58-93), Psi2 [D,M,M] (rbf_kernel.py:164-199) and Psi1^T y [D,M]
+    (rbf_kernel.py:135-161 contracted with y), the Psi statistics streamed over n-chunks."""
     n, d = y.shape
     m = z.shape[0]
     zd = z[:, None, :] - z[None, :, :]                                                       # [M,M,Q]
     zbar = 0.5 * (z[:, None, :] + z[None, :, :])
     sq = torch.einsum('dq,ijq->dij', gamma, zd * zd)
-    k_uu = alpha[:, None, None] * torch.exp(-0.5 * sq) + jitter * torch.eye(m, dtype=y.dtype)  # rbf_kernel.py:58-93
-    # Psi1^T y (rbf_kernel.py:135-161 contracted with y) and Psi2 (rbf_kernel.py:164-199), streamed over n-chunks
+    k_uu = alpha[:, None, None] * torch.exp(-0.5 * sq) + jitter * torch.eye(m, dtype=y.dtype)
     v = torch.zeros((d, m), dtype=y.dtype)
     p2 = torch.zeros((d, m, m), dtype=y.dtype)
     t1 = 0.25 * sq
@@ -86,6 +84,13 @@ def fhat(y, z, mu, s, gamma, alpha, beta, jitter=GP_DEFAULT_JITTER, chunk=64):
         lp = 2.0 * torch.log(alpha)[:, None, None, None] - (0.5 * torch.sum(torch.log(den2), dim=-1)[:, :, None, None]
                                                              + t1[:, None] + e2)
         p2 = p2 + torch.sum(torch.exp(lp), dim=1)
+    return k_uu, p2, v
+
+
+def fhat_from_pieces(k_uu, p2, v, alpha, beta, yy, n):
+    """f_hat of dp_gp_lvm.py:108-145 in the B = K_uu + beta Psi2 form, five terms per output dim:
+        1/2 N (log beta - log 2 pi), -(log|L_B| - log|L_K|), 1/2 beta (<K^-1, Psi2> - alpha N), -1/2 beta y^T y,
+        1/2 beta^2 || L_B^-1 Psi1^T y ||^2."""
     l_k = torch.linalg.cholesky(k_uu)
     b = k_uu + beta[:, None, None] * p2
     l_b = torch.linalg.cholesky(b)
@@ -93,9 +98,31 @@ def fhat(y, z, mu, s, gamma, alpha, beta, jitter=GP_DEFAULT_JITTER, chunk=64):
     logdet_b = torch.sum(torch.log(torch.diagonal(l_b, dim1=-2, dim2=-1)), dim=-1)
     tr = torch.sum(torch.cholesky_solve(p2, l_k).diagonal(dim1=-2, dim2=-1), dim=-1)         # <K^-1, Psi2>
     c = torch.linalg.solve_triangular(l_b, v[:, :, None], upper=False)[:, :, 0]
-    terms = torch.stack([0.5 * n * (torch.log(beta) - LOG_2PI), -(logdet_b - logdet_k), 0.5 * beta * (tr - alpha * n),
-                         -0.5 * beta * torch.sum(y * y, dim=0), 0.5 * beta * beta * torch.sum(c * c, dim=-1)], dim=1)
-    return terms
+    return torch.stack([0.5 * n * (torch.log(beta) - LOG_2PI), -(logdet_b - logdet_k), 0.5 * beta * (tr - alpha * n),
+                        -0.5 * beta * yy, 0.5 * beta * beta * torch.sum(c * c, dim=-1)], dim=1)
+
+
+def fhat(y, z, mu, s, gamma, alpha, beta, jitter=GP_DEFAULT_JITTER, chunk=64):
+    k_uu, p2, v = psi_pieces(y, z, mu, s, gamma, alpha, jitter=jitter, chunk=chunk)
+    return fhat_from_pieces(k_uu, p2, v, alpha, beta, torch.sum(y * y, dim=0), y.shape[0])
+
+
+def chain_adjoints(y, z, mu, s, gamma, alpha, beta, jitter=GP_DEFAULT_JITTER):
+    """What stage A of the HIP backward pass (dpgp_elbo_grad_chain) must return, by autograd (NumPy in / out):
+    g_psi2, g_kuu (symmetrised d f_hat / d Psi2, d K_uu), g_v, and the COMPLETE d f_hat / d alpha_d, d beta_d."""
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64))
+    y, z, mu, s, gamma = t(y), t(z), t(mu), t(s), t(gamma)
+    al = t(alpha).reshape(-1).clone().requires_grad_(True)
+    be = t(beta).reshape(-1).clone().requires_grad_(True)
+    k_uu, p2, v = psi_pieces(y, z, mu, s, gamma, al, jitter=jitter)
+    kl, pl, vl = (a.detach().clone().requires_grad_(True) for a in (k_uu, p2, v))
+    f = torch.sum(fhat_from_pieces(kl, pl, vl, al.detach(), be.detach(), torch.sum(y * y, dim=0), y.shape[0]))
+    gk, gp, gv = torch.autograd.grad(f, [kl, pl, vl])
+    total = torch.sum(fhat_from_pieces(k_uu, p2, v, al, be, torch.sum(y * y, dim=0), y.shape[0]))
+    da, db = torch.autograd.grad(total, [al, be])
+    sym = lambda a: 0.5 * (a + a.transpose(1, 2))
+    return dict(g_kuu=sym(gk).numpy(), g_psi2=sym(gp).numpy(), g_v=gv.numpy(), d_alpha=da.numpy(), d_beta=db.numpy(),
+                k_uu=k_uu.detach().numpy(), psi2=p2.detach().numpy(), v=v.detach().numpy())
 
 
 def objective(y, raw, s_1=1.0, s_2=1.0, mask_size=1, jitter=GP_DEFAULT_JITTER):

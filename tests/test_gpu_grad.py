@@ -1,0 +1,50 @@
+"""GPU tests of the backward pass of the fused ELBO (first version), against the autograd gradient oracle
+(oracle/dpgp_oracle_torch.py, pinned by tests/golden/grad_ref_*.npz = gradients of the reference's own objective).
+Stage A: dpgp_elbo_grad_chain — adjoints of the per-output dense algebra (dp_gp_lvm.py:108-145 differentiated).
+Tolerances: fp64 chain on fp64 psi statistics 1e-8; mixed (fp32 psi statistics) 2e-4 relative to the largest entry."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from dp_gp_lvm_amd import ops
+from oracle import dpgp_oracle_torch as ot
+
+pytestmark = pytest.mark.gpu
+
+
+def softplus(x):
+    return np.logaddexp(0.0, x)
+
+
+def point(name):
+    g = golden(name)
+    e = np.exp(g['dp_logits'] - g['dp_logits'].max(axis=1, keepdims=True))
+    phi = e / e.sum(axis=1, keepdims=True)
+    return dict(y=g['y'], z=g['x_u'], mu=g['x_mean'], s=softplus(g['x_var_raw']), gamma=phi @ softplus(g['gamma_atoms_raw']),
+                alpha=(phi @ softplus(g['alpha_atoms_raw']))[:, 0], beta=(phi @ softplus(g['beta_atoms_raw']))[:, 0])
+
+
+@pytest.mark.parametrize('fixture', ['grad_ref_40_6_12_3_T4', 'grad_ref_60_10_15_4_T5'])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_chain_adjoints(dev, fixture, prec):
+    p = point(fixture)
+    ref = ot.chain_adjoints(p['y'], p['z'], p['mu'], p['s'], p['gamma'], p['alpha'], p['beta'])
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    n, d = p['y'].shape
+    m, q = p['z'].shape
+    w = ops.ElboWorkspace(d, n, m, q, prec, dev)
+    ops.elbo_fhat(t(p['y']), t(p['z']), t(p['mu']), t(p['s']), t(p['gamma']), t(p['alpha']), t(p['beta']), prec=prec, workspace=w)
+    gp, wk, gv, dab, info = ops.elbo_grad_chain(t(p['alpha']), t(p['beta']), w)
+    assert int(info.abs().max()) == 0
+    tol = 1e-8 if prec == 'f64' else 2e-4
+    low = np.tril(np.ones((m, m), dtype=bool))
+
+    def close(got, want, what):
+        np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max(), err_msg=what)
+    close(gp.cpu().numpy()[:, :m, :m][:, low], ref['g_psi2'][:, low], 'd f_hat / d Psi2')
+    k_scaled = ref['k_uu'] - 1e-8 * np.eye(m)
+    close(wk.cpu().numpy()[:, :m, :m][:, low], (ref['g_kuu'] * k_scaled)[:, low], '(d f_hat / d K_uu) .* (K_uu - jitter I)')
+    close(gv.cpu().numpy()[:, :m], ref['g_v'], 'd f_hat / d Psi1^T y')
+    close(dab.cpu().numpy()[:, 0], ref['d_alpha'], 'd f_hat / d alpha')
+    close(dab.cpu().numpy()[:, 1], ref['d_beta'], 'd f_hat / d beta')
