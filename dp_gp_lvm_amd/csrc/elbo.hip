@@ -113,6 +113,43 @@ extern "C" int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *al
                                      beta, yy, jitter, la, g_psi2, w_kuu, g_v, d_alpha_beta, info, (hipStream_t)stream);
 }
 
+// Backward pass, stage B (grad.hip): the second streaming pass over the observations.
+extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q) {
+    if (D <= 0 || N <= 0 || M <= 0 || Q <= 0) return 0;
+    return dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
+}
+extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                                  const double *s, const double *gamma, const double *alpha, const double *g_psi2,
+                                  const double *w_kuu, const double *g_v, int prec, void *ws, size_t ws_bytes,
+                                  double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream) {
+    if (D <= 0) return -1;
+    if (N <= 0) return -2;
+    if (M <= 0 || M > N) return -3;
+    if (Q <= 0 || Q > DPGP_MAX_Q) return -4;
+    if (!y) return -5;
+    if (ldy < D) return -6;
+    if (!z) return -7;
+    if (!mu) return -8;
+    if (!s) return -9;
+    if (!gamma) return -10;
+    if (!alpha) return -11;
+    if (!g_psi2) return -12;
+    if (!w_kuu) return -13;
+    if (!g_v) return -14;
+    if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_F64) return -15;
+    if (!ws) return -16;
+    if (ws_bytes < dpgp_elbo_grad_psi_workspace_bytes(D, N, M, Q)) return -17;
+    if (!d_mu) return -18;
+    if (!d_s) return -19;
+    if (!d_z) return -20;
+    if (!d_gamma) return -21;
+    if (prec == DPGP_PREC_MIXED)
+        return launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
+                                      d_z, d_gamma, (hipStream_t)stream);
+    return launch_psi_grad<double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
+                                   d_z, d_gamma, (hipStream_t)stream);
+}
+
 extern "C" int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z,
                                  const double *mu, const double *s, const double *gamma, const double *alpha,
                                  const double *beta, double jitter, int prec, int algo, double *terms, double *sums,

@@ -197,3 +197,268 @@ template int launch_chain_grad<float>(int, int, int, const float *, int, const d
 template int launch_chain_grad<double>(int, int, int, const double *, int, const double *, int, const double *,
                                        const double *, const double *, double, double *, double *, double *, double *,
                                        double *, int *, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage B (psi_grad_kernel): second streaming pass over the observations, first version (plain VALU, no symmetry saving).
+// With G = d f_hat / d Psi2_d (symmetric), g = d f_hat / d (Psi1_d^T y_d), W = (d f_hat / d K_uu,d) .* (K_uu,d - jitter I):
+//   w [n,a,m'] = G[a,m'] psi2(n,a,m'),     R = sum_m' w,  T_q = sum_m' w z_m'q             (rbf_kernel.py:164-199)
+//   w1[n,a]    = g[a] y_nd psi1(n,a)                                                        (rbf_kernel.py:135-161)
+//   wk[a,m']   = W[a,m'],                 R_K = sum_m' wk, T_K,q = sum_m' wk z_m'q          (rbf_kernel.py:58-93)
+// thread = (row a of the M x M statistics, one of two observations); per observation the sums over a of
+// (R, R z_a, R z_a^2, z_a T) and (w1, w1 z_a, w1 z_a^2) give d/dmu_n, d/dS_n and the per-observation part of d/dgamma_d;
+// d/dz_a accumulates thread-locally over the observations.  Partial results per (output dim, n-split) are summed by
+// grad_reduce_kernel in a fixed order (deterministic).  alpha enters only as a factor (its derivative is stage A's).
+//   log psi2 = 2 log alpha - sum_q [ 1/2 log den2 + 1/4 gamma (z_a - z_m')^2 + gamma (mu - (z_a + z_m')/2)^2 / den2 ],  den2 = 2 gamma S + 1
+//   log psi1 =   log alpha - 1/2 sum_q [ log den1 + gamma (mu - z_a)^2 / den1 ],                                       den1 = gamma S + 1
+// ---------------------------------------------------------------------------------------------------------------
+// QP: latent dims padded to a multiple of 4 (compile time, so that the per-thread q-arrays stay in registers)
+template <typename TC, int QP>
+__global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int Mp, int Q, const double *__restrict__ y, int ldy,
+                                                       const double *__restrict__ z, const double *__restrict__ mu,
+                                                       const double *__restrict__ s, const double *__restrict__ gamma,
+                                                       const double *__restrict__ alpha, const double *__restrict__ GP,
+                                                       const double *__restrict__ WK, const double *__restrict__ Gv,
+                                                       int n_per_split, double *__restrict__ dmu_part,
+                                                       double *__restrict__ ds_part, double *__restrict__ dz_part,
+                                                       double *__restrict__ dg_part) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    TC *gs = reinterpret_cast<TC *>(smem_raw);                 // [Mp][Mp + 1] symmetric G (then W for the K_uu part)
+    TC *zs = gs + (size_t)Mp * (Mp + 1);                       // [Mp][QP], zero padded
+    TC *red = zs + (size_t)Mp * QP;                             // [2][7 Q + 2][128] per-observation partial sums
+    TC *nq = red + (size_t)2 * (7 * Q + 2) * 128;              // [2][6][Q] per-observation per-q factors
+    const int d = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y, t = threadIdx.x, a = t & 127, nl = t >> 7;
+    const int NV = 7 * Q + 2;
+    const TC al = (TC)alpha[d];
+    for (int e = t; e < Mp * Mp; e += 256) {
+        const int i = e / Mp, j = e - i * Mp;
+        const double v = (i < M && j < M) ? GP[(size_t)d * Mp * Mp + (size_t)(i >= j ? i : j) * Mp + (i >= j ? j : i)] : 0.0;
+        gs[i * (Mp + 1) + j] = (TC)v;
+    }
+    for (int e = t; e < Mp * QP; e += 256) {
+        const int i = e / QP, q = e - i * QP;
+        zs[e] = (i < M && q < Q) ? (TC)z[(size_t)i * Q + q] : (TC)0;
+    }
+    __syncthreads();
+    TC ga[QP], za[QP], dza[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        ga[q] = (q < Q) ? (TC)gamma[(size_t)d * Q + q] : (TC)0;
+        za[q] = (a < M) ? zs[a * QP + q] : (TC)0;
+        dza[q] = 0;
+    }
+    const TC gva = (a < M) ? (TC)Gv[(size_t)d * Mp + a] : (TC)0;
+    TC dg_mine = 0;
+    const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    for (int n0 = nbeg; n0 < nend; n0 += 2) {
+        const int n = n0 + nl;
+        const bool live = (n < nend);
+        // per-observation factors, one thread per (observation, q): a2 = gamma / den2, a1 = gamma / den1, ...
+        if (t < 2 * Q) {
+            const int l = t / Q, q = t - l * Q, nn = n0 + l;
+            TC *o = nq + (l * 6) * Q + q;
+            if (nn < nend) {
+                const TC g = (TC)gamma[(size_t)d * Q + q], ss = (TC)s[(size_t)nn * Q + q], m_ = (TC)mu[(size_t)nn * Q + q];
+                const TC den2 = 2 * g * ss + 1, den1 = g * ss + 1;
+                o[0] = g / den2; o[Q] = g / den1; o[2 * Q] = m_; o[3 * Q] = ss;
+                o[4 * Q] = dpgp_log(den2); o[5 * Q] = dpgp_log(den1);
+            } else {
+                o[0] = 0; o[Q] = 0; o[2 * Q] = 0; o[3 * Q] = 1; o[4 * Q] = 0; o[5 * Q] = 0;
+            }
+        }
+        __syncthreads();
+        const TC *f = nq + (nl * 6) * Q;
+        TC a2[QP], mq[QP];
+        TC l2 = 0, l1 = 0;
+        TC a1v[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const bool in = q < Q;
+            a2[q] = in ? f[q] : (TC)0; a1v[q] = in ? f[Q + q] : (TC)0; mq[q] = in ? f[2 * Q + q] : (TC)0;
+            l2 += in ? f[4 * Q + q] : (TC)0; l1 += in ? f[5 * Q + q] : (TC)0;
+        }
+        TC R = 0, T[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) T[q] = 0;
+        TC w1 = 0;
+        if (live && a < M) {
+            const TC pref = 2 * dpgp_log(al) - (TC)0.5 * l2;
+            for (int mp = 0; mp < M; ++mp) {
+                TC e = pref, zm[QP];
+#pragma unroll
+                for (int q = 0; q < QP; ++q) {
+                    zm[q] = zs[mp * QP + q];
+                    const TC dz_ = za[q] - zm[q], c = mq[q] - (TC)0.5 * (za[q] + zm[q]);
+                    e -= (TC)0.25 * ga[q] * dz_ * dz_ + a2[q] * c * c;
+                }
+                const TC w = gs[mp * (Mp + 1) + a] * exp(e);
+                R += w;
+#pragma unroll
+                for (int q = 0; q < QP; ++q) T[q] += w * zm[q];
+            }
+            TC e1 = dpgp_log(al) - (TC)0.5 * l1;
+#pragma unroll
+            for (int q = 0; q < QP; ++q) { const TC c = mq[q] - za[q]; e1 -= (TC)0.5 * a1v[q] * c * c; }
+            w1 = gva * (TC)y[(size_t)n * ldy + d] * exp(e1);
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                // gamma (1 +- 1 / den2) = gamma +- a2
+                dza[q] += -(ga[q] + a2[q]) * za[q] * R + (ga[q] - a2[q]) * T[q] + 2 * a2[q] * mq[q] * R
+                          + w1 * a1v[q] * (mq[q] - za[q]);
+            }
+        }
+        // partial sums over the rows a: [R | R z | R z^2 | z T | w1 | w1 z | w1 z^2]
+        TC *rp = red + (size_t)nl * NV * 128 + a;
+        rp[0] = R;
+        rp[(size_t)(3 * Q + 1) * 128] = w1;
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+            if (q < Q) {
+                rp[(size_t)(1 + q) * 128] = R * za[q];
+                rp[(size_t)(1 + Q + q) * 128] = R * za[q] * za[q];
+                rp[(size_t)(1 + 2 * Q + q) * 128] = za[q] * T[q];
+                rp[(size_t)(3 * Q + 2 + q) * 128] = w1 * za[q];
+                rp[(size_t)(4 * Q + 2 + q) * 128] = w1 * za[q] * za[q];
+            }
+        __syncthreads();
+        // thread (l, q) finishes observation l, latent dim q
+        if (t < 2 * Q) {
+            const int l = t / Q, q = t - l * Q, nn = n0 + l;
+            if (nn < nend) {
+                const TC *r0 = red + (size_t)l * NV * 128;
+                TC S0 = 0, S1 = 0, S2 = 0, S3 = 0, V0 = 0, V1 = 0, V2 = 0;
+                for (int k = 0; k < 128; ++k) {
+                    S0 += r0[k]; S1 += r0[(size_t)(1 + q) * 128 + k]; S2 += r0[(size_t)(1 + Q + q) * 128 + k];
+                    S3 += r0[(size_t)(1 + 2 * Q + q) * 128 + k]; V0 += r0[(size_t)(3 * Q + 1) * 128 + k];
+                    V1 += r0[(size_t)(3 * Q + 2 + q) * 128 + k]; V2 += r0[(size_t)(4 * Q + 2 + q) * 128 + k];
+                }
+                const TC *o = nq + (l * 6) * Q + q;
+                const TC a2_ = o[0], a1_ = o[Q], m_ = o[2 * Q], ss = o[3 * Q], g = (TC)gamma[(size_t)d * Q + q];
+                const TC id2 = a2_ / g, id1 = a1_ / g;                       // 1 / den2, 1 / den1
+                const TC A2 = (TC)0.5 * (S2 + S3);
+                const TC q2 = m_ * m_ * S0 - 2 * m_ * S1 + A2;               // sum w (mu - zbar)^2
+                const TC q1 = m_ * m_ * V0 - 2 * m_ * V1 + V2;               // sum w1 (mu - z)^2
+                const TC dmu = -2 * a2_ * (m_ * S0 - S1) - a1_ * (m_ * V0 - V1);
+                const TC dss = -a2_ * S0 + 2 * a2_ * a2_ * q2 + (TC)0.5 * (a1_ * a1_ * q1 - a1_ * V0);
+                dmu_part[((size_t)d * N + nn) * Q + q] = (double)dmu;
+                ds_part[((size_t)d * N + nn) * Q + q] = (double)dss;
+                dg_mine += -ss * id2 * S0 - q2 * id2 * id2 - (TC)0.5 * (S2 - S3) - (TC)0.5 * (q1 * id1 * id1 + ss * id1 * V0);
+            }
+        }
+        __syncthreads();
+    }
+    // K_uu part, once per output dim (split 0): wk = W (symmetric), no dependence on the observations
+    TC dgk = 0;
+    if (sp == 0) {
+        __syncthreads();
+        for (int e = t; e < Mp * Mp; e += 256) {
+            const int i = e / Mp, j = e - i * Mp;
+            const double v = (i < M && j < M) ? WK[(size_t)d * Mp * Mp + (size_t)(i >= j ? i : j) * Mp + (i >= j ? j : i)] : 0.0;
+            gs[i * (Mp + 1) + j] = (TC)v;
+        }
+        __syncthreads();
+        TC RK = 0, TK[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) TK[q] = 0;
+        if (nl == 0 && a < M) {
+            for (int mp = 0; mp < M; ++mp) {
+                const TC w = gs[mp * (Mp + 1) + a];
+                RK += w;
+#pragma unroll
+                for (int q = 0; q < QP; ++q) TK[q] += w * zs[mp * QP + q];
+            }
+#pragma unroll
+            for (int q = 0; q < QP; ++q) dza[q] += -2 * ga[q] * (za[q] * RK - TK[q]);
+        }
+        TC *rp = red + a;
+        if (nl == 0) {
+#pragma unroll
+            for (int q = 0; q < QP; ++q)
+                if (q < Q) rp[(size_t)q * 128] = (a < M) ? (RK * za[q] * za[q] - za[q] * TK[q]) : (TC)0;
+        }
+        __syncthreads();
+        if (t < Q) {
+            TC v = 0;
+            for (int k = 0; k < 128; ++k) v += red[(size_t)t * 128 + k];
+            dgk = -v;                                                        // -1/2 sum wk (z_a - z_m')^2 = -(S2 - S3)
+        }
+        __syncthreads();
+    }
+    // d/dgamma: threads (l, q) hold their observations' share; combine the two observation lanes through LDS
+    if (t < 2 * Q) red[t] = dg_mine;
+    __syncthreads();
+    if (t < Q) dg_part[((size_t)sp * D + d) * Q + t] = (double)(red[t] + red[Q + t] + dgk);
+    // d/dz: the two observation lanes of row a
+    __syncthreads();
+    if (a < M) {
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+            if (q < Q) red[(size_t)(nl * Q + q) * 128 + a] = dza[q];
+    }
+    __syncthreads();
+    if (nl == 0 && a < M)
+        for (int q = 0; q < Q; ++q)
+            dz_part[(((size_t)d * nsplit + sp) * M + a) * Q + q] = (double)(red[(size_t)q * 128 + a] + red[(size_t)(Q + q) * 128 + a]);
+}
+
+// out[i] = sum_k part[k * n + i], k < nk, fixed order
+__global__ __launch_bounds__(256) void grad_reduce_kernel(size_t n, int nk, const double *__restrict__ part, double *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (int k = 0; k < nk; ++k) a += part[(size_t)k * n + i];
+    out[i] = a;
+}
+
+size_t psi_grad_ws_bytes(int D, int N, int M, int Q, int *nsplit_out) {
+    int ns = dpgp_ceil_div(1024, D);
+    if (ns > dpgp_ceil_div(N, 32)) ns = dpgp_ceil_div(N, 32);
+    if (ns < 1) ns = 1;
+    if (nsplit_out) *nsplit_out = ns;
+    return sizeof(double) * ((size_t)2 * D * N * Q + (size_t)D * ns * M * Q + (size_t)ns * D * Q);
+}
+
+template <typename TC>
+int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
+                    const double *gamma, const double *alpha, const double *GP, const double *WK, const double *Gv,
+                    double *ws, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+    const int Mp = dpgp_round_up(M, 16);
+    if (Mp > 128) return -30;                                  // first version: one thread per row of the M x M statistics
+    int ns = 1;
+    psi_grad_ws_bytes(D, N, M, Q, &ns);
+    const int nper = 2 * dpgp_ceil_div(dpgp_ceil_div(N, ns), 2);
+    double *dmu_part = ws, *ds_part = dmu_part + (size_t)D * N * Q, *dz_part = ds_part + (size_t)D * N * Q,
+           *dg_part = dz_part + (size_t)D * ns * M * Q;
+    const int QPr = 4 * dpgp_ceil_div(Q, 4);
+    const size_t lds = sizeof(TC) * ((size_t)Mp * (Mp + 1) + (size_t)Mp * QPr + (size_t)2 * (7 * Q + 2) * 128 + (size_t)12 * Q);
+    void (*kern)(int, int, int, int, int, const double *, int, const double *, const double *, const double *, const double *,
+                 const double *, const double *, const double *, const double *, int, double *, double *, double *, double *) = nullptr;
+    switch (QPr / 4) {
+#define CASE(k) case k: kern = psi_grad_kernel<TC, 4 * k>; break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    if (!kern) return -4;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+        return DPGP_ERR_LAUNCH;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(D, ns), dim3(256), lds, st, D, N, M, Mp, Q, y, ldy, z, mu, s, gamma, alpha, GP, WK, Gv,
+                       nper, dmu_part, ds_part, dz_part, dg_part);
+    DPGP_LAUNCH_CHECK();
+    const size_t nq = (size_t)N * Q, mq = (size_t)M * Q, dq = (size_t)D * Q;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)dmu_part, dmu);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)ds_part, ds);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((mq + 255) / 256)), dim3(256), 0, st, mq, D * ns, (const double *)dz_part, dz);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, dq, ns, (const double *)dg_part, dgamma);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+template int launch_psi_grad<float>(int, int, int, int, const double *, int, const double *, const double *, const double *,
+                                    const double *, const double *, const double *, const double *, const double *, double *,
+                                    double *, double *, double *, double *, hipStream_t);
+template int launch_psi_grad<double>(int, int, int, int, const double *, int, const double *, const double *, const double *,
+                                     const double *, const double *, const double *, const double *, const double *,
+                                     double *, double *, double *, double *, double *, hipStream_t);

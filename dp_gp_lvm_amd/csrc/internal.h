@@ -71,4 +71,11 @@ template <typename TP>
 int launch_chain_grad(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1, const double *alpha,
                       const double *beta, const double *yy_part, double jitter, double *ws, double *GP, double *WK,
                       double *Gv, double *dab, int *info, hipStream_t st);
+// second streaming pass: d f_hat / d mu [N,Q], d S [N,Q], d z [M,Q], d gamma [D,Q] from the stage-A adjoints (alpha is a
+// constant factor here: its derivative is complete in stage A).  ws: psi_grad_ws_bytes(D, N, M, Q, nullptr) bytes.
+size_t psi_grad_ws_bytes(int D, int N, int M, int Q, int *nsplit_out);
+template <typename TC>
+int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
+                    const double *gamma, const double *alpha, const double *GP, const double *WK, const double *Gv,
+                    double *ws, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st);
 #define DPGP_PREP_ROWS 16   // output dims per row-block of dpgp_model_prepare (scal has 2 + ceil(D / 16) entries)

@@ -257,3 +257,25 @@ def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8):
                                                gp.data_ptr(), wk.data_ptr(), gv.data_ptr(), dab.data_ptr(), info.data_ptr(),
                                                _stream()), 'dpgp_elbo_grad_chain')
     return gp, wk, gv, dab, info
+
+
+def elbo_grad_psi(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, prec='mixed'):
+    """Backward pass, stage B: d f_hat / d (mu [N,Q], s [N,Q], z [M,Q], gamma [D,Q]) from the stage-A adjoints
+    (rbf_kernel.py:58-199 differentiated; first version, M <= 128)."""
+    f64 = torch.float64
+    z, mu, s = _prep(z, f64, 'z'), _prep(mu, f64, 'mu'), _prep(s, f64, 's')
+    gamma, alpha, _, d = _hyp(gamma, alpha, None, f64)
+    if y.dtype != f64 or y.stride(1) != 1:
+        y = y.to(f64).contiguous()
+    n, m, q = mu.shape[0], z.shape[0], z.shape[1]
+    dev = mu.device
+    l = _lib.lib()
+    wsb = l.dpgp_elbo_grad_psi_workspace_bytes(d, n, m, q)
+    ws = _ws(wsb, dev)
+    dmu, ds = torch.empty((n, q), dtype=f64, device=dev), torch.empty((n, q), dtype=f64, device=dev)
+    dz, dg = torch.empty((m, q), dtype=f64, device=dev), torch.empty((d, q), dtype=f64, device=dev)
+    _lib.check(l.dpgp_elbo_grad_psi(d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(), s.data_ptr(),
+                                    gamma.data_ptr(), alpha.data_ptr(), g_psi2.data_ptr(), w_kuu.data_ptr(), g_v.data_ptr(),
+                                    _lib.PREC[prec], ws.data_ptr(), wsb, dmu.data_ptr(), ds.data_ptr(), dz.data_ptr(),
+                                    dg.data_ptr(), _stream()), 'dpgp_elbo_grad_psi')
+    return dmu, ds, dz, dg

@@ -152,6 +152,17 @@ int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *alpha, const 
                          void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v, double *d_alpha_beta,
                          int *info, void *stream);
 
+/* Backward pass, stage B (first version): second streaming pass over the observations — the derivatives of
+ * <g_psi2, Psi2> + <g_v, Psi1^T y> + <d f_hat / d K_uu, K_uu> (reference forward: src/kernels/rbf_kernel.py:58-199) with
+ * respect to mu[N,Q], the diagonal q(X) variances s[N,Q], z[M,Q] and gamma[D,Q], given the stage-A adjoints.  alpha is a
+ * constant factor here (its derivative is complete in d_alpha_beta of stage A).  prec = DPGP_PREC_MIXED (fp32
+ * arithmetic, fp64 reductions) or DPGP_PREC_F64; M <= 128.  ws: dpgp_elbo_grad_psi_workspace_bytes(D,N,M,Q).                */
+size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q);
+int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                       const double *s, const double *gamma, const double *alpha, const double *g_psi2,
+                       const double *w_kuu, const double *g_v, int prec, void *ws, size_t ws_bytes, double *d_mu,
+                       double *d_s, double *d_z, double *d_gamma, void *stream);
+
 void *dpgp_event_create(void);
 void dpgp_event_destroy(void *event);
 float dpgp_event_elapsed_ms(void *begin, void *end);

@@ -125,6 +125,18 @@ def chain_adjoints(y, z, mu, s, gamma, alpha, beta, jitter=GP_DEFAULT_JITTER):
                 k_uu=k_uu.detach().numpy(), psi2=p2.detach().numpy(), v=v.detach().numpy())
 
 
+def fhat_input_gradients(y, z, mu, s, gamma, alpha, beta, jitter=GP_DEFAULT_JITTER):
+    """d f_hat / d (mu, s, z, gamma, alpha, beta) by autograd (NumPy in / out): what stages A + B of the HIP backward pass
+    must deliver together."""
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)).clone().requires_grad_(True)
+    yt = torch.as_tensor(np.asarray(y, dtype=np.float64))
+    zt, mt, st, gt = t(z), t(mu), t(s), t(gamma)
+    at, bt = t(np.asarray(alpha).reshape(-1)), t(np.asarray(beta).reshape(-1))
+    f = torch.sum(fhat(yt, zt, mt, st, gt, at, bt, jitter=jitter))
+    g = torch.autograd.grad(f, [mt, st, zt, gt, at, bt])
+    return dict(zip(['d_mu', 'd_s', 'd_z', 'd_gamma', 'd_alpha', 'd_beta'], [a.numpy() for a in g]), f_hat=float(f))
+
+
 def objective(y, raw, s_1=1.0, s_2=1.0, mask_size=1, jitter=GP_DEFAULT_JITTER):
     """dp_gp_lvm.py:100-154 as a function of the raw variables; returns (objective, dict of pieces)."""
     mu, z = raw['x_mean'], raw['x_u']

@@ -48,3 +48,29 @@ def test_chain_adjoints(dev, fixture, prec):
     close(gv.cpu().numpy()[:, :m], ref['g_v'], 'd f_hat / d Psi1^T y')
     close(dab.cpu().numpy()[:, 0], ref['d_alpha'], 'd f_hat / d alpha')
     close(dab.cpu().numpy()[:, 1], ref['d_beta'], 'd f_hat / d beta')
+
+
+@pytest.mark.parametrize('fixture', ['grad_ref_40_6_12_3_T4', 'grad_ref_60_10_15_4_T5'])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_fhat_gradients_wrt_kernel_inputs(dev, fixture, prec):
+    """Stages A + B: d f_hat / d (mu, S, z, gamma, alpha, beta) against autograd of the oracle."""
+    p = point(fixture)
+    ref = ot.fhat_input_gradients(p['y'], p['z'], p['mu'], p['s'], p['gamma'], p['alpha'], p['beta'])
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    n, d = p['y'].shape
+    m, q = p['z'].shape
+    w = ops.ElboWorkspace(d, n, m, q, prec, dev)
+    args = [t(p[k]) for k in ('y', 'z', 'mu', 's', 'gamma', 'alpha', 'beta')]
+    ops.elbo_fhat(*args, prec=prec, workspace=w)
+    gp, wk, gv, dab, info = ops.elbo_grad_chain(args[5], args[6], w)
+    dmu, ds, dz, dg = ops.elbo_grad_psi(args[0], args[1], args[2], args[3], args[4], args[5], gp, wk, gv, prec=prec)
+    tol = 1e-8 if prec == 'f64' else 3e-4
+
+    def close(got, want, what):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=tol, atol=tol * np.abs(want).max(), err_msg=what)
+    close(dmu, ref['d_mu'], 'd f_hat / d mu')
+    close(ds, ref['d_s'], 'd f_hat / d S')
+    close(dz, ref['d_z'], 'd f_hat / d z')
+    close(dg, ref['d_gamma'], 'd f_hat / d gamma')
+    close(dab[:, 0], ref['d_alpha'], 'd f_hat / d alpha')
+    close(dab[:, 1], ref['d_beta'], 'd f_hat / d beta')
