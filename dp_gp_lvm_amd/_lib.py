@@ -40,6 +40,7 @@ SIGNATURES = {
     'dpgp_model_prepare': (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
     'dpgp_model_scal_count': (_i, [_i]),
+    'dpgp_model_backward': (_i, [_i] * 8 + [_vp] * 10 + [_d, _d, _i] + [_vp] * 15 + [_vp]),
     'dpgp_model_pack': (_i, [_i, _vp, _vp, _vp, _vp]),
     'dpgp_model_finalize': (_i, [_vp, _vp, _vp, _vp, _vp]),
 }

@@ -356,6 +356,196 @@ __global__ void model_pack_kernel(const double *__restrict__ fhat, const double 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Model-level backward pass (stage C, first version): d objective / d (the reference's eleven raw trainable variables)
+// from d f_hat / d (mu, S, z, gamma, alpha, beta) of stages A + B.  objective = DP objective - (f_hat - KL) - hyper-prior
+// (dp_gp_lvm.py:148-154) with gamma = phi gamma_atoms etc. (:100-102), phi = softmax(logits) (dirichlet_process.py:40-51),
+// S, atoms, q(V), q(alpha) parameters = softplus(raw) (utils/types.py:40-72).  Outputs are this GPU's PARTIAL sums over its
+// output dims; the D-independent terms (KL, hyper-prior, E[log p(V|alpha)], E[log p(alpha)], entropies of q(V), q(alpha))
+// are added iff add_constants (exactly one rank), so that a sum-all-reduce of the outputs gives the gradient.
+//   block 0            : atoms, q(V), q(alpha)           (thread = (stick t, column j), loops over the local output dims)
+//   blocks 1..nlb      : logits rows (thread = one mask group of output dims)
+//   remaining blocks   : x_mean, x_var_raw, x_u element-wise
+// ---------------------------------------------------------------------------------------------------------------
+__device__ double trigamma_d(double x) {
+    double r = 0.0;
+    while (x < 6.0) { r += 1.0 / (x * x); x += 1.0; }
+    const double f = 1.0 / (x * x);
+    return r + 1.0 / x + 0.5 * f + (1.0 / x) * f * (1.0 / 6.0 - f * (1.0 / 30.0 - f * (1.0 / 42.0 - f * (1.0 / 30.0))));
+}
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+__global__ __launch_bounds__(256) void model_backward_kernel(
+    int D, int T, int Q, int N, int M, int d_offset, int mask_size, int nlb, const double *__restrict__ logits,
+    const double *__restrict__ gat_raw, const double *__restrict__ aat_raw, const double *__restrict__ bat_raw,
+    const double *__restrict__ s_raw, const double *__restrict__ g1_raw, const double *__restrict__ g2_raw,
+    const double *__restrict__ w_raw, const double *__restrict__ x_mean, const double *__restrict__ phi, double s1,
+    double s2, int add_constants, const double *__restrict__ df_dmu, const double *__restrict__ df_ds,
+    const double *__restrict__ df_dz, const double *__restrict__ df_dgamma, const double *__restrict__ df_dab,
+    double *__restrict__ d_x_mean, double *__restrict__ d_s_raw, double *__restrict__ d_x_u,
+    double *__restrict__ d_logits, double *__restrict__ d_g1_raw, double *__restrict__ d_g2_raw,
+    double *__restrict__ d_w_raw, double *__restrict__ d_gat_raw, double *__restrict__ d_aat_raw,
+    double *__restrict__ d_bat_raw) {
+    const int t = threadIdx.x;
+    __shared__ double gat[PREP_MAX_T * DPGP_MAX_Q], aat[PREP_MAX_T], bat[PREP_MAX_T];
+    __shared__ double c1[PREP_MAX_T], c2cum[PREP_MAX_T + 1], scratch[8];
+    if ((int)blockIdx.x > nlb) {                       // element-wise part
+        const size_t nq = (size_t)N * Q, mq = (size_t)M * Q;
+        const int nb = gridDim.x - 1 - nlb;
+        for (size_t i = (size_t)(blockIdx.x - 1 - nlb) * 256 + t; i < nq + mq; i += (size_t)nb * 256) {
+            if (i < nq) {
+                const double sv = softplus_d(s_raw[i]);
+                d_x_mean[i] = -df_dmu[i] + (add_constants ? x_mean[i] : 0.0);                   // KL: gp_expressions.py:10-24
+                d_s_raw[i] = (-df_ds[i] + (add_constants ? 0.5 * (1.0 - 1.0 / sv) : 0.0)) * sigmoid_d(s_raw[i]);
+            } else {
+                d_x_u[i - nq] = -df_dz[i - nq];
+            }
+        }
+        return;
+    }
+    for (int i = t; i < T * Q; i += 256) gat[i] = softplus_d(gat_raw[i]);
+    if (t < T) {
+        aat[t] = softplus_d(aat_raw[t]);
+        bat[t] = softplus_d(bat_raw[t]);
+    }
+    if (t == 0) {                                       // c1_k = psi(g1)-psi(g1+g2); c2cum_k = sum_{k' < k} (psi(g2)-psi(g1+g2))
+        double cum = 0.0;
+        for (int k = 0; k < T; ++k) {
+            c2cum[k] = cum;
+            if (k < T - 1) {
+                const double g1 = softplus_d(g1_raw[k]), g2 = softplus_d(g2_raw[k]), p12 = digamma_d(g1 + g2);
+                c1[k] = digamma_d(g1) - p12;
+                cum += digamma_d(g2) - p12;
+            } else {
+                c1[k] = 0.0;
+            }
+        }
+        c2cum[T] = cum;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        const int cols = Q + 4;                          // j < Q: gamma atoms; Q: alpha atoms; Q+1: beta atoms; Q+2: g1; Q+3: g2
+        for (int e = t; e < T * cols; e += 256) {
+            const int k = e / cols, j = e - k * cols;
+            double acc = 0.0;
+            if (j <= Q + 2) {
+                for (int d = 0; d < D; ++d) {
+                    const double p = phi[(size_t)d * T + k];
+                    acc += p * (j < Q ? df_dgamma[(size_t)d * Q + j] : (j == Q ? df_dab[2 * d] : (j == Q + 1 ? df_dab[2 * d + 1] : 1.0)));
+                }
+            } else {
+                for (int d = 0; d < D; ++d) {            // sum_d tail[d,k], tail = sum_{k' > k} phi
+                    double tl = 0.0;
+                    for (int kk = k + 1; kk < T; ++kk) tl += phi[(size_t)d * T + kk];
+                    acc += tl;
+                }
+            }
+            if (j <= Q + 1) {
+                const double raw = j < Q ? gat_raw[k * Q + j] : (j == Q ? aat_raw[k] : bat_raw[k]);
+                const double x = softplus_d(raw);
+                const double hyp = add_constants ? (1.0 / x + log(x) / x) : 0.0;               // -d/dx log_normal.log_pdf(x)
+                const double g = (-acc + hyp) * sigmoid_d(raw);
+                if (j < Q) d_gat_raw[k * Q + j] = g;
+                else if (j == Q) d_aat_raw[k] = g;
+                else d_bat_raw[k] = g;
+            }
+        }
+        __syncthreads();
+        // q(V): thread k < T-1 needs sum_d phi[d,k] and sum_d tail[d,k]: recompute (cheap) rather than pass through LDS
+        if (t < T - 1) {
+            const int k = t;
+            double sphi = 0.0, stail = 0.0;
+            for (int d = 0; d < D; ++d) {
+                sphi += phi[(size_t)d * T + k];
+                for (int kk = k + 1; kk < T; ++kk) stail += phi[(size_t)d * T + kk];
+            }
+            const double g1 = softplus_d(g1_raw[k]), g2 = softplus_d(g2_raw[k]);
+            const double t1 = trigamma_d(g1), t2 = trigamma_d(g2), t12 = trigamma_d(g1 + g2);
+            double e1 = sphi * (t1 - t12) - stail * t12, e2 = -sphi * t12 + stail * (t2 - t12);
+            if (add_constants) {
+                const double w1 = softplus_d(w_raw[0]), w2 = softplus_d(w_raw[1]), r = w1 / w2 - 1.0;
+                e1 += -r * t12 - (g1 - 1.0) * t1 + (g1 + g2 - 2.0) * t12;
+                e2 += r * (t2 - t12) - (g2 - 1.0) * t2 + (g1 + g2 - 2.0) * t12;
+            }
+            d_g1_raw[k] = -e1 * sigmoid_d(g1_raw[k]);
+            d_g2_raw[k] = -e2 * sigmoid_d(g2_raw[k]);
+        }
+        if (t == 0) {
+            double e1 = 0.0, e2 = 0.0;
+            if (add_constants) {
+                const double w1 = softplus_d(w_raw[0]), w2 = softplus_d(w_raw[1]), tw = trigamma_d(w1), sc2 = c2cum[T];
+                e1 = (T - 1.0) * tw + sc2 / w2 + (s1 - 1.0) * tw - s2 / w2 + 1.0 + (1.0 - w1) * tw;
+                e2 = -(T - 1.0) / w2 - (w1 / (w2 * w2)) * sc2 - (s1 - 1.0) / w2 + s2 * w1 / (w2 * w2) - 1.0 / w2;
+            }
+            d_w_raw[0] = -e1 * sigmoid_d(w_raw[0]);
+            d_w_raw[1] = -e2 * sigmoid_d(w_raw[1]);
+        }
+        return;
+    }
+    // ---- logits rows touched by the local output dims: thread = mask group ----
+    const int r0 = d_offset / mask_size, r1 = (d_offset + D - 1) / mask_size;
+    const int r = r0 + ((int)blockIdx.x - 1) * 256 + t;
+    if (r > r1) return;
+    const int dlo = max(r * mask_size, d_offset) - d_offset, dhi = min((r + 1) * mask_size, d_offset + D) - d_offset;
+    for (int k = 0; k < T; ++k) d_logits[(size_t)r * T + k] = 0.0;
+    for (int d = dlo; d < dhi; ++d) {
+        const double *ph = phi + (size_t)d * T;
+        const double *dg = df_dgamma + (size_t)d * Q;
+        const double da = df_dab[2 * d], db = df_dab[2 * d + 1];
+        auto gk = [&](int k) {
+            double mix = da * aat[k] + db * bat[k];
+            for (int q = 0; q < Q; ++q) mix += dg[q] * gat[k * Q + q];
+            // d DP objective / d phi = -( [k < T-1] c1_k + sum_{k' < k} c2_k' - log phi - 1 )
+            return -mix - (c1[k] + c2cum[k] - log(ph[k]) - 1.0);
+        };
+        double sdot = 0.0;
+        for (int k = 0; k < T; ++k) sdot += ph[k] * gk(k);
+        for (int k = 0; k < T; ++k) d_logits[(size_t)r * T + k] += ph[k] * (gk(k) - sdot);
+    }
+}
+
+extern "C" int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offset, int mask_size, int logits_rows,
+                                   const double *logits, const double *gamma_atoms_raw, const double *alpha_atoms_raw,
+                                   const double *beta_atoms_raw, const double *s_raw, const double *g1_raw,
+                                   const double *g2_raw, const double *w_raw, const double *x_mean, const double *phi,
+                                   double s1, double s2, int add_constants, const double *df_dmu, const double *df_ds,
+                                   const double *df_dz, const double *df_dgamma, const double *df_dalpha_beta,
+                                   double *d_x_mean, double *d_s_raw, double *d_x_u, double *d_logits, double *d_g1_raw,
+                                   double *d_g2_raw, double *d_w_raw, double *d_gamma_atoms_raw,
+                                   double *d_alpha_atoms_raw, double *d_beta_atoms_raw, void *stream) {
+    if (D <= 0) return -1;
+    if (T <= 0 || T > PREP_MAX_T) return -2;
+    if (Q <= 0 || Q > DPGP_MAX_Q) return -3;
+    if (N <= 0) return -4;
+    if (M <= 0) return -5;
+    if (d_offset < 0) return -6;
+    if (mask_size <= 0) return -7;
+    if (logits_rows <= 0 || (d_offset + D - 1) / mask_size >= logits_rows) return -8;
+    const void *ins[] = {logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw, g1_raw, g2_raw, w_raw, x_mean, phi};
+    for (int i = 0; i < 10; ++i)
+        if (!ins[i] && !(T == 1 && (i == 5 || i == 6))) return -(9 + i);
+    if (!(s1 > 0.0)) return -19;
+    if (!(s2 > 0.0)) return -20;
+    const void *gs[] = {df_dmu, df_ds, df_dz, df_dgamma, df_dalpha_beta};
+    for (int i = 0; i < 5; ++i)
+        if (!gs[i]) return -(22 + i);
+    void *outs[] = {d_x_mean, d_s_raw, d_x_u, d_logits, d_g1_raw, d_g2_raw, d_w_raw, d_gamma_atoms_raw, d_alpha_atoms_raw,
+                    d_beta_atoms_raw};
+    for (int i = 0; i < 10; ++i)
+        if (!outs[i] && !(T == 1 && (i == 4 || i == 5))) return -(27 + i);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(d_logits, 0, sizeof(double) * (size_t)logits_rows * T, st) != hipSuccess) return DPGP_ERR_LAUNCH;
+    const int rows = (d_offset + D - 1) / mask_size - d_offset / mask_size + 1, nlb = dpgp_ceil_div(rows, 256);
+    int neb = dpgp_ceil_div(N * Q + M * Q, 256 * 4);
+    if (neb > 1024) neb = 1024;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_backward_kernel, dim3(1 + nlb + neb), dim3(256), 0, st, D, T, Q, N, M, d_offset, mask_size, nlb,
+                       logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw, g1_raw, g2_raw, w_raw, x_mean, phi, s1, s2,
+                       add_constants, df_dmu, df_ds, df_dz, df_dgamma, df_dalpha_beta, d_x_mean, d_s_raw, d_x_u, d_logits,
+                       d_g1_raw, d_g2_raw, d_w_raw, d_gamma_atoms_raw, d_alpha_atoms_raw, d_beta_atoms_raw);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
 extern "C" int dpgp_model_scal_count(int D) { return D > 0 ? 2 + dpgp_ceil_div(D, PREP_ROWS) : 0; }
 
 extern "C" int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,

@@ -147,6 +147,55 @@ def dp_gp_lvm(y_train,
                                                out.data_ptr(), st), 'dpgp_model_finalize')
         return out
 
+    grad_names = ('x_mean', 'x_var', 'x_u', 'dp_logits', 'dp_gamma_1', 'dp_gamma_2', 'dp_w', 'gamma_atoms', 'alpha_atoms',
+                  'beta_atoms')
+
+    def _gradients():
+        """d objective / d (raw trainable variables) — what tf.gradients(objective, trainable variables) gives the
+        reference's optimiser (test/synthetic_data_hard_test.py:143-155).  First version of the backward pass: one forward
+        evaluation, then dpgp_elbo_grad_chain, dpgp_elbo_grad_psi and dpgp_model_backward; sharded over D, the per-GPU
+        partial gradients are packed into one buffer and sum-all-reduced.  Returns {name: tensor} keyed like ``raw``."""
+        assert precision in ('mixed', 'f64'), 'the backward pass exists for precision mixed and f64'
+        lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+        evaluate()
+        r = dp_model.raw
+        gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER)
+        dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
+                                            prec=precision)
+        rows = r['logits'].shape[0]
+        sizes = [num_samples * num_latent_dims, num_samples * num_latent_dims, num_inducing_points * num_latent_dims,
+                 rows * truncation_level, max(truncation_level - 1, 1), max(truncation_level - 1, 1), 2,
+                 truncation_level * num_latent_dims, truncation_level, truncation_level]
+        flat = torch.zeros(sum(sizes), **f64)
+        parts = list(torch.split(flat, sizes))
+        t_ = truncation_level
+        _lib.check(lib.dpgp_model_backward(
+            d_local, t_, num_latent_dims, num_samples, num_inducing_points, d_lo, mask_size, rows, r['logits'].data_ptr(),
+            gamma_atoms_raw.data_ptr(), sig_var_atoms_raw.data_ptr(), beta_atoms_raw.data_ptr(), x_var_raw.data_ptr(),
+            r['gamma_1'].data_ptr(), r['gamma_2'].data_ptr(), r['w'].data_ptr(), x_mean.data_ptr(), buf['phi'].data_ptr(),
+            s_1, s_2, 1 if rank == 0 else 0, dmu.data_ptr(), ds.data_ptr(), dz.data_ptr(), dg.data_ptr(), dab.data_ptr(),
+            *[p_.data_ptr() for p_ in parts], st), 'dpgp_model_backward')
+        if sharded:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)      # one packed exchange (N Q x 2 + M Q + ...)
+        shapes = [x_mean.shape, x_var_raw.shape, x_u.shape, r['logits'].shape, r['gamma_1'].shape, r['gamma_2'].shape,
+                  r['w'].shape, gamma_atoms_raw.shape, sig_var_atoms_raw.shape, beta_atoms_raw.shape]
+        return {k: p_[:int(np.prod(sh))].reshape(sh) for k, p_, sh in zip(grad_names, parts, shapes)}
+
+    def _optimise(num_iterations, learning_rate=0.01, callback=None):
+        """Adam on the raw variables with the HIP gradients (the reference: tf.train.AdamOptimizer(...).minimize(objective),
+        test/synthetic_data_hard_test.py:143-155).  torch.optim.Adam only applies the update (plumbing)."""
+        params = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, dp_logits=dp_model.raw['logits'],
+                      dp_gamma_1=dp_model.raw['gamma_1'], dp_gamma_2=dp_model.raw['gamma_2'], dp_w=dp_model.raw['w'],
+                      gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw, beta_atoms=beta_atoms_raw)
+        opt = torch.optim.Adam(list(params.values()), lr=learning_rate)
+        for it in range(num_iterations):
+            g = _gradients()
+            for k, p_ in params.items():
+                p_.grad = g[k].reshape(p_.shape).clone()
+            opt.step()
+            if callback is not None:
+                callback(it)
+
     def _mixed():
         phi = dp_model.assignments                                               # [D x T], all output dims
         return (phi @ F.softplus(gamma_atoms_raw), phi @ F.softplus(sig_var_atoms_raw), phi @ F.softplus(beta_atoms_raw))
@@ -210,6 +259,8 @@ def dp_gp_lvm(y_train,
             return workspace.terms, workspace.info
 
         evaluate_ = staticmethod(evaluate)
+        gradients = staticmethod(_gradients)
+        optimise = staticmethod(_optimise)
 
         @staticmethod
         def predict_new_latent_variables(y_test, use_pca=False):

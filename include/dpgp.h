@@ -185,6 +185,19 @@ int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, 
                        const double *s_raw, const double *g1_raw, const double *g2_raw, const double *w_raw, double s1,
                        double s2, int add_constants, double *gamma, double *alpha, double *beta, double *s, double *phi,
                        double *scal, void *stream);
+/* Model-level backward pass (first version): d objective / d (the reference's eleven raw trainable variables,
+ * dp_gp_lvm.py:63-94, dirichlet_process.py:40-59) from d f_hat / d (mu, S, z, gamma, alpha, beta) of dpgp_elbo_grad_chain +
+ * dpgp_elbo_grad_psi, for the D output dims resident on this GPU.  phi[D,T]: as written by dpgp_model_prepare.  Outputs are
+ * PARTIAL over this GPU's output dims, the D-independent terms being added iff add_constants (exactly one rank): a
+ * sum-all-reduce of the outputs is the gradient.  d_logits[logits_rows][T] is zero outside the rows of the local dims.  */
+int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offset, int mask_size, int logits_rows,
+                        const double *logits, const double *gamma_atoms_raw, const double *alpha_atoms_raw,
+                        const double *beta_atoms_raw, const double *s_raw, const double *g1_raw, const double *g2_raw,
+                        const double *w_raw, const double *x_mean, const double *phi, double s1, double s2,
+                        int add_constants, const double *df_dmu, const double *df_ds, const double *df_dz,
+                        const double *df_dgamma, const double *df_dalpha_beta, double *d_x_mean, double *d_s_raw,
+                        double *d_x_u, double *d_logits, double *d_g1_raw, double *d_g2_raw, double *d_w_raw,
+                        double *d_gamma_atoms_raw, double *d_alpha_atoms_raw, double *d_beta_atoms_raw, void *stream);
 int dpgp_model_pack(int D, const double *fhat, const double *scal, double *pack, void *stream);
 int dpgp_model_finalize(const double *pack, const double *kl, const double *hyper, double *out, void *stream);
 
