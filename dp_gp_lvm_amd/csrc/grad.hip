@@ -211,6 +211,8 @@ template int launch_chain_grad<double>(int, int, int, const double *, int, const
 //   log psi2 = 2 log alpha - sum_q [ 1/2 log den2 + 1/4 gamma (z_a - z_m')^2 + gamma (mu - (z_a + z_m')/2)^2 / den2 ],  den2 = 2 gamma S + 1
 //   log psi1 =   log alpha - 1/2 sum_q [ log den1 + gamma (mu - z_a)^2 / den1 ],                                       den1 = gamma S + 1
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ double pg_exp(double x) { return exp(x); }
 // QP: latent dims padded to a multiple of 4 (compile time, so that the per-thread q-arrays stay in registers)
 template <typename TC, int QP>
 __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int Mp, int Q, const double *__restrict__ y, int ldy,
@@ -226,6 +228,9 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
     TC *zs = gs + (size_t)Mp * (Mp + 1);                       // [Mp][QP], zero padded
     TC *red = zs + (size_t)Mp * QP;                             // [2][7 Q + 2][128] per-observation partial sums
     TC *nq = red + (size_t)2 * (7 * Q + 2) * 128;              // [2][6][Q] per-observation per-q factors
+    TC *pbuf = nq + (size_t)12 * Q;                            // [2][128] per-observation P[n, m] (see below)
+    TC *zcs = pbuf + 256;                                      // [32] column means of z (everything works on centred z, mu)
+    TC *rsum = zcs + 32;                                       // [2][7 Q + 2] sums over the rows of `red`
     const int d = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y, t = threadIdx.x, a = t & 127, nl = t >> 7;
     const int NV = 7 * Q + 2;
     const TC al = (TC)alpha[d];
@@ -234,9 +239,24 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
         const double v = (i < M && j < M) ? GP[(size_t)d * Mp * Mp + (size_t)(i >= j ? i : j) * Mp + (i >= j ? j : i)] : 0.0;
         gs[i * (Mp + 1) + j] = (TC)v;
     }
+    {   // column means (fp64 partial sums through the `red` area, which is free here)
+        double *sc = reinterpret_cast<double *>(red);
+        const int q = t & 31, rg = t >> 5;
+        double acc = 0.0;
+        if (q < Q)
+            for (int m_ = rg; m_ < M; m_ += 8) acc += z[(size_t)m_ * Q + q];
+        sc[rg * 32 + q] = acc;
+        __syncthreads();
+        if (t < 32) {
+            double v = 0.0;
+            for (int k = 0; k < 8; ++k) v += sc[k * 32 + t];
+            zcs[t] = (t < Q) ? (TC)(v / (double)M) : (TC)0;
+        }
+        __syncthreads();
+    }
     for (int e = t; e < Mp * QP; e += 256) {
         const int i = e / QP, q = e - i * QP;
-        zs[e] = (i < M && q < Q) ? (TC)z[(size_t)i * Q + q] : (TC)0;
+        zs[e] = (i < M && q < Q) ? (TC)(z[(size_t)i * Q + q] - (double)zcs[q]) : (TC)0;
     }
     __syncthreads();
     TC ga[QP], za[QP], dza[QP];
@@ -257,7 +277,8 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
             const int l = t / Q, q = t - l * Q, nn = n0 + l;
             TC *o = nq + (l * 6) * Q + q;
             if (nn < nend) {
-                const TC g = (TC)gamma[(size_t)d * Q + q], ss = (TC)s[(size_t)nn * Q + q], m_ = (TC)mu[(size_t)nn * Q + q];
+                const TC g = (TC)gamma[(size_t)d * Q + q], ss = (TC)s[(size_t)nn * Q + q];
+                const TC m_ = (TC)(mu[(size_t)nn * Q + q] - (double)zcs[q]);
                 const TC den2 = 2 * g * ss + 1, den1 = g * ss + 1;
                 o[0] = g / den2; o[Q] = g / den1; o[2 * Q] = m_; o[3 * Q] = ss;
                 o[4 * Q] = dpgp_log(den2); o[5 * Q] = dpgp_log(den1);
@@ -276,21 +297,33 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
             a2[q] = in ? f[q] : (TC)0; a1v[q] = in ? f[Q + q] : (TC)0; mq[q] = in ? f[2 * Q + q] : (TC)0;
             l2 += in ? f[4 * Q + q] : (TC)0; l1 += in ? f[5 * Q + q] : (TC)0;
         }
+        // log psi2(n,a,m') = P[a] + P[m'] + sum_q X_q z_aq z_m'q with (centred z, mu)
+        //   X_q = (gamma_q - a2_q) / 2,   P[m] = const_n / 2 - sum_q ( (gamma_q + a2_q) z_mq^2 / 4 - a2_q mu_q z_mq ),
+        //   const_n = 2 log alpha - 1/2 sum_q log den2_q - sum_q a2_q mu_q^2
+        // (the expansion the forward kernel uses): the inner loop is one dot product per (a, m') instead of ~7 Q flops
+        TC cn = 2 * dpgp_log(al) - (TC)0.5 * l2, pa = 0, xz[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            cn -= a2[q] * mq[q] * mq[q];
+            pa -= (TC)0.25 * (ga[q] + a2[q]) * za[q] * za[q] - a2[q] * mq[q] * za[q];
+            xz[q] = (TC)0.5 * (ga[q] - a2[q]) * za[q];
+        }
+        pa += (TC)0.5 * cn;
+        pbuf[nl * 128 + a] = pa;
+        __syncthreads();
         TC R = 0, T[QP];
 #pragma unroll
         for (int q = 0; q < QP; ++q) T[q] = 0;
         TC w1 = 0;
         if (live && a < M) {
-            const TC pref = 2 * dpgp_log(al) - (TC)0.5 * l2;
             for (int mp = 0; mp < M; ++mp) {
-                TC e = pref, zm[QP];
+                TC e = pa + pbuf[nl * 128 + mp], zm[QP];
 #pragma unroll
                 for (int q = 0; q < QP; ++q) {
                     zm[q] = zs[mp * QP + q];
-                    const TC dz_ = za[q] - zm[q], c = mq[q] - (TC)0.5 * (za[q] + zm[q]);
-                    e -= (TC)0.25 * ga[q] * dz_ * dz_ + a2[q] * c * c;
+                    e += xz[q] * zm[q];
                 }
-                const TC w = gs[mp * (Mp + 1) + a] * exp(e);
+                const TC w = gs[mp * (Mp + 1) + a] * pg_exp(e);
                 R += w;
 #pragma unroll
                 for (int q = 0; q < QP; ++q) T[q] += w * zm[q];
@@ -298,7 +331,7 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
             TC e1 = dpgp_log(al) - (TC)0.5 * l1;
 #pragma unroll
             for (int q = 0; q < QP; ++q) { const TC c = mq[q] - za[q]; e1 -= (TC)0.5 * a1v[q] * c * c; }
-            w1 = gva * (TC)y[(size_t)n * ldy + d] * exp(e1);
+            w1 = gva * (TC)y[(size_t)n * ldy + d] * pg_exp(e1);
 #pragma unroll
             for (int q = 0; q < QP; ++q) {
                 // gamma (1 +- 1 / den2) = gamma +- a2
@@ -320,17 +353,21 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
                 rp[(size_t)(4 * Q + 2 + q) * 128] = w1 * za[q] * za[q];
             }
         __syncthreads();
-        // thread (l, q) finishes observation l, latent dim q
+        // the 2 (5 Q + 2) column sums over the rows, one per thread; then thread (l, q) finishes observation l, latent dim q
+        for (int e = t; e < 2 * (5 * Q + 2); e += 256) {
+            const int l = e / (5 * Q + 2), v = e - l * (5 * Q + 2);
+            const TC *r0 = red + ((size_t)l * NV + v) * 128;
+            TC acc = 0;
+            for (int k = 0; k < 128; ++k) acc += r0[k];
+            rsum[l * NV + v] = acc;
+        }
+        __syncthreads();
         if (t < 2 * Q) {
             const int l = t / Q, q = t - l * Q, nn = n0 + l;
             if (nn < nend) {
-                const TC *r0 = red + (size_t)l * NV * 128;
-                TC S0 = 0, S1 = 0, S2 = 0, S3 = 0, V0 = 0, V1 = 0, V2 = 0;
-                for (int k = 0; k < 128; ++k) {
-                    S0 += r0[k]; S1 += r0[(size_t)(1 + q) * 128 + k]; S2 += r0[(size_t)(1 + Q + q) * 128 + k];
-                    S3 += r0[(size_t)(1 + 2 * Q + q) * 128 + k]; V0 += r0[(size_t)(3 * Q + 1) * 128 + k];
-                    V1 += r0[(size_t)(3 * Q + 2 + q) * 128 + k]; V2 += r0[(size_t)(4 * Q + 2 + q) * 128 + k];
-                }
+                const TC *r0 = rsum + (size_t)l * NV;
+                const TC S0 = r0[0], S1 = r0[1 + q], S2 = r0[1 + Q + q], S3 = r0[1 + 2 * Q + q], V0 = r0[3 * Q + 1],
+                         V1 = r0[3 * Q + 2 + q], V2 = r0[4 * Q + 2 + q];
                 const TC *o = nq + (l * 6) * Q + q;
                 const TC a2_ = o[0], a1_ = o[Q], m_ = o[2 * Q], ss = o[3 * Q], g = (TC)gamma[(size_t)d * Q + q];
                 const TC id2 = a2_ / g, id1 = a1_ / g;                       // 1 / den2, 1 / den1
@@ -429,7 +466,7 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
     double *dmu_part = ws, *ds_part = dmu_part + (size_t)D * N * Q, *dz_part = ds_part + (size_t)D * N * Q,
            *dg_part = dz_part + (size_t)D * ns * M * Q;
     const int QPr = 4 * dpgp_ceil_div(Q, 4);
-    const size_t lds = sizeof(TC) * ((size_t)Mp * (Mp + 1) + (size_t)Mp * QPr + (size_t)2 * (7 * Q + 2) * 128 + (size_t)12 * Q);
+    const size_t lds = sizeof(TC) * ((size_t)Mp * (Mp + 1) + (size_t)Mp * QPr + (size_t)2 * (7 * Q + 2) * 128 + (size_t)12 * Q + 256 + 32 + (size_t)2 * (7 * Q + 2));
     void (*kern)(int, int, int, int, int, const double *, int, const double *, const double *, const double *, const double *,
                  const double *, const double *, const double *, const double *, int, double *, double *, double *, double *) = nullptr;
     switch (QPr / 4) {

@@ -138,7 +138,6 @@ int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, cons
                       const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                       int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,
                       void *stream, const dpgp_exec_t *exec);
-/* hipEvent helpers for hosts without their own HIP binding */
 /* Backward pass of the fused ELBO, stage A (first version; reference: tf.gradients(objective) as used by every training
  * script, test/synthetic_data_hard_test.py:143-155; the forward it differentiates: src/models/dp_gp_lvm.py:108-145).
  * Adjoints of the per-output dense algebra, computed from the workspace `ws` of a FINISHED dpgp_elbo_fhat[_ex] call with
@@ -163,6 +162,7 @@ int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, con
                        const double *w_kuu, const double *g_v, int prec, void *ws, size_t ws_bytes, double *d_mu,
                        double *d_s, double *d_z, double *d_gamma, void *stream);
 
+/* hipEvent helpers for hosts without their own HIP binding */
 void *dpgp_event_create(void);
 void dpgp_event_destroy(void *event);
 float dpgp_event_elapsed_ms(void *begin, void *end);
