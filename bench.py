@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--prec', default='mixed', choices=['mixed', 'f32', 'f64'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the gram GB/s and Cholesky TFLOP/s side measurements')
+    ap.add_argument('--no-grad', action='store_true', help='skip the objective + gradients side measurement (first-version backward pass)')
     ap.add_argument('--cpu-dims', type=int, default=0, help='output dims in the bounded CPU sample (0 = auto)')
     return ap.parse_args()
 
@@ -231,6 +232,19 @@ def main():
         }
         if world == 1 and not a.no_secondary:
             res['secondary'] = secondary(dev, shape, p)
+        if world == 1 and not a.no_grad and a.prec != 'f32' and m <= 128:
+            # side measurement, not the headline metric: one objective evaluation + the gradients of all raw variables
+            # (first version of the backward pass; what one Adam iteration of the reference needs)
+            for _ in range(2):
+                model.gradients()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                model.gradients()
+            torch.cuda.synchronize()
+            res['objective_and_gradients'] = {'ms': 1e3 * (time.perf_counter() - t0) / reps, 'reps': reps,
+                                              'note': 'first, unoptimised backward pass (plain VALU streaming kernel)'}
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(a.config, p, shape, a.cpu_dims)
         print(json.dumps(res))
