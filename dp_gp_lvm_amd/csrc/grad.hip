@@ -226,13 +226,13 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
     extern __shared__ __align__(16) unsigned char smem_raw[];
     TC *gs = reinterpret_cast<TC *>(smem_raw);                 // [Mp][Mp + 1] symmetric G (then W for the K_uu part)
     TC *zs = gs + (size_t)Mp * (Mp + 1);                       // [Mp][QP], zero padded
-    TC *red = zs + (size_t)Mp * QP;                             // [2][7 Q + 2][128] per-observation partial sums
-    TC *nq = red + (size_t)2 * (7 * Q + 2) * 128;              // [2][6][Q] per-observation per-q factors
+    TC *red = zs + (size_t)Mp * QP;                             // [2][5 Q + 2][128] per-observation partial sums
+    TC *nq = red + (size_t)2 * (5 * Q + 2) * 128;              // [2][6][Q] per-observation per-q factors
     TC *pbuf = nq + (size_t)12 * Q;                            // [2][128] per-observation P[n, m] (see below)
     TC *zcs = pbuf + 256;                                      // [32] column means of z (everything works on centred z, mu)
     TC *rsum = zcs + 32;                                       // [2][7 Q + 2] sums over the rows of `red`
     const int d = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y, t = threadIdx.x, a = t & 127, nl = t >> 7;
-    const int NV = 7 * Q + 2;
+    const int NV = 5 * Q + 2;
     const TC al = (TC)alpha[d];
     for (int e = t; e < Mp * Mp; e += 256) {
         const int i = e / Mp, j = e - i * Mp;
@@ -466,7 +466,7 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
     double *dmu_part = ws, *ds_part = dmu_part + (size_t)D * N * Q, *dz_part = ds_part + (size_t)D * N * Q,
            *dg_part = dz_part + (size_t)D * ns * M * Q;
     const int QPr = 4 * dpgp_ceil_div(Q, 4);
-    const size_t lds = sizeof(TC) * ((size_t)Mp * (Mp + 1) + (size_t)Mp * QPr + (size_t)2 * (7 * Q + 2) * 128 + (size_t)12 * Q + 256 + 32 + (size_t)2 * (7 * Q + 2));
+    const size_t lds = sizeof(TC) * ((size_t)Mp * (Mp + 1) + (size_t)Mp * QPr + (size_t)2 * (5 * Q + 2) * 128 + (size_t)12 * Q + 256 + 32 + (size_t)2 * (7 * Q + 2));
     void (*kern)(int, int, int, int, int, const double *, int, const double *, const double *, const double *, const double *,
                  const double *, const double *, const double *, const double *, int, double *, double *, double *, double *) = nullptr;
     switch (QPr / 4) {
