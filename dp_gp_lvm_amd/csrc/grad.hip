@@ -211,11 +211,12 @@ template int launch_chain_grad<double>(int, int, int, const double *, int, const
 //   log psi2 = 2 log alpha - sum_q [ 1/2 log den2 + 1/4 gamma (z_a - z_m')^2 + gamma (mu - (z_a + z_m')/2)^2 / den2 ],  den2 = 2 gamma S + 1
 //   log psi1 =   log alpha - 1/2 sum_q [ log den1 + gamma (mu - z_a)^2 / den1 ],                                       den1 = gamma S + 1
 // ---------------------------------------------------------------------------------------------------------------
+#define PG_RED_ELEMS(Q) ((size_t)1024)       // wave sums [4][5 Q + 2] <= 608; 256 doubles of column-mean scratch
 __device__ __forceinline__ float pg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ double pg_exp(double x) { return exp(x); }
 // QP: latent dims padded to a multiple of 4 (compile time, so that the per-thread q-arrays stay in registers)
 template <typename TC, int QP>
-__global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int Mp, int Q, const double *__restrict__ y, int ldy,
+__global__ __launch_bounds__(256, 2) void psi_grad_kernel(int D, int N, int M, int Mp, int Q, const double *__restrict__ y, int ldy,
                                                        const double *__restrict__ z, const double *__restrict__ mu,
                                                        const double *__restrict__ s, const double *__restrict__ gamma,
                                                        const double *__restrict__ alpha, const double *__restrict__ GP,
@@ -224,10 +225,10 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
                                                        double *__restrict__ ds_part, double *__restrict__ dz_part,
                                                        double *__restrict__ dg_part) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    TC *gs = reinterpret_cast<TC *>(smem_raw);                 // [Mp][Mp + 1] symmetric G (then W for the K_uu part)
-    TC *zs = gs + (size_t)Mp * (Mp + 1);                       // [Mp][QP], zero padded
-    TC *red = zs + (size_t)Mp * QP;                             // [2][5 Q + 2][128] per-observation partial sums
-    TC *nq = red + (size_t)2 * (5 * Q + 2) * 128;              // [2][6][Q] per-observation per-q factors
+    TC *gs = reinterpret_cast<TC *>(smem_raw);                 // [Mp][Mp] symmetric G (then W for the K_uu part; [2 Q][128] at the very end)
+    TC *zs = gs + (size_t)(Mp * Mp > 2 * Q * 128 ? Mp * Mp : 2 * Q * 128);                       // [Mp][QP], zero padded
+    TC *red = zs + (size_t)Mp * QP;                             // scratch: wave sums [4][5 Q + 2]; 256 doubles (column means)
+    TC *nq = red + PG_RED_ELEMS(Q);              // [2][6][Q] per-observation per-q factors
     TC *pbuf = nq + (size_t)12 * Q;                            // [2][128] per-observation P[n, m] (see below)
     TC *zcs = pbuf + 256;                                      // [32] column means of z (everything works on centred z, mu)
     TC *rsum = zcs + 32;                                       // [2][7 Q + 2] sums over the rows of `red`
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
     for (int e = t; e < Mp * Mp; e += 256) {
         const int i = e / Mp, j = e - i * Mp;
         const double v = (i < M && j < M) ? GP[(size_t)d * Mp * Mp + (size_t)(i >= j ? i : j) * Mp + (i >= j ? j : i)] : 0.0;
-        gs[i * (Mp + 1) + j] = (TC)v;
+        gs[i * Mp + j] = (TC)v;
     }
     {   // column means (fp64 partial sums through the `red` area, which is free here)
         double *sc = reinterpret_cast<double *>(red);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
                     zm[q] = zs[mp * QP + q];
                     e += xz[q] * zm[q];
                 }
-                const TC w = gs[mp * (Mp + 1) + a] * pg_exp(e);
+                const TC w = gs[mp * Mp + a] * pg_exp(e);
                 R += w;
 #pragma unroll
                 for (int q = 0; q < QP; ++q) T[q] += w * zm[q];
@@ -339,27 +340,30 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
                           + w1 * a1v[q] * (mq[q] - za[q]);
             }
         }
-        // partial sums over the rows a: [R | R z | R z^2 | z T | w1 | w1 z | w1 z^2]
-        TC *rp = red + (size_t)nl * NV * 128 + a;
-        rp[0] = R;
-        rp[(size_t)(3 * Q + 1) * 128] = w1;
+        // sums over the rows a of [R | R z | R z^2 | z T | w1 | w1 z | w1 z^2]: wave-level shuffles, then the two waves of
+        // an observation through a few LDS words (staging all of it in LDS cost 53 KB and a second workgroup per CU)
+        {
+            const int wave = t >> 6, lane_ = t & 63;
+            auto put = [&](int v, TC x) {
+                x = wave_sum(x);
+                if (lane_ == 0) red[wave * NV + v] = x;
+            };
+            put(0, R);
+            put(3 * Q + 1, w1);
 #pragma unroll
-        for (int q = 0; q < QP; ++q)
-            if (q < Q) {
-                rp[(size_t)(1 + q) * 128] = R * za[q];
-                rp[(size_t)(1 + Q + q) * 128] = R * za[q] * za[q];
-                rp[(size_t)(1 + 2 * Q + q) * 128] = za[q] * T[q];
-                rp[(size_t)(3 * Q + 2 + q) * 128] = w1 * za[q];
-                rp[(size_t)(4 * Q + 2 + q) * 128] = w1 * za[q] * za[q];
-            }
+            for (int q = 0; q < QP; ++q)
+                if (q < Q) {
+                    put(1 + q, R * za[q]);
+                    put(1 + Q + q, R * za[q] * za[q]);
+                    put(1 + 2 * Q + q, za[q] * T[q]);
+                    put(3 * Q + 2 + q, w1 * za[q]);
+                    put(4 * Q + 2 + q, w1 * za[q] * za[q]);
+                }
+        }
         __syncthreads();
-        // the 2 (5 Q + 2) column sums over the rows, one per thread; then thread (l, q) finishes observation l, latent dim q
-        for (int e = t; e < 2 * (5 * Q + 2); e += 256) {
-            const int l = e / (5 * Q + 2), v = e - l * (5 * Q + 2);
-            const TC *r0 = red + ((size_t)l * NV + v) * 128;
-            TC acc = 0;
-            for (int k = 0; k < 128; ++k) acc += r0[k];
-            rsum[l * NV + v] = acc;
+        for (int e = t; e < 2 * NV; e += 256) {
+            const int l = e / NV, v = e - l * NV;
+            rsum[l * NV + v] = red[(2 * l) * NV + v] + red[(2 * l + 1) * NV + v];
         }
         __syncthreads();
         if (t < 2 * Q) {
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
         for (int e = t; e < Mp * Mp; e += 256) {
             const int i = e / Mp, j = e - i * Mp;
             const double v = (i < M && j < M) ? WK[(size_t)d * Mp * Mp + (size_t)(i >= j ? i : j) * Mp + (i >= j ? j : i)] : 0.0;
-            gs[i * (Mp + 1) + j] = (TC)v;
+            gs[i * Mp + j] = (TC)v;
         }
         __syncthreads();
         TC RK = 0, TK[QP];
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
         for (int q = 0; q < QP; ++q) TK[q] = 0;
         if (nl == 0 && a < M) {
             for (int mp = 0; mp < M; ++mp) {
-                const TC w = gs[mp * (Mp + 1) + a];
+                const TC w = gs[mp * Mp + a];
                 RK += w;
 #pragma unroll
                 for (int q = 0; q < QP; ++q) TK[q] += w * zs[mp * QP + q];
@@ -406,16 +410,19 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
 #pragma unroll
             for (int q = 0; q < QP; ++q) dza[q] += -2 * ga[q] * (za[q] * RK - TK[q]);
         }
-        TC *rp = red + a;
-        if (nl == 0) {
+        {
+            const int wave = t >> 6, lane_ = t & 63;
 #pragma unroll
             for (int q = 0; q < QP; ++q)
-                if (q < Q) rp[(size_t)q * 128] = (a < M) ? (RK * za[q] * za[q] - za[q] * TK[q]) : (TC)0;
+                if (q < Q) {
+                    TC x = (nl == 0 && a < M) ? (RK * za[q] * za[q] - za[q] * TK[q]) : (TC)0;
+                    x = wave_sum(x);
+                    if (lane_ == 0) red[wave * Q + q] = x;
+                }
         }
         __syncthreads();
         if (t < Q) {
-            TC v = 0;
-            for (int k = 0; k < 128; ++k) v += red[(size_t)t * 128 + k];
+            const TC v = red[t] + red[Q + t];                                // (waves 0 and 1 hold the rows; 2 and 3 wrote zeros)
             dgk = -v;                                                        // -1/2 sum wk (z_a - z_m')^2 = -(S2 - S3)
         }
         __syncthreads();
@@ -429,12 +436,12 @@ __global__ __launch_bounds__(256) void psi_grad_kernel(int D, int N, int M, int 
     if (a < M) {
 #pragma unroll
         for (int q = 0; q < QP; ++q)
-            if (q < Q) red[(size_t)(nl * Q + q) * 128 + a] = dza[q];
+            if (q < Q) gs[(size_t)(nl * Q + q) * 128 + a] = dza[q];
     }
     __syncthreads();
     if (nl == 0 && a < M)
         for (int q = 0; q < Q; ++q)
-            dz_part[(((size_t)d * nsplit + sp) * M + a) * Q + q] = (double)(red[(size_t)q * 128 + a] + red[(size_t)(Q + q) * 128 + a]);
+            dz_part[(((size_t)d * nsplit + sp) * M + a) * Q + q] = (double)(gs[(size_t)q * 128 + a] + gs[(size_t)(Q + q) * 128 + a]);
 }
 
 // out[i] = sum_k part[k * n + i], k < nk, fixed order
@@ -466,7 +473,7 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
     double *dmu_part = ws, *ds_part = dmu_part + (size_t)D * N * Q, *dz_part = ds_part + (size_t)D * N * Q,
            *dg_part = dz_part + (size_t)D * ns * M * Q;
     const int QPr = 4 * dpgp_ceil_div(Q, 4);
-    const size_t lds = sizeof(TC) * ((size_t)Mp * (Mp + 1) + (size_t)Mp * QPr + (size_t)2 * (5 * Q + 2) * 128 + (size_t)12 * Q + 256 + 32 + (size_t)2 * (7 * Q + 2));
+    const size_t lds = sizeof(TC) * ((size_t)(Mp * Mp > 2 * Q * 128 ? Mp * Mp : 2 * Q * 128) + (size_t)Mp * QPr + PG_RED_ELEMS(Q) + (size_t)12 * Q + 256 + 32 + (size_t)2 * (7 * Q + 2));
     void (*kern)(int, int, int, int, int, const double *, int, const double *, const double *, const double *, const double *,
                  const double *, const double *, const double *, const double *, int, double *, double *, double *, double *) = nullptr;
     switch (QPr / 4) {
