@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""
+Train a DP-GP-LVM on synthetic data with the HIP forward + backward pass — the flow of the reference's
+test/synthetic_data_hard_test.py:120-172 (build model, Adam on the objective, log every 100 iterations, save the converged
+values under the reference's result keys, src/utils/constants.py:38-72), with `model.optimise` in place of
+`tf.train.AdamOptimizer(...).minimize(objective)` inside a `tf.Session`.
+
+    python examples/train_synthetic.py [--n 200] [--d 24] [--m 30] [--q 5] [--t 8] [--iters 500] [--lr 0.01] [--out result.npz]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    for k, v in dict(n=200, d=24, m=30, q=5, t=8, iters=500, seed=1).items():
+        ap.add_argument('--' + k, type=int, default=v)
+    ap.add_argument('--lr', type=float, default=0.01)
+    ap.add_argument('--precision', default='mixed', choices=['mixed', 'f64'])
+    ap.add_argument('--out', default='')
+    a = ap.parse_args()
+    import torch
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+
+    # three groups of output dims generated from different subsets of a shared latent space (what the DP should recover)
+    rng = np.random.default_rng(a.seed)
+    np.random.seed(a.seed)
+    x = rng.standard_normal((a.n, 3))
+    groups = np.array_split(np.arange(a.d), 3)
+    y = np.empty((a.n, a.d))
+    for gi, idx in enumerate(groups):
+        w = rng.standard_normal((2, len(idx)))
+        y[:, idx] = np.tanh(x[:, [gi, (gi + 1) % 3]]) @ w + 0.05 * rng.standard_normal((a.n, len(idx)))
+    y = (y - y.mean(axis=0)) / y.std(axis=0)
+
+    model = dp_gp_lvm(y_train=y, num_inducing_points=a.m, num_latent_dims=a.q, truncation_level=a.t,
+                      device=torch.device('cuda', 0), precision=a.precision)
+    print('Training DP-GP-LVM: N=%d D=%d M=%d Q=%d T=%d, %d Adam iterations, lr %g' % (a.n, a.d, a.m, a.q, a.t, a.iters, a.lr))
+    t0 = time.time()
+
+    def log(c):
+        if c % 100 == 0:
+            print('  GP-DP opt iter {:5}: {}'.format(c, float(model.objective)))
+    model.optimise(a.iters, learning_rate=a.lr, callback=log)
+    train_opt_time = time.time() - t0
+    print('Final iter {:5}:\n  GP-DP: {}\nTime to optimise: {} s'.format(a.iters - 1, float(model.objective), train_opt_time))
+    x_mean, x_covar = model.q_x
+    gat, aat, bat = model.dp_atoms
+    phi = model.assignments.cpu().numpy()
+    print('group assignment of the output dims (argmax of q(Z)):', phi.argmax(axis=1))
+    if a.out:
+        np.savez(a.out, y_train=y, ard_weights=model.ard_weights.cpu().numpy(), noise_precision=model.noise_precision.cpu().numpy(),
+                 signal_variance=model.signal_variance.cpu().numpy(), x_u=model.inducing_input.cpu().numpy(),
+                 x_mean=x_mean.cpu().numpy(), x_covar=x_covar.cpu().numpy(), assignments=phi, gamma_atoms=gat.cpu().numpy(),
+                 alpha_atoms=aat.cpu().numpy(), beta_atoms=bat.cpu().numpy(), train_opt_time=train_opt_time)
+        print('saved', a.out)
+
+
+if __name__ == '__main__':
+    main()
