@@ -41,7 +41,7 @@ def dp_gp_lvm(y_train,
               truncation_level=DP_DEFAULT_TRUNCATION_LEVEL,
               alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
               mask_size=1,
-              device=None, precision='mixed', process_group=None, initial_values=None):
+              device=None, precision='mixed', process_group=None, initial_values=None, _shard_of=None):
     """
     :param y_train: [N x D] numpy array, columns normalised to zero mean / unit variance (dp_gp_lvm.py:30-32).
     :param num_latent_dims: Q.  :param num_inducing_points: M.  :param truncation_level: T.
@@ -106,6 +106,10 @@ def dp_gp_lvm(y_train,
     if process_group is not None:
         import torch.distributed as dist
         rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    elif _shard_of is not None:
+        # test hook: behave as rank r of w WITHOUT a communicator — objective terms / gradients come back as this
+        # rank's PARTIAL values (what would enter the all-reduce), so that one GPU can check the sharding arithmetic
+        dist, (rank, world) = None, _shard_of
     else:
         dist, rank, world = None, 0, 1
     sharded = process_group is not None          # (a 1-rank group still goes through pack -> all_reduce -> finalize)
@@ -259,6 +263,14 @@ def dp_gp_lvm(y_train,
             return workspace.terms, workspace.info
 
         evaluate_ = staticmethod(evaluate)
+
+        @staticmethod
+        def partial_pack():
+            """(f_hat, DP objective) shares of the local output dims after one evaluation: the 2-vector that is
+            sum-all-reduced when D is sharded (tests of the sharding arithmetic)."""
+            evaluate()
+            return buf['red'].clone()
+
         gradients = staticmethod(_gradients)
         optimise = staticmethod(_optimise)
 

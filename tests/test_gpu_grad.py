@@ -159,3 +159,56 @@ def test_training_trajectory_matches_the_oracle(dev):
             ref_traj.append(float(ot.objective(y, raw, s_1=float(g['s_1']), s_2=float(g['s_2']))[0]))
     np.testing.assert_allclose(hip_traj, ref_traj, rtol=1e-7)
     assert hip_traj[-1] < hip_traj[0]
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharding_arithmetic_on_one_gpu(dev, world):
+    """Rank r of `world` without a communicator (test hook _shard_of): the partial (f_hat, DP objective) pairs and the
+    partial gradients of all ranks add up to the single-GPU values — what the all-reduces of the sharded path compute."""
+    g = golden('grad_ref_60_10_15_4_T5')
+    full = build_model(g, dev, 'f64')
+    terms = full.objective_terms.cpu().numpy()                      # objective, f_hat, KL, DP objective, hyper-prior
+    want = full.gradients()
+    pack = sum(build_model(g, dev, 'f64', _shard_of=(r, world)).partial_pack().cpu().numpy() for r in range(world))
+    np.testing.assert_allclose(pack, [terms[1], terms[3]], rtol=1e-12)
+    parts = [build_model(g, dev, 'f64', _shard_of=(r, world)).gradients() for r in range(world)]
+    for k in want:
+        got = sum(p_[k].cpu().numpy() for p_ in parts)
+        ref = want[k].cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+@pytest.mark.parametrize('shape', [(33, 5, 17, 5, 1, 1), (70, 9, 33, 9, 3, 3), (80, 8, 64, 6, 4, 2), (45, 14, 20, 13, 3, 1)])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_model_gradients_odd_shapes(dev, shape, prec):
+    """Shapes off the tile sizes (M not a multiple of 16, Q not a multiple of 4, T = 1, mask_size > 1) against the pinned
+    autograd oracle at random raw variables."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    n, d, m, q, t, mask = shape
+    rng = np.random.default_rng(n + d)
+    y = rng.standard_normal((n, d))
+    y = (y - y.mean(0)) / y.std(0)
+    raw = dict(x_mean=rng.standard_normal((n, q)), x_var_raw=0.3 * rng.standard_normal((n, q)),
+               x_u=rng.standard_normal((m, q)), dp_logits=rng.standard_normal((d // mask, t)),
+               gamma_1_raw=rng.standard_normal(max(t - 1, 0)), gamma_2_raw=rng.standard_normal(max(t - 1, 0)),
+               w_1_raw=np.array(0.4), w_2_raw=np.array(0.7), gamma_atoms_raw=0.5 * rng.standard_normal((t, q)),
+               alpha_atoms_raw=0.5 * rng.standard_normal((t, 1)), beta_atoms_raw=0.5 * rng.standard_normal((t, 1)) + 1.0)
+    obj, ref = ot.objective_and_gradients(y, raw, s_1=1.0, s_2=1.0, mask_size=mask)
+    sp = softplus
+    model = dp_gp_lvm(y, num_latent_dims=q, num_inducing_points=m, truncation_level=t, alpha_prior_params=np.array([1.0, 1.0]),
+                      mask_size=mask, device=dev, precision=prec,
+                      initial_values=dict(x_mean=raw['x_mean'], x_var=sp(raw['x_var_raw']), x_u=raw['x_u'],
+                                          phi_logits=raw['dp_logits'], gamma_atoms=sp(raw['gamma_atoms_raw']),
+                                          alpha_atoms=sp(raw['alpha_atoms_raw']), beta_atoms=sp(raw['beta_atoms_raw']),
+                                          gamma_1=sp(raw['gamma_1_raw']), gamma_2=sp(raw['gamma_2_raw']),
+                                          w_1=float(sp(raw['w_1_raw'])), w_2=float(sp(raw['w_2_raw']))))
+    tol = 1e-7 if prec == 'f64' else 1e-3
+    np.testing.assert_allclose(float(model.objective), obj, rtol=1e-7 if prec == 'f64' else 2e-5)   # (random x_u: K_uu can be ill-conditioned)
+    got = model.gradients()
+    for ref_name, raw_name in REF2RAW.items():
+        want = ref[ref_name]
+        if want.size == 0:
+            continue
+        have = got[raw_name].cpu().numpy().reshape(-1)[:want.size].reshape(want.shape)
+        np.testing.assert_allclose(have, want, rtol=tol, atol=tol * max(1.0, np.abs(want).max()), err_msg=ref_name)
+    np.testing.assert_allclose(got['dp_w'].cpu().numpy(), [float(ref['w_1_raw']), float(ref['w_2_raw'])], rtol=tol, atol=tol)
