@@ -4,14 +4,15 @@
 //   1. diag   (B workgroups)              : L_kk = chol(A_kk) (128 x 128) and W_kk = L_kk^-1, LDS-resident (potrf_lds +
 //                                           trtri_lds); a launch of its own only for k = 0 (see 3.)
 //   2. panel  (B x row blocks x 2)        : P_i = A_ik W_kk^T for the 64-row blocks below, into a panel buffer
-//   3. update (B x lower pairs of blocks) : A_ij -= P_i P_j^T (64 x 64 x 128 MFMA block products), the trailing update.
-//                                           The workgroup that owns the three blocks of the NEXT diagonal 128 x 128 block
-//                                           updates them and factors + inverts that block right away (look-ahead: the
-//                                           ~60 us of that latency-bound step hide behind the other workgroups' updates).
+//   3. update (B x lower pairs of blocks) : A_IJ -= P_I P_J^T (128 x 128 x 128 MFMA block products), the trailing update.
+//                                           The workgroup that owns the NEXT diagonal 128 x 128 block updates it and factors
+//                                           + inverts it right away (look-ahead: the ~90 us of that latency-bound step
+//                                           hide behind the other workgroups' updates).
 // Panel width: with 64-wide panels the update does 8 flops per byte of the trailing matrix it reads and writes and was
 // HBM-bound at 20-22 TFLOP/s (27-29 % of the fp64 MFMA peak); 128-wide panels double that.  The single-workgroup routine
 // (potrf_blocked) uses 1 of 4 CUs at B = 64 (1.5 TFLOP/s).  Matrices are padded with an identity block to a multiple of
 // 128 (in place when M is one already); all kernels are bounded to 256 VGPRs (two workgroups per compute unit).
+#include <cstdlib>
 #include "internal.h"
 #include "linalg_dev.h"
 
@@ -143,57 +144,87 @@ __global__ __launch_bounds__(256, 2) void pbig_panel(int Mw, int k, const T *__r
     pbig_store<T>(pbuf + ((size_t)b * Mw + RB * i) * PW + RB * c, PW, acc);
 }
 
-// one 64 x 64 trailing block: A_ij -= P_i P_j^T (K = 128 in two staged halves); i == j also writes P_i into the panel of A
+// one 128 x 128 trailing block: A_IJ -= P_I P_J^T, K = 128 staged in four quarters of 32 through LDS; every wave owns 32
+// rows x 128 columns of the block in registers (16 result tiles).  128 x 128 rather than 64 x 64 per workgroup: the panel
+// rows are fetched from memory once per 128 x 128 block (8 flops per byte moved instead of 5.5; the 64 x 64 version ran at
+// 22 TFLOP/s whatever the panel width).  I == J also writes P_I into the panel columns of A (the finished L_Ik).
+#define UB 128                // row / column block of the update
+#define KQ 32                 // K staged per pass
+#define KQ_LD (KQ + 2)
+template <typename T> __device__ __forceinline__ void pbig_stage_q(const T *__restrict__ g, int ld, T *__restrict__ s) {
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    for (int e = threadIdx.x; e < UB * KQ / 4; e += 256) {            // 128 rows x 32 columns
+        const int r = e >> 3, c4 = (e & 7) * 4;
+        const t4 v = *reinterpret_cast<const t4 *>(g + (size_t)r * ld + c4);
+        T *d = s + r * KQ_LD + c4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+}
 template <typename T>
-__device__ __forceinline__ void pbig_update_block(int Mw, int k, int b, int i, int j, T *__restrict__ w,
+__device__ __forceinline__ void pbig_update_block(int Mw, int k, int b, int I, int J, T *__restrict__ w,
                                                   const T *__restrict__ pbuf, T *xs, T *ys) {
     typedef typename Mfma<T>::acc_t acc_t;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
     T *Wb = w + (size_t)b * Mw * Mw;
     const int r0 = PW * (k + 1);
-    T *Cij = Wb + (size_t)(r0 + RB * i) * Mw + r0 + RB * j;
-    const T *Pi = pbuf + ((size_t)b * Mw + RB * i) * PW, *Pj = pbuf + ((size_t)b * Mw + RB * j) * PW;
-    acc_t acc[4];
+    T *Cij = Wb + (size_t)(r0 + UB * I) * Mw + r0 + UB * J;
+    const T *Pi = pbuf + ((size_t)b * Mw + UB * I) * PW, *Pj = pbuf + ((size_t)b * Mw + UB * J) * PW;
+    acc_t acc[2][8];
 #pragma unroll
-    for (int J = 0; J < 4; ++J)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[J][v] = Cij[(size_t)(16 * wv + Mfma<T>::row(lane, v)) * Mw + 16 * J + li];
-    for (int h = 0; h < PW / RB; ++h) {
+        for (int Jt = 0; Jt < 8; ++Jt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc[i][Jt][v] = Cij[(size_t)(32 * wv + 16 * i + Mfma<T>::row(lane, v)) * Mw + 16 * Jt + li];
+    for (int h = 0; h < PW / KQ; ++h) {
         __syncthreads();
-        pbig_stage<T>(Pi + RB * h, PW, xs);
-        if (i != j) pbig_stage<T>(Pj + RB * h, PW, ys);
+        pbig_stage_q<T>(Pi + KQ * h, PW, xs);
+        if (I != J) pbig_stage_q<T>(Pj + KQ * h, PW, ys);
         __syncthreads();
-        pbig_mma_half<T>(xs, (i != j) ? ys : xs, acc, (T)-1);
-        if (i == j) {                                            // the finished panel block L_ik = P_i goes back into A
-            T *Lik = Wb + (size_t)(r0 + RB * i) * Mw + PW * k + RB * h;
-            for (int e = threadIdx.x; e < RB * RB; e += 256) Lik[(size_t)(e >> 6) * Mw + (e & 63)] = xs[(e >> 6) * RB_LD + (e & 63)];
+        const T *yy = (I != J) ? ys : xs;
+#pragma unroll 2
+        for (int ks = 0; ks < KQ / 4; ++ks) {
+            const T x0 = -xs[(32 * wv + li) * KQ_LD + 4 * ks + kk], x1 = -xs[(32 * wv + 16 + li) * KQ_LD + 4 * ks + kk];
+#pragma unroll
+            for (int Jt = 0; Jt < 8; ++Jt) {
+                const T yv = yy[(16 * Jt + li) * KQ_LD + 4 * ks + kk];
+                acc[0][Jt] = Mfma<T>::mma(x0, yv, acc[0][Jt]);
+                acc[1][Jt] = Mfma<T>::mma(x1, yv, acc[1][Jt]);
+            }
+        }
+        if (I == J) {                                            // the finished panel block L_Ik = P_I goes back into A
+            T *Lik = Wb + (size_t)(r0 + UB * I) * Mw + PW * k + KQ * h;
+            for (int e = threadIdx.x; e < UB * KQ; e += 256) Lik[(size_t)(e >> 5) * Mw + (e & 31)] = xs[(e >> 5) * KQ_LD + (e & 31)];
         }
     }
-    pbig_store<T>(Cij, Mw, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int Jt = 0; Jt < 8; ++Jt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                Cij[(size_t)(32 * wv + 16 * i + Mfma<T>::row(lane, v)) * Mw + 16 * Jt + li] = acc[i][Jt][v];
 }
 
-// step 3.  blockIdx.y enumerates the lower pairs (i, j) of the 64-row blocks below the panel; the pairs (0,0), (1,0), (1,1)
-// form the next diagonal 128 x 128 block: workgroup 0 does all three and then factors + inverts that block (look-ahead).
+// step 3.  blockIdx.y enumerates the lower pairs (I, J) of the 128-row blocks below the panel; pair (0,0) is the next
+// diagonal block: its workgroup factors + inverts it right after updating it (look-ahead).
 template <typename T>
 __global__ __launch_bounds__(256, 2) void pbig_update(int Mw, int k, T *__restrict__ w, const T *__restrict__ pbuf,
-                                                      T *__restrict__ winv, T *__restrict__ dinv_g, int *__restrict__ info) {
+                                                      T *__restrict__ winv, T *__restrict__ dinv_g, int *__restrict__ info,
+                                                      int lookahead) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    T *xs = reinterpret_cast<T *>(smem_raw), *ys = xs + RB * RB_LD;
+    T *xs = reinterpret_cast<T *>(smem_raw), *ys = xs + UB * KQ_LD;
     const int b = blockIdx.x, p = blockIdx.y;
-    if (p == 1 || p == 2) return;                                // (done by workgroup 0)
-    if (p == 0) {
-        pbig_update_block<T>(Mw, k, b, 0, 0, w, pbuf, xs, ys);
-        pbig_update_block<T>(Mw, k, b, 1, 0, w, pbuf, xs, ys);
-        pbig_update_block<T>(Mw, k, b, 1, 1, w, pbuf, xs, ys);
+    int I = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= p) ++I;
+    while (I * (I + 1) / 2 > p) --I;
+    pbig_update_block<T>(Mw, k, b, I, p - I * (I + 1) / 2, w, pbuf, xs, ys);
+    if (p == 0 && lookahead) {
         __threadfence_block();
         __syncthreads();
         pbig_diag_body<T>(Mw, k + 1, b, w, winv, dinv_g, info, smem_raw);
-        return;
     }
-    int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
-    while ((i + 1) * (i + 2) / 2 <= p) ++i;
-    while (i * (i + 1) / 2 > p) --i;
-    pbig_update_block<T>(Mw, k, b, i, p - i * (i + 1) / 2, w, pbuf, xs, ys);
 }
 
 size_t potrf_big_ws_elems(int B, int M) {
@@ -205,11 +236,15 @@ template <typename T>
 int launch_potrf_big(int B, int M, T *a, int *info, T *ws, hipStream_t st) {
     const int Mw = dpgp_round_up(M, PW), nblk = Mw / PW;
     const bool in_place = (Mw == M);
+    // DPGP_POTRF_NO_LOOKAHEAD=1 (profiling only): diagonal blocks as launches of their own, so that the update kernel's own
+    // rate can be read off a kernel trace
+    const char *nl_ = getenv("DPGP_POTRF_NO_LOOKAHEAD");
+    const int lookahead = (nl_ && nl_[0] == '1') ? 0 : 1;
     T *w = in_place ? a : ws, *winv = ws + (size_t)B * Mw * Mw, *dinv_g = winv + (size_t)B * PW * PW,
       *pbuf = dinv_g + (size_t)B * (PW / 16) * 256;
     const size_t lds_diag = LA_LDS_HDR + sizeof(T) * (size_t)TSZ * (1 + (PW / 16) * (PW / 16 + 1) / 2);
-    size_t lds_blk = sizeof(T) * (size_t)2 * RB * RB_LD;
-    const size_t lds_upd = lds_blk > lds_diag ? lds_blk : lds_diag;    // the look-ahead workgroup reuses it for the diagonal block
+    const size_t lds_blk = sizeof(T) * (size_t)2 * RB * RB_LD, lds_u = sizeof(T) * (size_t)2 * UB * KQ_LD;
+    const size_t lds_upd = lds_u > lds_diag ? lds_u : lds_diag;        // the look-ahead workgroup reuses it for the diagonal block
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pbig_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_diag) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(pbig_panel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -230,9 +265,14 @@ int launch_potrf_big(int B, int M, T *a, int *info, T *ws, hipStream_t st) {
         DPGP_PRELAUNCH(); hipLaunchKernelGGL((pbig_panel<T>), dim3(B, nrb, PW / RB), dim3(256), lds_blk, st, Mw, k, (const T *)w, (const T *)winv,
                            pbuf);
         DPGP_LAUNCH_CHECK();
-        DPGP_PRELAUNCH(); hipLaunchKernelGGL((pbig_update<T>), dim3(B, nrb * (nrb + 1) / 2), dim3(256), lds_upd, st, Mw, k, w, (const T *)pbuf,
-                           winv, dinv_g, info);
+        const int nub = nrb / 2;                                   // 128-row blocks below the panel
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL((pbig_update<T>), dim3(B, nub * (nub + 1) / 2), dim3(256), lds_upd, st, Mw, k, w, (const T *)pbuf,
+                           winv, dinv_g, info, lookahead);
         DPGP_LAUNCH_CHECK();
+        if (!lookahead) {
+            DPGP_PRELAUNCH(); hipLaunchKernelGGL((pbig_diag<T>), dim3(B), dim3(256), lds_diag, st, Mw, k + 1, w, winv, dinv_g, info);
+            DPGP_LAUNCH_CHECK();
+        }
     }
     if (in_place) {
         DPGP_PRELAUNCH(); hipLaunchKernelGGL((pbig_zero_upper<T>), dim3(cp, B), dim3(256), 0, st, M, a);
