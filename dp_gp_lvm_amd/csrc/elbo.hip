@@ -116,7 +116,10 @@ extern "C" int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *al
 // Backward pass, stage B (grad.hip): the second streaming pass over the observations.
 extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q) {
     if (D <= 0 || N <= 0 || M <= 0 || Q <= 0) return 0;
-    return dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
+    size_t b = dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
+    if (psi2_grad_supported(M, Q))
+        b += dpgp_align256(psi2_consts_bytes(M, Q)) + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q));
+    return b;
 }
 extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                                   const double *s, const double *gamma, const double *alpha, const double *g_psi2,
@@ -143,11 +146,21 @@ extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, i
     if (!d_s) return -19;
     if (!d_z) return -20;
     if (!d_gamma) return -21;
-    if (prec == DPGP_PREC_MIXED)
-        return launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
-                                      d_z, d_gamma, (hipStream_t)stream);
+    if (prec == DPGP_PREC_MIXED) {
+        // the Psi2 term (nearly all of the work) on the matrix pipe where that kernel applies, the rest by the plain kernel
+        const bool fast = psi2_grad_supported(M, Q) && !getenv("DPGP_GRAD_PLAIN");
+        int rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu,
+                                        d_s, d_z, d_gamma, fast ? 0 : 1, (hipStream_t)stream);
+        if (rc != DPGP_OK || !fast) return rc;
+        unsigned char *consts = (unsigned char *)ws + dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
+        double *part = reinterpret_cast<double *>(consts + dpgp_align256(psi2_consts_bytes(M, Q)));
+        rc = launch_psi2_consts<double>(z, M, Q, consts, (hipStream_t)stream);
+        if (rc != DPGP_OK) return rc;
+        return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, part, d_mu, d_s, d_z, d_gamma,
+                                (hipStream_t)stream);
+    }
     return launch_psi_grad<double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
-                                   d_z, d_gamma, (hipStream_t)stream);
+                                   d_z, d_gamma, 1, (hipStream_t)stream);
 }
 
 extern "C" int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z,

@@ -221,9 +221,10 @@ __global__ __launch_bounds__(256, 2) void psi_grad_kernel(int D, int N, int M, i
                                                        const double *__restrict__ s, const double *__restrict__ gamma,
                                                        const double *__restrict__ alpha, const double *__restrict__ GP,
                                                        const double *__restrict__ WK, const double *__restrict__ Gv,
-                                                       int n_per_split, double *__restrict__ dmu_part,
+                                                       int n_per_split, int do_psi2, double *__restrict__ dmu_part,
                                                        double *__restrict__ ds_part, double *__restrict__ dz_part,
                                                        double *__restrict__ dg_part) {
+    // do_psi2 == 0: the Psi2 term is left to psi2_grad_kernel (psi2.hip, matrix pipe); this kernel then only does Psi1 and K_uu
     extern __shared__ __align__(16) unsigned char smem_raw[];
     TC *gs = reinterpret_cast<TC *>(smem_raw);                 // [Mp][Mp] symmetric G (then W for the K_uu part; [2 Q][128] at the very end)
     TC *zs = gs + (size_t)(Mp * Mp > 2 * Q * 128 ? Mp * Mp : 2 * Q * 128);                       // [Mp][QP], zero padded
@@ -235,11 +236,12 @@ __global__ __launch_bounds__(256, 2) void psi_grad_kernel(int D, int N, int M, i
     const int d = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y, t = threadIdx.x, a = t & 127, nl = t >> 7;
     const int NV = 5 * Q + 2;
     const TC al = (TC)alpha[d];
-    for (int e = t; e < Mp * Mp; e += 256) {
-        const int i = e / Mp, j = e - i * Mp;
-        const double v = (i < M && j < M) ? GP[(size_t)d * Mp * Mp + (size_t)(i >= j ? i : j) * Mp + (i >= j ? j : i)] : 0.0;
-        gs[i * Mp + j] = (TC)v;
-    }
+    if (do_psi2)
+        for (int e = t; e < Mp * Mp; e += 256) {
+            const int i = e / Mp, j = e - i * Mp;
+            const double v = (i < M && j < M) ? GP[(size_t)d * Mp * Mp + (size_t)(i >= j ? i : j) * Mp + (i >= j ? j : i)] : 0.0;
+            gs[i * Mp + j] = (TC)v;
+        }
     {   // column means (fp64 partial sums through the `red` area, which is free here)
         double *sc = reinterpret_cast<double *>(red);
         const int q = t & 31, rg = t >> 5;
@@ -310,14 +312,17 @@ __global__ __launch_bounds__(256, 2) void psi_grad_kernel(int D, int N, int M, i
             xz[q] = (TC)0.5 * (ga[q] - a2[q]) * za[q];
         }
         pa += (TC)0.5 * cn;
-        pbuf[nl * 128 + a] = pa;
-        __syncthreads();
+        if (do_psi2) {
+            pbuf[nl * 128 + a] = pa;
+            __syncthreads();
+        }
         TC R = 0, T[QP];
 #pragma unroll
         for (int q = 0; q < QP; ++q) T[q] = 0;
         TC w1 = 0;
         if (live && a < M) {
-            for (int mp = 0; mp < M; ++mp) {
+            if (do_psi2)
+              for (int mp = 0; mp < M; ++mp) {
                 TC e = pa + pbuf[nl * 128 + mp], zm[QP];
 #pragma unroll
                 for (int q = 0; q < QP; ++q) {
@@ -348,14 +353,19 @@ __global__ __launch_bounds__(256, 2) void psi_grad_kernel(int D, int N, int M, i
                 x = wave_sum(x);
                 if (lane_ == 0) red[wave * NV + v] = x;
             };
-            put(0, R);
+            if (do_psi2) put(0, R);
+            else if (lane_ == 0) red[wave * NV] = 0;
             put(3 * Q + 1, w1);
 #pragma unroll
             for (int q = 0; q < QP; ++q)
                 if (q < Q) {
-                    put(1 + q, R * za[q]);
-                    put(1 + Q + q, R * za[q] * za[q]);
-                    put(1 + 2 * Q + q, za[q] * T[q]);
+                    if (do_psi2) {
+                        put(1 + q, R * za[q]);
+                        put(1 + Q + q, R * za[q] * za[q]);
+                        put(1 + 2 * Q + q, za[q] * T[q]);
+                    } else if (lane_ == 0) {
+                        red[wave * NV + 1 + q] = 0; red[wave * NV + 1 + Q + q] = 0; red[wave * NV + 1 + 2 * Q + q] = 0;
+                    }
                     put(3 * Q + 2 + q, w1 * za[q]);
                     put(4 * Q + 2 + q, w1 * za[q] * za[q]);
                 }
@@ -464,7 +474,7 @@ size_t psi_grad_ws_bytes(int D, int N, int M, int Q, int *nsplit_out) {
 template <typename TC>
 int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
                     const double *gamma, const double *alpha, const double *GP, const double *WK, const double *Gv,
-                    double *ws, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+                    double *ws, double *dmu, double *ds, double *dz, double *dgamma, int do_psi2, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16);
     if (Mp > 128) return -30;                                  // first version: one thread per row of the M x M statistics
     int ns = 1;
@@ -475,7 +485,7 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
     const int QPr = 4 * dpgp_ceil_div(Q, 4);
     const size_t lds = sizeof(TC) * ((size_t)(Mp * Mp > 2 * Q * 128 ? Mp * Mp : 2 * Q * 128) + (size_t)Mp * QPr + PG_RED_ELEMS(Q) + (size_t)12 * Q + 256 + 32 + (size_t)2 * (7 * Q + 2));
     void (*kern)(int, int, int, int, int, const double *, int, const double *, const double *, const double *, const double *,
-                 const double *, const double *, const double *, const double *, int, double *, double *, double *, double *) = nullptr;
+                 const double *, const double *, const double *, const double *, int, int, double *, double *, double *, double *) = nullptr;
     switch (QPr / 4) {
 #define CASE(k) case k: kern = psi_grad_kernel<TC, 4 * k>; break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -487,7 +497,7 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
             hipSuccess)
         return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(D, ns), dim3(256), lds, st, D, N, M, Mp, Q, y, ldy, z, mu, s, gamma, alpha, GP, WK, Gv,
-                       nper, dmu_part, ds_part, dz_part, dg_part);
+                       nper, do_psi2, dmu_part, ds_part, dz_part, dg_part);
     DPGP_LAUNCH_CHECK();
     const size_t nq = (size_t)N * Q, mq = (size_t)M * Q, dq = (size_t)D * Q;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)dmu_part, dmu);
@@ -502,7 +512,7 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
 }
 template int launch_psi_grad<float>(int, int, int, int, const double *, int, const double *, const double *, const double *,
                                     const double *, const double *, const double *, const double *, const double *, double *,
-                                    double *, double *, double *, double *, hipStream_t);
+                                    double *, double *, double *, double *, int, hipStream_t);
 template int launch_psi_grad<double>(int, int, int, int, const double *, int, const double *, const double *, const double *,
                                      const double *, const double *, const double *, const double *, const double *,
-                                     double *, double *, double *, double *, double *, hipStream_t);
+                                     double *, double *, double *, double *, double *, int, hipStream_t);

@@ -1169,6 +1169,514 @@ __global__ __launch_bounds__(256) void psi2_plain_kernel(int N, int M, int Q, co
     }
 }
 
+// ===============================================================================================================
+// Backward pass, matrix-core version of the Psi2 term of stage B (grad.hip has the plain first version and the Psi1 / K_uu
+// terms).  For every (output dim d, observation n) it needs, with W[a,m'] = G_d[a,m'] psi2(n,a,m') (G = d f_hat / d Psi2,
+// symmetric), the column sums C[m'] = sum_a W and T'[m',q] = sum_a W z_aq; everything else follows per (n, m', q):
+//     d/dz[m',q] += (gamma_q - a2_nq) T' + (2 a2_nq mu_nq - (gamma_q + a2_nq) z_m'q) C            a2 = gamma / (2 gamma S + 1)
+//     S0 = sum C,  S1_q = sum C z,  S2_q = sum C z^2,  S3_q = sum z T'   (sums over m')  ->  d/dmu_n, d/dS_n, d/dgamma_d
+// (the row-sum halves of the symmetric expressions are the column sums of the transposed patch, so every patch of the FULL
+// M x M square is processed and contributes its column side only).  Workgroup = (64 x 64 patch, output dim, n-split) as in
+// the forward kernel, same phases A (per-(n,q) factors) and B (P rows on the matrix pipe), same exponent tiles (32x32x16 f16
+// MFMA, hi/lo-split operands); then, instead of accumulating exp2(E):  w = G' .* exp2(E)  (G' = G alpha^2 exp2(beta_mm') held
+// in the registers the forward uses for its accumulators),  C and T' by per-lane FMAs over the 16 rows a lane holds of each
+// tile (z rows broadcast from LDS), the two lane halves combined, and per observation a DPP reduction over the columns.
+// Outputs are partial sums per workgroup, added up in fixed order by psi2_grad_reduce_* (deterministic).
+// ===============================================================================================================
+template <int KB> __host__ __device__ inline Psi2PLayout psi2g_layout(int Q) {
+    typedef Psi2F16Lds<KB> G;
+    Psi2PLayout L;
+    L.SL = 32 * ((6 * Q + 2 + 31) / 32);
+    L.QS = G::KQ;
+    L.off_bimg = 2 * G::PS * G::ZLD + 2 * (DPGP_MAX_Q + 2);
+    L.off_wave = L.off_bimg;                                   // (column image read from global memory)
+    L.o_aimg = 16 * G::XLD;
+    L.o_cq = L.o_aimg + 16 * L.SL / 2;
+    L.o_pw = L.o_cq + 16 * L.QS;
+    L.wsz = L.o_pw + 16 * G::PLD + 36 + 2 * 16 * G::XLD;       // + mu'[16][XLD], S[16][XLD]
+    const int fill = L.off_wave + 4 * L.wsz, red = L.off_wave + 4 * 64 * (G::KQ + 1);
+    L.elems = fill > red ? fill : red;
+    return L;
+}
+
+// sum over the 32 lanes of each wave half, result in lanes 31 and 63 (DPP: row_shr 1, 2, 4, 8; row_bcast:15 into rows 1, 3)
+__device__ __forceinline__ float half_sum_dpp(float x) {
+    int v = __builtin_bit_cast(int, x);
+#define DPP_ADD(ctrl, rmask)                                                                                          \
+    v = __builtin_bit_cast(int, __builtin_bit_cast(float, v) +                                                        \
+                                    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)))
+    DPP_ADD(0x111, 0xf);
+    DPP_ADD(0x112, 0xf);
+    DPP_ADD(0x114, 0xf);
+    DPP_ADD(0x118, 0xf);
+    DPP_ADD(0x142, 0xa);
+#undef DPP_ADD
+    return __builtin_bit_cast(float, v);
+}
+
+template <int KB>
+__global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
+                                                           const double *__restrict__ mu, const double *__restrict__ s,
+                                                           const double *__restrict__ gamma, const double *__restrict__ alpha,
+                                                           const double *__restrict__ GP, int Mp, int n_per_split,
+                                                           int n_splits, float *__restrict__ dmu_part,
+                                                           float *__restrict__ ds_part, double *__restrict__ dz_part,
+                                                           double *__restrict__ dg_part) {
+    typedef Psi2F16Lds<KB> G;
+    constexpr int PS = G::PS, XLD = G::XLD, ZLD = G::ZLD, PLD = G::PLD, NR = 16, KQ = G::KQ, QH = KQ / 2;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const Psi2PLayout L = psi2g_layout<KB>(Q);
+    const int SL = L.SL, QS = L.QS, kf1 = SL / 32;
+    const int nps = (Mp + 63) / 64, npatch = nps * nps;
+    const int item = blockIdx.x, b = item % B, sp = (item / B) % n_splits, patch = item / (B * n_splits);
+    const int pi = patch / nps, pj = patch - pi * nps;
+    float *zs = reinterpret_cast<float *>(smem_raw);          // [2*PS][ZLD] centred z rows: row block pi, then column block pj
+    float *zc = zs + 2 * PS * ZLD;
+    float *gq = zc + DPGP_MAX_Q + 2;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
+    const int m_base = pi * PS, mp_base = pj * PS;
+    float *wp = zs + L.off_wave + wv * L.wsz;
+    float *xa = wp;
+    _Float16 *aimg = reinterpret_cast<_Float16 *>(wp + L.o_aimg);
+    float *cq = wp + L.o_cq;
+    unsigned *pw = reinterpret_cast<unsigned *>(wp + L.o_pw);
+    float *mus = wp + L.o_pw + 16 * PLD + 36, *sss = mus + 16 * XLD;          // mu - zc and S of this wave's 16 rows
+    constexpr int CONST_ONE = NR * PLD;
+    constexpr int NCOL = 2 * PS;
+    const Psi2Consts C = psi2_consts_layout(M, Q);
+    const float *zs_g = reinterpret_cast<const float *>(consts + C.off_zs);
+    const _Float16 *bimg_g = reinterpret_cast<const _Float16 *>(consts + C.off_bimg);
+    if (t < KQ) gq[t] = (t < Q) ? (float)gamma[(size_t)b * Q + t] : 0.0f;
+    if (t < 32) zc[t] = reinterpret_cast<const float *>(consts)[t];
+    for (int e = t; e < 2 * PS * (ZLD / 4); e += 256) {
+        const int r = e / (ZLD / 4), k4 = e - r * (ZLD / 4);
+        const int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
+        reinterpret_cast<f32x4 *>(zs)[e] = reinterpret_cast<const f32x4 *>(zs_g + (size_t)m * ZLD)[k4];
+    }
+    for (int e = lane; e < 16 * SL / 2; e += 64) reinterpret_cast<unsigned *>(aimg)[e] = 0u;
+    if (lane < 2) pw[CONST_ONE + 32 * lane] = DPGP_H2_ONES;
+    __syncthreads();
+
+    const int li5 = lane & 31, k2 = lane >> 5;
+    dpgp_f2 zA[2][KB];
+    unsigned bh[2][KB], bl[2][KB];
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) {
+        const int q0 = 2 * (k2 + 2 * ks);
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            zA[I][ks][0] = (q0 < Q) ? zs[(32 * I + li5) * ZLD + q0] : 0.0f;
+            zA[I][ks][1] = (q0 + 1 < Q) ? zs[(32 * I + li5) * ZLD + q0 + 1] : 0.0f;
+            const float b0 = (q0 < Q) ? zs[(PS + 32 * I + li5) * ZLD + q0] : 0.0f;
+            const float b1 = (q0 + 1 < Q) ? zs[(PS + 32 * I + li5) * ZLD + q0 + 1] : 0.0f;
+            const _Float16 h0 = (_Float16)b0, h1 = (_Float16)b1;
+            dpgp_h2 hv = {h0, h1};
+            bh[I][ks] = __builtin_bit_cast(unsigned, hv);
+            bl[I][ks] = pack_h2(b0 - (float)h0, b1 - (float)h1);
+        }
+    }
+    const unsigned *pwA = pw + ((k2 == 0) ? li5 : CONST_ONE);
+    const unsigned *pwB = pw + ((k2 == 1) ? PS + li5 : CONST_ONE);
+    const int stepA = (k2 == 0) ? PLD : 0, stepB = (k2 == 1) ? PLD : 0;
+    const float *xaq = xa + 2 * k2;
+
+    // G' tiles in the 32x32 MFMA result layout: register v of lane l = (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
+    f32x16 g[2][2];
+    {
+        const float al = (float)alpha[b], al2 = al * al;
+        const double *Gd = GP + (size_t)b * Mp * Mp;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = 32 * I + 8 * (v >> 2) + 4 * k2 + (v & 3), col = 32 * J + li5;
+                    const int m = m_base + row, mp = mp_base + col;
+                    float val = 0.0f;
+                    if (m < M && mp < M) {
+                        const float *z1 = zs + row * ZLD, *z2 = zs + (PS + col) * ZLD;
+                        float bsum = 0;
+                        for (int q = 0; q < Q; ++q) {
+                            const float dd = z1[q] - z2[q];
+                            bsum += gq[q] * dd * dd;
+                        }
+                        const double gv = Gd[(size_t)(m >= mp ? m : mp) * Mp + (m >= mp ? mp : m)];
+                        val = (float)gv * al2 * dpgp_exp2((float)(-0.25 * DPGP_LOG2E) * bsum);
+                    }
+                    g[I][J][v] = val;
+                }
+    }
+    // common power-of-two scale of the tiles (the products w = G' psi2 go through f16 hi/lo pairs): max |G'| -> [2^13, 2^14)
+    float unscale = 1.0f;
+    {
+        float mx = 0.0f;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) mx = fmaxf(mx, fabsf(g[I][J][v]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (mx > 0.0f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);
+            ex = max(-100, min(100, ex));
+            const float sc = ldexpf(1.0f, 14 - ex);
+            unscale = ldexpf(1.0f, ex - 14);
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) g[I][J][v] *= sc;
+        }
+    }
+    // Second product on the matrix pipe: per observation  T'^T[slot, m'] = sum_a Zt[slot, a] w[a, m'],  the w tile taken as
+    // the B operand straight from the registers the exponent tile arrived in (k-slot 8 (l / 32) + j of step s <-> register
+    // 8 s + j <-> patch row 8 (2 s + j / 4) + 4 (l / 32) + j % 4, the A operand is permuted to match).  Output rows (slots,
+    // 16 per lane half h): u < QH: z_hi[., QH h + u];  QH <= u < 2 QH: z_lo[., QH h + u - QH];  u = 2 QH: ones (column sums).
+    dpgp_h8 za[2][2];
+    {
+        const int rho = li5, u = 4 * (rho >> 3) + (rho & 3), hh = (rho >> 2) & 1;
+        const int qq = QH * hh + (u < QH ? u : u - QH);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int a = 32 * I + 8 * (2 * s_ + (j >> 2)) + 4 * k2 + (j & 3);
+                    const float zv = (qq < Q) ? zs[a * ZLD + qq] : 0.0f;
+                    const _Float16 zh = (_Float16)zv;
+                    _Float16 val = (_Float16)0.0f;
+                    if (u < QH) val = zh;
+                    else if (u < 2 * QH) val = (_Float16)(zv - (float)zh);
+                    else if (u == 2 * QH) val = (_Float16)1.0f;
+                    za[I][s_][j] = val;
+                }
+    }
+    float dz[2][QH], dgam[QH];                                  // lane = column (l % 32), half l / 32 owns q = QH (l / 32) + i
+#pragma unroll
+    for (int i = 0; i < QH; ++i) { dz[0][i] = 0.0f; dz[1][i] = 0.0f; dgam[i] = 0.0f; }
+    const int qb = QH * k2;
+    const float *zcol[2] = {zs + (PS + li5) * ZLD + qb, zs + (PS + 32 + li5) * ZLD + qb};
+    const size_t slot = (size_t)b * npatch + patch;
+
+    const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    constexpr int NPA = (NR * XLD + 63) / 64;
+    float pf_s[NPA], pf_m[NPA];
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+        const int e = 64 * u + lane, r = e / XLD, k = e - r * XLD, n = nbeg + wv + 4 * r;
+        const bool ok = (e < NR * XLD) && (k < Q) && (n < nend);
+        pf_s[u] = ok ? (float)s[(size_t)n * Q + k] : 1.0f;
+        pf_m[u] = ok ? (float)mu[(size_t)n * Q + k] : 0.0f;
+    }
+    for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {
+        // ---- phase A (as the forward kernel) + mu', S of the rows for the finishing step ----
+#pragma unroll
+        for (int u = 0; u < NPA; ++u) {
+            const int e = 64 * u + lane;
+            if (e < NR * XLD) {
+                const int r = e / XLD, k = e - r * XLD, n = nc + 4 * r;
+                float vx = 0.0f, mc = 0.0f, sv = 1.0f;
+                if (k < Q) {
+                    float a = 0.0f, bb = 0.0f, cc = (k == 0) ? -30000.0f : 0.0f;
+                    if (n < nend) {
+                        const float gg = gq[k];
+                        mc = pf_m[u] - zc[k];
+                        sv = pf_s[u];
+                        const float den = 2.0f * gg * sv + 1.0f;
+                        const float w = gg / den;
+                        vx = (float)(-0.5 * DPGP_LOG2E) * w;
+                        a = (float)(-0.25 * DPGP_LOG2E) * w;
+                        bb = (float)DPGP_LOG2E * w * mc;
+                        cc = (float)(-DPGP_LOG2E) * (0.5f * w * mc * mc + 0.25f * dpgp_log(den));
+                    }
+                    const _Float16 ah = (_Float16)a, al_ = (_Float16)(a - (float)ah);
+                    const _Float16 bhh = (_Float16)bb, bll = (_Float16)(bb - (float)bhh);
+                    unsigned *dst = reinterpret_cast<unsigned *>(aimg + r * SL + 6 * k);
+                    const dpgp_h2 w0 = {ah, ah}, w1 = {al_, bhh}, w2 = {bhh, bll};
+                    dst[0] = __builtin_bit_cast(unsigned, w0);
+                    dst[1] = __builtin_bit_cast(unsigned, w1);
+                    dst[2] = __builtin_bit_cast(unsigned, w2);
+                    cq[r * QS + k] = cc;
+                } else if (k < QS) {
+                    cq[r * QS + k] = 0.0f;
+                }
+                xa[e] = vx;
+                mus[e] = mc;
+                sss[e] = sv;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NPA; ++u) {
+            const int e = 64 * u + lane, r = e / XLD, k = e - r * XLD, n = nc + 4 * NR + 4 * r;
+            const bool ok = (e < NR * XLD) && (k < Q) && (n < nend);
+            pf_s[u] = ok ? (float)s[(size_t)n * Q + k] : 1.0f;
+            pf_m[u] = ok ? (float)mu[(size_t)n * Q + k] : 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 16) {
+            float c = 0.0f;
+#pragma unroll
+            for (int q4 = 0; q4 < KQ / 4; ++q4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(cq + lane * KQ + 4 * q4);
+                c += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            c = fmaxf(c, -30000.0f);
+            const _Float16 ch = (_Float16)c;
+            const dpgp_h2 cw = {ch, (_Float16)(c - (float)ch)};
+            *reinterpret_cast<unsigned *>(aimg + lane * SL + 6 * Q) = __builtin_bit_cast(unsigned, cw);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase B (as the forward kernel, column image from global memory) ----
+        {
+            constexpr int NJ = NCOL / 16;
+            f32x4 pc[NJ];
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) pc[J] = (f32x4){0, 0, 0, 0};
+            auto bload = [&](dpgp_h8 (&bq)[NJ], int ks) __attribute__((always_inline)) {
+#pragma unroll
+                for (int J = 0; J < NJ; ++J) {
+                    const int m = (J < PS / 16) ? (m_base + 16 * J + li) : (mp_base + 16 * (J - PS / 16) + li);
+                    bq[J] = *reinterpret_cast<const dpgp_h8 *>(bimg_g + (size_t)m * SL + 32 * ks + 8 * kk);
+                }
+            };
+            auto bmma = [&](const dpgp_h8 (&bq)[NJ], int ks) __attribute__((always_inline)) {
+                const dpgp_h8 av = *reinterpret_cast<const dpgp_h8 *>(aimg + li * SL + 32 * ks + 8 * kk);
+#pragma unroll
+                for (int J = 0; J < NJ; ++J) pc[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bq[J], pc[J], 0, 0, 0);
+            };
+            dpgp_h8 b0[NJ], b1[NJ];
+            bload(b0, 0);
+            for (int ks = 0; ks < kf1; ks += 2) {
+                if (ks + 1 < kf1) bload(b1, ks + 1);
+                bmma(b0, ks);
+                if (ks + 2 < kf1) bload(b0, ks + 2);
+                if (ks + 1 < kf1) bmma(b1, ks + 1);
+            }
+#pragma unroll
+            for (int J = 0; J < NJ; ++J)
+#pragma unroll
+                for (int v = 0; v < 4; v += 2) {
+                    unsigned w0, w1;
+                    split_pair_words(fminf(fmaxf(pc[J][v], -30000.0f), 30000.0f),
+                                     fminf(fmaxf(pc[J][v + 1], -30000.0f), 30000.0f), w0, w1);
+                    pw[(4 * kk + v) * PLD + 16 * J + li] = w0;
+                    pw[(4 * kk + v + 1) * PLD + 16 * J + li] = w1;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase C': per row, w = G' exp2(E) tile by tile, T'^T += Zt w on the matrix pipe; then the finishing step ----
+#pragma unroll 1
+        for (int r = 0; r < NR; ++r) {
+            dpgp_f2 xk[KB];
+            unsigned spA[2], spB[2];
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) xk[ks] = *reinterpret_cast<const dpgp_f2 *>(xaq + r * XLD + 4 * ks);
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                spA[I] = pwA[r * stepA + 32 * I];
+                spB[I] = pwB[r * stepB + 32 * I];
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { acc[0][v] = 0.0f; acc[1][v] = 0.0f; }
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                dpgp_u4 aop[KB];
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    unsigned hi, lo;
+                    split_products(xk[ks], zA[I][ks], hi, lo);
+                    aop[ks] = (dpgp_u4){hi, hi, lo, ks == 0 ? spA[I] : 0u};
+                }
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    f32x16 c;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) c[v] = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < KB; ++ks) {
+                        const dpgp_u4 bop = {bh[J][ks], bl[J][ks], bh[J][ks], ks == 0 ? spB[J] : 0u};
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dpgp_h8, aop[ks]),
+                                                                   __builtin_bit_cast(dpgp_h8, bop), c, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s_ = 0; s_ < 2; ++s_) {
+                        dpgp_u4 whi, wlo;
+#pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            const float w0 = g[I][J][8 * s_ + j] * dpgp_exp2(c[8 * s_ + j]);
+                            const float w1 = g[I][J][8 * s_ + j + 1] * dpgp_exp2(c[8 * s_ + j + 1]);
+                            unsigned h, l;
+                            float l0, l1;
+                            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(w0), "v"(w1));
+                            asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(w0), "v"(h));
+                            asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(w1), "v"(h));
+                            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(l0), "v"(l1));
+                            whi[j >> 1] = h;
+                            wlo[j >> 1] = l;
+                        }
+                        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, whi), acc[J], 0, 0, 0);
+                        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, wlo), acc[J], 0, 0, 0);
+                    }
+                }
+            }
+            // finishing: this lane = column l % 32 of both column tiles, latent dims q = qb + i
+            const int n = nc + 4 * r;
+            const float cs[2] = {acc[0][2 * QH], acc[1][2 * QH]};
+            float s0 = (k2 == 0) ? (cs[0] + cs[1]) : 0.0f, s1[QH], s2[QH], s3[QH];
+#pragma unroll
+            for (int i = 0; i < QH; ++i) {
+                const float gg = gq[qb + i], a2 = xa[r * XLD + qb + i] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + qb + i];
+                float a1 = 0.0f, a2s = 0.0f, a3 = 0.0f;
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    const float tq = acc[J][i] + acc[J][QH + i], zq = zcol[J][i];
+                    dz[J][i] += (gg - a2) * tq + (2.0f * a2 * mq - (gg + a2) * zq) * cs[J];
+                    a1 += cs[J] * zq;
+                    a2s += cs[J] * zq * zq;
+                    a3 += zq * tq;
+                }
+                s1[i] = a1; s2[i] = a2s; s3[i] = a3;
+            }
+            s0 = half_sum_dpp(s0);
+#pragma unroll
+            for (int i = 0; i < QH; ++i) { s1[i] = half_sum_dpp(s1[i]); s2[i] = half_sum_dpp(s2[i]); s3[i] = half_sum_dpp(s3[i]); }
+            const float S0 = __shfl(s0, 31, 64);                 // (the total over the columns lives in the first half)
+            if (li5 == 31 && n < nend) {
+#pragma unroll
+                for (int i = 0; i < QH; ++i) {
+                    const int q = qb + i;
+                    if (q < Q) {
+                        const float gg = gq[q], a2 = xa[r * XLD + q] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + q], sv = sss[r * XLD + q];
+                        const float id2 = a2 / gg, A2 = 0.5f * (s2[i] + s3[i]);
+                        const float q2 = mq * mq * S0 - 2.0f * mq * s1[i] + A2;
+                        dmu_part[(slot * N + n) * Q + q] = unscale * (-2.0f * a2 * (mq * S0 - s1[i]));
+                        ds_part[(slot * N + n) * Q + q] = unscale * (-a2 * S0 + 2.0f * a2 * a2 * q2);
+                        dgam[i] += -sv * id2 * S0 - q2 * id2 * id2 - 0.5f * (s2[i] - s3[i]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // ---- this workgroup's partial d/dz (64 columns x Q) and d/dgamma (Q): 4 waves through LDS ----
+    float *red = zs + L.off_wave;                               // [4][64][KQ + 1]
+    __syncthreads();
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int i = 0; i < QH; ++i) red[(wv * 64 + 32 * J + li5) * (KQ + 1) + qb + i] = dz[J][i];
+    __syncthreads();
+    for (int e = t; e < 64 * Q; e += 256) {
+        const int col = e / Q, q = e - col * Q;
+        float v = 0.0f;
+        for (int w_ = 0; w_ < 4; ++w_) v += red[(w_ * 64 + col) * (KQ + 1) + q];
+        dz_part[((size_t)item * 64 + col) * Q + q] = (double)(unscale * v);
+    }
+    __syncthreads();
+    if (li5 == 31)
+#pragma unroll
+        for (int i = 0; i < QH; ++i) red[wv * KQ + qb + i] = dgam[i];
+    __syncthreads();
+    if (t < Q) dg_part[((size_t)(patch * n_splits + sp) * B + b) * Q + t] = (double)(unscale * (red[t] + red[KQ + t] + red[2 * KQ + t] + red[3 * KQ + t]));
+}
+
+// d/dz[m', q] = sum over output dims, n-splits and the row blocks pi of the patches with column block pj = m' / 64
+__global__ __launch_bounds__(256) void psi2_grad_reduce_dz(int M, int Q, int B, int nps, int ns, const double *__restrict__ part,
+                                                           double *__restrict__ dz, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * Q) return;
+    const int m = i / Q, q = i - m * Q, pj = m >> 6, col = m & 63;
+    double a = accumulate ? dz[i] : 0.0;
+    for (int pi = 0; pi < nps; ++pi)
+        for (int sp = 0; sp < ns; ++sp)
+            for (int b = 0; b < B; ++b) {
+                const size_t item = (size_t)b + (size_t)B * (sp + (size_t)ns * (pi * nps + pj));
+                a += part[(item * 64 + col) * Q + q];
+            }
+    dz[i] = a;
+}
+
+// out[i] (+)= sum_k part[k * n + i], k < nk, fixed order
+template <typename TP>
+__global__ __launch_bounds__(256) void psi2_grad_reduce_rows(size_t n, int nk, const TP *__restrict__ part, double *__restrict__ out,
+                                                             int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double a = accumulate ? out[i] : 0.0;
+    for (int k = 0; k < nk; ++k) a += (double)part[(size_t)k * n + i];
+    out[i] = a;
+}
+
+bool psi2_grad_supported(int M, int Q) { return Q <= 12 && M >= 1; }
+int psi2_grad_nsplit(int B, int N, int M) {
+    const int nps = dpgp_ceil_div(dpgp_round_up(M, 16), 64);
+    int ns = dpgp_ceil_div(1024, B * nps * nps);
+    if (ns > dpgp_ceil_div(N, 256)) ns = dpgp_ceil_div(N, 256);
+    return ns < 1 ? 1 : ns;
+}
+// in doubles: d/dmu, d/dS partials [B npatch][N][Q] (float each); d/dz [items][64][Q]; d/dgamma [npatch ns][B][Q]
+size_t psi2_grad_part_elems(int B, int N, int M, int Q) {
+    const int nps = dpgp_ceil_div(dpgp_round_up(M, 16), 64), np = nps * nps, ns = psi2_grad_nsplit(B, N, M);
+    return (size_t)B * np * N * Q + 2 + (size_t)B * np * ns * 64 * Q + (size_t)np * ns * B * Q;
+}
+
+template <int KB>
+static int launch_psi2_grad_kb(int B, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
+                               const double *gamma, const double *alpha, const double *GP, double *part, double *dmu,
+                               double *ds, double *dz, double *dgamma, hipStream_t st) {
+    const int Mp = dpgp_round_up(M, 16), nps = dpgp_ceil_div(Mp, 64), np = nps * nps, ns = psi2_grad_nsplit(B, N, M);
+    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);
+    const size_t slab = (size_t)B * np * N * Q;
+    float *dmu_part = reinterpret_cast<float *>(part), *ds_part = dmu_part + slab;
+    double *dz_part = part + slab + 2;                          // (2 float slabs = `slab` doubles, + alignment slack)
+    double *dg_part = dz_part + (size_t)B * np * ns * 64 * Q;
+    const size_t lds = sizeof(float) * (size_t)psi2g_layout<KB>(Q).elems;
+    auto kern = psi2_grad_kernel<KB>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+        return DPGP_ERR_LAUNCH;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * ns * np)), dim3(256), lds, st, N, M, Q, B, consts, mu, s, gamma, alpha, GP, Mp,
+                       nper, ns, dmu_part, ds_part, dz_part, dg_part);
+    DPGP_LAUNCH_CHECK();
+    // the Psi1 / K_uu parts are already in the outputs: add the Psi2 part on top
+    const size_t nq = (size_t)N * Q, dq = (size_t)B * Q;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(psi2_grad_reduce_rows<float>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, B * np, (const float *)dmu_part, dmu, 1);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(psi2_grad_reduce_rows<float>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, B * np, (const float *)ds_part, ds, 1);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(psi2_grad_reduce_rows<double>, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, dq, np * ns, (const double *)dg_part, dgamma, 1);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(psi2_grad_reduce_dz, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, B, nps, ns, (const double *)dz_part, dz, 1);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+// Psi2 part of stage B on the matrix pipe, ADDED to dmu [N,Q], ds [N,Q], dz [M,Q], dgamma [B,Q] (which hold the other parts)
+int launch_psi2_grad(int B, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
+                     const double *gamma, const double *alpha, const double *GP, double *part, double *dmu, double *ds,
+                     double *dz, double *dgamma, hipStream_t st) {
+    if (!psi2_grad_supported(M, Q)) return -4;
+    switch (dpgp_ceil_div(Q, 4)) {
+#define CASE(k) case k: return launch_psi2_grad_kb<k>(B, N, M, Q, consts, mu, s, gamma, alpha, GP, part, dmu, ds, dz, dgamma, st);
+        CASE(1) CASE(2) CASE(3)
+#undef CASE
+    }
+    return -4;
+}
+
 // slabs -> dense symmetric [B,M,M]
 template <typename T>
 __global__ void psi2_finish_kernel(int B, int M, int Mp, int ns, const T *__restrict__ part, T *__restrict__ out) {
