@@ -117,8 +117,11 @@ extern "C" int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *al
 extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q) {
     if (D <= 0 || N <= 0 || M <= 0 || Q <= 0) return 0;
     size_t b = dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
-    if (psi2_grad_supported(M, Q))
-        b += dpgp_align256(psi2_consts_bytes(M, Q)) + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q));
+    if (psi2_grad_supported(M, Q)) {
+        const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
+        b += dpgp_align256(psi2_consts_bytes(M, Q)) + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)) +
+             dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
+    }
     return b;
 }
 extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
@@ -147,17 +150,24 @@ extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, i
     if (!d_z) return -20;
     if (!d_gamma) return -21;
     if (prec == DPGP_PREC_MIXED) {
-        // the Psi2 term (nearly all of the work) on the matrix pipe where that kernel applies, the rest by the plain kernel
+        // K_uu term by the plain kernel (no pass over the observations), Psi1 by the reduction-free kernels, Psi2 (nearly all
+        // of the work) on the matrix pipe -- where those apply; otherwise everything by the plain kernel
         const bool fast = psi2_grad_supported(M, Q) && !getenv("DPGP_GRAD_PLAIN");
+        hipStream_t st = (hipStream_t)stream;
         int rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu,
-                                        d_s, d_z, d_gamma, fast ? 0 : 1, (hipStream_t)stream);
+                                        d_s, d_z, d_gamma, fast ? 0 : 1, st);
         if (rc != DPGP_OK || !fast) return rc;
+        const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
         unsigned char *consts = (unsigned char *)ws + dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
         double *part = reinterpret_cast<double *>(consts + dpgp_align256(psi2_consts_bytes(M, Q)));
-        rc = launch_psi2_consts<double>(z, M, Q, consts, (hipStream_t)stream);
+        double *ws1 = reinterpret_cast<double *>((unsigned char *)part + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)));
+        double *stage = reinterpret_cast<double *>((unsigned char *)ws1 + dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)));
+        (void)mx;
+        rc = launch_psi2_consts<double>(z, M, Q, consts, st);
         if (rc != DPGP_OK) return rc;
-        return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, part, d_mu, d_s, d_z, d_gamma,
-                                (hipStream_t)stream);
+        rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, ws1, stage, d_mu, d_s, d_z, d_gamma, st);
+        if (rc != DPGP_OK) return rc;
+        return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, part, stage, d_mu, d_s, d_z, d_gamma, st);
     }
     return launch_psi_grad<double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
                                    d_z, d_gamma, 1, (hipStream_t)stream);

@@ -15,6 +15,7 @@
 // matrices in global memory.  It runs after a forward evaluation on the same workspace (K, K^-1 and the Psi slabs are there).
 #include "internal.h"
 #include "linalg_dev.h"
+#include "psi2_consts.h"
 
 __device__ __forceinline__ double sym_at(const double *__restrict__ a, int ld, int i, int j) {
     return (i >= j) ? a[(size_t)i * ld + j] : a[(size_t)j * ld + i];
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void psi_grad_kernel(int D, int N, int M, i
                                                        int n_per_split, int do_psi2, double *__restrict__ dmu_part,
                                                        double *__restrict__ ds_part, double *__restrict__ dz_part,
                                                        double *__restrict__ dg_part) {
-    // do_psi2 == 0: the Psi2 term is left to psi2_grad_kernel (psi2.hip, matrix pipe); this kernel then only does Psi1 and K_uu
+    // do_psi2 == 0: the Psi2 and Psi1 terms are left to psi2_grad_kernel (psi2.hip, matrix pipe) and psi1_grad_*_kernel; this
+    // kernel then only does the K_uu term (no pass over the observations, d/dmu and d/dS partials not written)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     TC *gs = reinterpret_cast<TC *>(smem_raw);                 // [Mp][Mp] symmetric G (then W for the K_uu part; [2 Q][128] at the very end)
     TC *zs = gs + (size_t)(Mp * Mp > 2 * Q * 128 ? Mp * Mp : 2 * Q * 128);                       // [Mp][QP], zero padded
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void psi_grad_kernel(int D, int N, int M, i
     }
     const TC gva = (a < M) ? (TC)Gv[(size_t)d * Mp + a] : (TC)0;
     TC dg_mine = 0;
-    const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
+    const int nbeg = sp * n_per_split, nend = do_psi2 ? min(N, nbeg + n_per_split) : nbeg;
     for (int n0 = nbeg; n0 < nend; n0 += 2) {
         const int n = n0 + nl;
         const bool live = (n < nend);
@@ -463,6 +465,273 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(size_t n, int nk, cons
     out[i] = a;
 }
 
+// out[i] (+)= sum_k part[k * pitch + i], i < n, k < nk, in a fixed order; many partial rows go through `stage`
+// (reduce_rows_stage_elems(n) doubles): <= 64 chunks of rows are summed side by side, then the chunk sums.
+template <typename TP>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(size_t n, size_t pitch, int nk, int kchunk, const TP *__restrict__ part,
+                                                          double *__restrict__ out, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = blockIdx.y, k0 = c * kchunk, k1 = min(nk, k0 + kchunk);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+        a0 += (double)part[(size_t)k * pitch + i];
+        a1 += (double)part[(size_t)(k + 1) * pitch + i];
+        a2 += (double)part[(size_t)(k + 2) * pitch + i];
+        a3 += (double)part[(size_t)(k + 3) * pitch + i];
+    }
+    for (; k < k1; ++k) a0 += (double)part[(size_t)k * pitch + i];
+    const double a = (a0 + a1) + (a2 + a3);
+    double *o = out + (size_t)c * n + i;
+    *o = accumulate ? *o + a : a;
+}
+size_t reduce_rows_stage_elems(size_t n) { return 64 * n; }
+template <typename TP>
+int launch_reduce_rows(size_t n, size_t pitch, int nk, const TP *part, double *out, int accumulate, double *stage, hipStream_t st) {
+    const unsigned gx = (unsigned)((n + 255) / 256);
+    if (nk <= 96 || !stage) {
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(reduce_rows_kernel<TP>, dim3(gx, 1), dim3(256), 0, st, n, pitch, nk, nk, part, out, accumulate);
+        DPGP_LAUNCH_CHECK();
+        return DPGP_OK;
+    }
+    const int kchunk = nk > 64 * 64 ? dpgp_ceil_div(nk, 64) : 64, nch = dpgp_ceil_div(nk, kchunk);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(reduce_rows_kernel<TP>, dim3(gx, nch), dim3(256), 0, st, n, pitch, nk, kchunk, part, stage, 0);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(gx, 1), dim3(256), 0, st, n, n, nch, nch, (const double *)stage, out, accumulate);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+template int launch_reduce_rows<float>(size_t, size_t, int, const float *, double *, int, double *, hipStream_t);
+template int launch_reduce_rows<double>(size_t, size_t, int, const double *, double *, int, double *, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Psi1 term of stage B without any per-observation workgroup reduction (mixed precision; the first version above spends
+// most of its time in those).  w1[n,a] = g_d[a] y_nd psi1_d(n,a),  c = mu_n - z_a (both centred),  a1 = gamma / (gamma S + 1):
+//   pass n (thread = observation, loops over a chunk of output dims and all a):   V0 = sum_a w1, U1_q = sum_a w1 c_q,
+//       U2_q = sum_a w1 c_q^2  ->  d/dmu_nq -= a1 U1,  d/dS_nq += (a1^2 U2 - a1 V0) / 2,  d/dgamma_dq -= (U2 / den1^2 + S V0 / den1) / 2
+//   pass z (thread = inducing point a, loops over a chunk of output dims and its observations):  d/dz_aq += w1 a1 c_q
+// both recompute psi1 (D N M exponentials each, ~0.1 ms), z rows come centred from the psi2 constants.     (rbf_kernel.py:135-161)
+// ---------------------------------------------------------------------------------------------------------------
+template <int QP>
+__global__ __launch_bounds__(256) void psi1_grad_n_kernel(int D, int N, int M, int Q, const double *__restrict__ y, int ldy,
+                                                          const unsigned char *__restrict__ consts, const double *__restrict__ mu,
+                                                          const double *__restrict__ s, const double *__restrict__ gamma,
+                                                          const double *__restrict__ alpha, const double *__restrict__ Gv, int Mp,
+                                                          int d_per_wg, float *__restrict__ dmu_part, float *__restrict__ ds_part,
+                                                          double *__restrict__ dg_part) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *zs = reinterpret_cast<float *>(smem_raw);            // [M][QP] centred
+    float *gv = zs + (size_t)M * QP;                            // [M] g_d
+    float *red = gv + Mp;                                       // [4][QP]
+    const Psi2Consts C = psi2_consts_layout(M, Q);
+    const float *zs_g = reinterpret_cast<const float *>(consts + C.off_zs), *zc = reinterpret_cast<const float *>(consts);
+    const int t = threadIdx.x, n = blockIdx.x * 256 + t, lane = t & 63, wave = t >> 6;
+    const bool live = n < N;
+    for (int e = t; e < M * QP; e += 256) {
+        const int a = e / QP, q = e - a * QP;
+        zs[e] = (q < C.ZLD) ? zs_g[(size_t)a * C.ZLD + q] : 0.0f;
+    }
+    float mq[QP], sv[QP], dmu[QP], dss[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        mq[q] = (live && q < Q) ? (float)mu[(size_t)n * Q + q] - zc[q] : 0.0f;
+        sv[q] = (live && q < Q) ? (float)s[(size_t)n * Q + q] : 1.0f;
+        dmu[q] = 0.0f;
+        dss[q] = 0.0f;
+    }
+    const int d0 = blockIdx.y * d_per_wg, d1 = min(D, d0 + d_per_wg);
+    for (int d = d0; d < d1; ++d) {
+        __syncthreads();
+        for (int a = t; a < M; a += 256) gv[a] = (float)Gv[(size_t)d * Mp + a];
+        __syncthreads();
+        float a1[QP], l1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const float g = (q < Q) ? (float)gamma[(size_t)d * Q + q] : 0.0f, den = g * sv[q] + 1.0f;
+            a1[q] = g / den;
+            l1 += __builtin_amdgcn_logf(den);                     // log2
+        }
+        const float al = (float)alpha[d];
+        const float e0 = __builtin_amdgcn_logf(al) - 0.5f * l1;  // log2 units
+        float V0 = 0.0f, U1[QP], U2[QP], h[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) { U1[q] = 0.0f; U2[q] = 0.0f; h[q] = (float)(-0.5 * DPGP_LOG2E) * a1[q]; }
+        for (int a = 0; a < M; ++a) {
+            float c[QP], cc[QP], e = e0;
+#pragma unroll
+            for (int q4 = 0; q4 < QP / 4; ++q4) {
+                const f32x4 zv = *reinterpret_cast<const f32x4 *>(zs + a * QP + 4 * q4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = 4 * q4 + k;
+                    c[q] = mq[q] - zv[k];
+                    cc[q] = c[q] * c[q];
+                    e += h[q] * cc[q];
+                }
+            }
+            const float w = gv[a] * dpgp_exp2(e);
+            V0 += w;
+#pragma unroll
+            for (int q = 0; q < QP; ++q) { U1[q] += w * c[q]; U2[q] += w * cc[q]; }
+        }
+        const float yv = live ? (float)y[(size_t)n * ldy + d] : 0.0f;
+        V0 *= yv;
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const float u1 = yv * U1[q], u2 = yv * U2[q];
+            dmu[q] -= a1[q] * u1;
+            dss[q] += 0.5f * (a1[q] * a1[q] * u2 - a1[q] * V0);
+            const float id1 = 1.0f / ((q < Q ? (float)gamma[(size_t)d * Q + q] : 0.0f) * sv[q] + 1.0f);
+            float dg = -0.5f * (u2 * id1 * id1 + sv[q] * id1 * V0);
+            dg = wave_sum(dg);
+            if (lane == 0) red[wave * QP + q] = dg;
+        }
+        __syncthreads();
+        if (t < Q) dg_part[((size_t)blockIdx.x * D + d) * Q + t] = (double)(red[t] + red[QP + t] + red[2 * QP + t] + red[3 * QP + t]);
+    }
+    if (live)
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+            if (q < Q) {
+                dmu_part[((size_t)blockIdx.y * N + n) * Q + q] = dmu[q];
+                ds_part[((size_t)blockIdx.y * N + n) * Q + q] = dss[q];
+            }
+}
+
+template <int QP>
+__global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, int Q, const double *__restrict__ y, int ldy,
+                                                          const unsigned char *__restrict__ consts, const double *__restrict__ mu,
+                                                          const double *__restrict__ s, const double *__restrict__ gamma,
+                                                          const double *__restrict__ alpha, const double *__restrict__ Gv, int Mp,
+                                                          int d_per_wg, int n_per_split, double *__restrict__ dz_part) {
+    constexpr int FS = 2 * QP + 4;                              // per observation: a1[QP], mu'[QP], e0, y, pad
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *fac = reinterpret_cast<float *>(smem_raw);           // [64][FS]
+    float *comb = fac + 64 * FS;                                // [128][QP] (end: the two observation lanes of a row)
+    const Psi2Consts C = psi2_consts_layout(M, Q);
+    const float *zs_g = reinterpret_cast<const float *>(consts + C.off_zs), *zc = reinterpret_cast<const float *>(consts);
+    const int t = threadIdx.x, a = t & 127, nl = t >> 7;
+    float za[QP], dza[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        za[q] = (a < M && q < C.ZLD) ? zs_g[(size_t)a * C.ZLD + q] : 0.0f;
+        dza[q] = 0.0f;
+    }
+    const int d0 = blockIdx.y * d_per_wg, d1 = min(D, d0 + d_per_wg);
+    const int nbeg = blockIdx.x * n_per_split, nend = min(N, nbeg + n_per_split);
+    const int fn = t >> 2, fp = t & 3;                          // factor computation: observation fn of the chunk, q = fp, fp + 4, ...
+    for (int d = d0; d < d1; ++d) {
+        const float gva = (a < M) ? (float)Gv[(size_t)d * Mp + a] : 0.0f;
+        const float l2al = __builtin_amdgcn_logf((float)alpha[d]);
+        for (int nc = nbeg; nc < nend; nc += 64) {
+            __syncthreads();
+            {
+                const int n = nc + fn;
+                float l1 = 0.0f;
+                for (int q = fp; q < QP; q += 4) {
+                    float a1 = 0.0f, m_ = 0.0f;
+                    if (q < Q && n < nend) {
+                        const float g = (float)gamma[(size_t)d * Q + q], den = g * (float)s[(size_t)n * Q + q] + 1.0f;
+                        a1 = g / den;
+                        m_ = (float)mu[(size_t)n * Q + q] - zc[q];
+                        l1 += __builtin_amdgcn_logf(den);
+                    }
+                    fac[fn * FS + q] = a1;
+                    fac[fn * FS + QP + q] = m_;
+                }
+                l1 += __shfl_xor(l1, 1, 64);
+                l1 += __shfl_xor(l1, 2, 64);
+                if (fp == 0) {
+                    fac[fn * FS + 2 * QP] = l2al - 0.5f * l1;
+                    fac[fn * FS + 2 * QP + 1] = (n < nend) ? (float)y[(size_t)n * ldy + d] : 0.0f;
+                }
+            }
+            __syncthreads();
+            for (int i = nl; i < 64; i += 2) {
+                const float *f = fac + i * FS;
+                float c[QP], a1[QP], e = f[2 * QP];
+#pragma unroll
+                for (int q4 = 0; q4 < QP / 4; ++q4) {
+                    const f32x4 av = *reinterpret_cast<const f32x4 *>(f + 4 * q4), mv = *reinterpret_cast<const f32x4 *>(f + QP + 4 * q4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int q = 4 * q4 + k;
+                        a1[q] = av[k];
+                        c[q] = mv[k] - za[q];
+                        e += (float)(-0.5 * DPGP_LOG2E) * a1[q] * c[q] * c[q];
+                    }
+                }
+                const float w = gva * f[2 * QP + 1] * dpgp_exp2(e);
+#pragma unroll
+                for (int q = 0; q < QP; ++q) dza[q] += w * a1[q] * c[q];
+            }
+        }
+    }
+    __syncthreads();
+    if (nl == 1)
+#pragma unroll
+        for (int q = 0; q < QP; ++q) comb[a * QP + q] = dza[q];
+    __syncthreads();
+    if (nl == 0 && a < M)
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+            if (q < Q) dz_part[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * M + a) * Q + q] = (double)(dza[q] + comb[a * QP + q]);
+}
+
+// workspace (doubles) of launch_psi1_grad: d/dmu, d/dS partials [DC][N][Q] float; d/dgamma [NB][D][Q]; d/dz [DC ns][M][Q]
+static void psi1_grad_shape(int D, int N, int *dpw, int *DC, int *NB, int *ns, int *nper) {
+    *dpw = 8;
+    *DC = dpgp_ceil_div(D, *dpw);
+    *NB = dpgp_ceil_div(N, 256);
+    int k = dpgp_ceil_div(1024, *DC);
+    if (k > dpgp_ceil_div(N, 128)) k = dpgp_ceil_div(N, 128);
+    if (k < 1) k = 1;
+    *nper = 64 * dpgp_ceil_div(dpgp_ceil_div(N, k), 64);
+    *ns = dpgp_ceil_div(N, *nper);
+}
+size_t psi1_grad_ws_elems(int D, int N, int M, int Q) {
+    int dpw, DC, NB, ns, nper;
+    psi1_grad_shape(D, N, &dpw, &DC, &NB, &ns, &nper);
+    return (size_t)DC * N * Q + 2 + (size_t)NB * D * Q + (size_t)DC * ns * M * Q;
+}
+// dmu, ds: overwritten; dz, dgamma: added to
+int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const unsigned char *consts, const double *mu,
+                     const double *s, const double *gamma, const double *alpha, const double *Gv, double *ws, double *stage,
+                     double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+    const int Mp = dpgp_round_up(M, 16);
+    if (Mp > 128) return -30;
+    int dpw, DC, NB, ns, nper;
+    psi1_grad_shape(D, N, &dpw, &DC, &NB, &ns, &nper);
+    const size_t slab = (size_t)DC * N * Q;
+    float *dmu_part = reinterpret_cast<float *>(ws), *ds_part = dmu_part + slab;
+    double *dg_part = ws + slab + 2, *dz_part = dg_part + (size_t)NB * D * Q;
+    const int QPr = 4 * dpgp_ceil_div(Q, 4);
+    void (*kn)(int, int, int, int, const double *, int, const unsigned char *, const double *, const double *, const double *,
+               const double *, const double *, int, int, float *, float *, double *) = nullptr;
+    void (*kz)(int, int, int, int, const double *, int, const unsigned char *, const double *, const double *, const double *,
+               const double *, const double *, int, int, int, double *) = nullptr;
+    switch (QPr / 4) {
+#define CASE(k) case k: kn = psi1_grad_n_kernel<4 * k>; kz = psi1_grad_z_kernel<4 * k>; break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    if (!kn) return -4;
+    const size_t lds_n = sizeof(float) * ((size_t)M * QPr + Mp + 4 * QPr), lds_z = sizeof(float) * ((size_t)64 * (2 * QPr + 4) + 128 * QPr);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kn, dim3(NB, DC), dim3(256), lds_n, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, Mp, dpw,
+                       dmu_part, ds_part, dg_part);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kz, dim3(ns, DC), dim3(256), lds_z, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, Mp, dpw,
+                       nper, dz_part);
+    DPGP_LAUNCH_CHECK();
+    const size_t nq = (size_t)N * Q, mq = (size_t)M * Q, dq = (size_t)D * Q;
+    int rc = launch_reduce_rows<float>(nq, nq, DC, dmu_part, dmu, 0, stage, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<float>(nq, nq, DC, ds_part, ds, 0, stage, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(dq, dq, NB, dg_part, dgamma, 1, stage, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(mq, mq, DC * ns, dz_part, dz, 1, stage, st);
+    return rc;
+}
+
 size_t psi_grad_ws_bytes(int D, int N, int M, int Q, int *nsplit_out) {
     int ns = dpgp_ceil_div(1024, D);
     if (ns > dpgp_ceil_div(N, 32)) ns = dpgp_ceil_div(N, 32);
@@ -479,6 +748,7 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
     if (Mp > 128) return -30;                                  // first version: one thread per row of the M x M statistics
     int ns = 1;
     psi_grad_ws_bytes(D, N, M, Q, &ns);
+    if (!do_psi2) ns = 1;
     const int nper = 2 * dpgp_ceil_div(dpgp_ceil_div(N, ns), 2);
     double *dmu_part = ws, *ds_part = dmu_part + (size_t)D * N * Q, *dz_part = ds_part + (size_t)D * N * Q,
            *dg_part = dz_part + (size_t)D * ns * M * Q;
@@ -500,10 +770,12 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
                        nper, do_psi2, dmu_part, ds_part, dz_part, dg_part);
     DPGP_LAUNCH_CHECK();
     const size_t nq = (size_t)N * Q, mq = (size_t)M * Q, dq = (size_t)D * Q;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)dmu_part, dmu);
-    DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)ds_part, ds);
-    DPGP_LAUNCH_CHECK();
+    if (do_psi2) {
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)dmu_part, dmu);
+        DPGP_LAUNCH_CHECK();
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)ds_part, ds);
+        DPGP_LAUNCH_CHECK();
+    }
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((mq + 255) / 256)), dim3(256), 0, st, mq, D * ns, (const double *)dz_part, dz);
     DPGP_LAUNCH_CHECK();
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, dq, ns, (const double *)dg_part, dgamma);

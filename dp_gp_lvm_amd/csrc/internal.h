@@ -78,11 +78,21 @@ template <typename TC>
 int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
                     const double *gamma, const double *alpha, const double *GP, const double *WK, const double *Gv,
                     double *ws, double *dmu, double *ds, double *dz, double *dgamma, int do_psi2, hipStream_t st);
+// do_psi2 = 0: only the K_uu term (dz, dgamma written; dmu, ds untouched) -- the other two terms then come from:
+// grad.hip: the Psi1 term (mixed precision): dmu, ds overwritten; dz, dgamma added to.  ws: psi1_grad_ws_elems doubles,
+// stage: reduce_rows_stage_elems(max(N Q, M Q, D Q)) doubles, consts as below
+size_t psi1_grad_ws_elems(int D, int N, int M, int Q);
+int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const unsigned char *consts, const double *mu,
+                     const double *s, const double *gamma, const double *alpha, const double *Gv, double *ws, double *stage,
+                     double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st);
+size_t reduce_rows_stage_elems(size_t n);
+template <typename TP>
+int launch_reduce_rows(size_t n, size_t pitch, int nk, const TP *part, double *out, int accumulate, double *stage, hipStream_t st);
 // psi2.hip: the Psi2 term of the same pass on the matrix pipe (mixed precision, Q <= 12), ADDED to the outputs of
 // launch_psi_grad(..., do_psi2 = 0, ...); consts: psi2 constants of z (launch_psi2_consts), part: psi2_grad_part_elems doubles
 bool psi2_grad_supported(int M, int Q);
 size_t psi2_grad_part_elems(int B, int N, int M, int Q);
 int launch_psi2_grad(int B, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
-                     const double *gamma, const double *alpha, const double *GP, double *part, double *dmu, double *ds,
-                     double *dz, double *dgamma, hipStream_t st);
+                     const double *gamma, const double *alpha, const double *GP, double *part, double *stage, double *dmu,
+                     double *ds, double *dz, double *dgamma, hipStream_t st);
 #define DPGP_PREP_ROWS 16   // output dims per row-block of dpgp_model_prepare (scal has 2 + ceil(D / 16) entries)

@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
         const int col = e / Q, q = e - col * Q;
         float v = 0.0f;
         for (int w_ = 0; w_ < 4; ++w_) v += red[(w_ * 64 + col) * (KQ + 1) + q];
-        dz_part[((size_t)item * 64 + col) * Q + q] = (double)(unscale * v);
+        dz_part[(((size_t)(pi * n_splits + sp) * B + b) * (nps * 64) + 64 * pj + col) * Q + q] = (double)(unscale * v);
     }
     __syncthreads();
     if (li5 == 31)
@@ -1593,33 +1593,6 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
     if (t < Q) dg_part[((size_t)(patch * n_splits + sp) * B + b) * Q + t] = (double)(unscale * (red[t] + red[KQ + t] + red[2 * KQ + t] + red[3 * KQ + t]));
 }
 
-// d/dz[m', q] = sum over output dims, n-splits and the row blocks pi of the patches with column block pj = m' / 64
-__global__ __launch_bounds__(256) void psi2_grad_reduce_dz(int M, int Q, int B, int nps, int ns, const double *__restrict__ part,
-                                                           double *__restrict__ dz, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * Q) return;
-    const int m = i / Q, q = i - m * Q, pj = m >> 6, col = m & 63;
-    double a = accumulate ? dz[i] : 0.0;
-    for (int pi = 0; pi < nps; ++pi)
-        for (int sp = 0; sp < ns; ++sp)
-            for (int b = 0; b < B; ++b) {
-                const size_t item = (size_t)b + (size_t)B * (sp + (size_t)ns * (pi * nps + pj));
-                a += part[(item * 64 + col) * Q + q];
-            }
-    dz[i] = a;
-}
-
-// out[i] (+)= sum_k part[k * n + i], k < nk, fixed order
-template <typename TP>
-__global__ __launch_bounds__(256) void psi2_grad_reduce_rows(size_t n, int nk, const TP *__restrict__ part, double *__restrict__ out,
-                                                             int accumulate) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double a = accumulate ? out[i] : 0.0;
-    for (int k = 0; k < nk; ++k) a += (double)part[(size_t)k * n + i];
-    out[i] = a;
-}
-
 bool psi2_grad_supported(int M, int Q) { return Q <= 12 && M >= 1; }
 int psi2_grad_nsplit(int B, int N, int M) {
     const int nps = dpgp_ceil_div(dpgp_round_up(M, 16), 64);
@@ -1627,7 +1600,7 @@ int psi2_grad_nsplit(int B, int N, int M) {
     if (ns > dpgp_ceil_div(N, 256)) ns = dpgp_ceil_div(N, 256);
     return ns < 1 ? 1 : ns;
 }
-// in doubles: d/dmu, d/dS partials [B npatch][N][Q] (float each); d/dz [items][64][Q]; d/dgamma [npatch ns][B][Q]
+// in doubles: d/dmu, d/dS partials [B npatch][N][Q] (float each); d/dz [nps ns B][64 nps][Q]; d/dgamma [npatch ns][B][Q]
 size_t psi2_grad_part_elems(int B, int N, int M, int Q) {
     const int nps = dpgp_ceil_div(dpgp_round_up(M, 16), 64), np = nps * nps, ns = psi2_grad_nsplit(B, N, M);
     return (size_t)B * np * N * Q + 2 + (size_t)B * np * ns * 64 * Q + (size_t)np * ns * B * Q;
@@ -1635,8 +1608,8 @@ size_t psi2_grad_part_elems(int B, int N, int M, int Q) {
 
 template <int KB>
 static int launch_psi2_grad_kb(int B, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
-                               const double *gamma, const double *alpha, const double *GP, double *part, double *dmu,
-                               double *ds, double *dz, double *dgamma, hipStream_t st) {
+                               const double *gamma, const double *alpha, const double *GP, double *part, double *stage,
+                               double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16), nps = dpgp_ceil_div(Mp, 64), np = nps * nps, ns = psi2_grad_nsplit(B, N, M);
     const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);
     const size_t slab = (size_t)B * np * N * Q;
@@ -1654,23 +1627,19 @@ static int launch_psi2_grad_kb(int B, int N, int M, int Q, const unsigned char *
     DPGP_LAUNCH_CHECK();
     // the Psi1 / K_uu parts are already in the outputs: add the Psi2 part on top
     const size_t nq = (size_t)N * Q, dq = (size_t)B * Q;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(psi2_grad_reduce_rows<float>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, B * np, (const float *)dmu_part, dmu, 1);
-    DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(psi2_grad_reduce_rows<float>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, B * np, (const float *)ds_part, ds, 1);
-    DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(psi2_grad_reduce_rows<double>, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, dq, np * ns, (const double *)dg_part, dgamma, 1);
-    DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(psi2_grad_reduce_dz, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, B, nps, ns, (const double *)dz_part, dz, 1);
-    DPGP_LAUNCH_CHECK();
-    return DPGP_OK;
+    int rc = launch_reduce_rows<float>(nq, nq, B * np, dmu_part, dmu, 1, stage, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<float>(nq, nq, B * np, ds_part, ds, 1, stage, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(dq, dq, np * ns, dg_part, dgamma, 1, stage, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>((size_t)M * Q, (size_t)nps * 64 * Q, nps * ns * B, dz_part, dz, 1, stage, st);
+    return rc;
 }
 // Psi2 part of stage B on the matrix pipe, ADDED to dmu [N,Q], ds [N,Q], dz [M,Q], dgamma [B,Q] (which hold the other parts)
 int launch_psi2_grad(int B, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
-                     const double *gamma, const double *alpha, const double *GP, double *part, double *dmu, double *ds,
-                     double *dz, double *dgamma, hipStream_t st) {
+                     const double *gamma, const double *alpha, const double *GP, double *part, double *stage, double *dmu,
+                     double *ds, double *dz, double *dgamma, hipStream_t st) {
     if (!psi2_grad_supported(M, Q)) return -4;
     switch (dpgp_ceil_div(Q, 4)) {
-#define CASE(k) case k: return launch_psi2_grad_kb<k>(B, N, M, Q, consts, mu, s, gamma, alpha, GP, part, dmu, ds, dz, dgamma, st);
+#define CASE(k) case k: return launch_psi2_grad_kb<k>(B, N, M, Q, consts, mu, s, gamma, alpha, GP, part, stage, dmu, ds, dz, dgamma, st);
         CASE(1) CASE(2) CASE(3)
 #undef CASE
     }
