@@ -447,41 +447,48 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
     }
     __syncthreads();
     if (blockIdx.x == 0) {
-        const int cols = Q + 4;                          // j < Q: gamma atoms; Q: alpha atoms; Q+1: beta atoms; Q+2: g1; Q+3: g2
-        for (int e = t; e < T * cols; e += 256) {
-            const int k = e / cols, j = e - k * cols;
+        // A[k][j] = sum_d phi[d,k] X[d,j], X = [df/dgamma (Q) | df/dalpha | df/dbeta | 1]: output dims staged through LDS in
+        // chunks of 32 (coalesced loads, fixed summation order) instead of one serial pass over D per thread
+        const int cols = Q + 3;                          // j < Q: gamma atoms; Q: alpha atoms; Q+1: beta atoms; Q+2: sum_d phi
+        __shared__ double ph_s[32][PREP_MAX_T], x_s[32][DPGP_MAX_Q + 3], sphi_s[PREP_MAX_T];
+        for (int e0 = 0; e0 < T * cols; e0 += 256) {
+            const int e = e0 + t, k = e / cols, j = e - k * cols;
             double acc = 0.0;
-            if (j <= Q + 2) {
-                for (int d = 0; d < D; ++d) {
-                    const double p = phi[(size_t)d * T + k];
-                    acc += p * (j < Q ? df_dgamma[(size_t)d * Q + j] : (j == Q ? df_dab[2 * d] : (j == Q + 1 ? df_dab[2 * d + 1] : 1.0)));
+            for (int dc = 0; dc < D; dc += 32) {
+                __syncthreads();
+                for (int i = t; i < 32 * T; i += 256) {
+                    const int dd = i / T, kk = i - dd * T;
+                    ph_s[dd][kk] = (dc + dd < D) ? phi[(size_t)(dc + dd) * T + kk] : 0.0;
                 }
-            } else {
-                for (int d = 0; d < D; ++d) {            // sum_d tail[d,k], tail = sum_{k' > k} phi
-                    double tl = 0.0;
-                    for (int kk = k + 1; kk < T; ++kk) tl += phi[(size_t)d * T + kk];
-                    acc += tl;
+                for (int i = t; i < 32 * cols; i += 256) {
+                    const int dd = i / cols, jj = i - dd * cols, d = dc + dd;
+                    x_s[dd][jj] = (d < D) ? (jj < Q ? df_dgamma[(size_t)d * Q + jj] : (jj == Q ? df_dab[2 * d] : (jj == Q + 1 ? df_dab[2 * d + 1] : 1.0))) : 0.0;
                 }
+                __syncthreads();
+                if (e < T * cols)
+                    for (int dd = 0; dd < 32; ++dd) acc += ph_s[dd][k] * x_s[dd][j];
             }
-            if (j <= Q + 1) {
-                const double raw = j < Q ? gat_raw[k * Q + j] : (j == Q ? aat_raw[k] : bat_raw[k]);
-                const double x = softplus_d(raw);
-                const double hyp = add_constants ? (1.0 / x + log(x) / x) : 0.0;               // -d/dx log_normal.log_pdf(x)
-                const double g = (-acc + hyp) * sigmoid_d(raw);
-                if (j < Q) d_gat_raw[k * Q + j] = g;
-                else if (j == Q) d_aat_raw[k] = g;
-                else d_bat_raw[k] = g;
+            if (e < T * cols) {
+                if (j <= Q + 1) {
+                    const double raw = j < Q ? gat_raw[k * Q + j] : (j == Q ? aat_raw[k] : bat_raw[k]);
+                    const double x = softplus_d(raw);
+                    const double hyp = add_constants ? (1.0 / x + log(x) / x) : 0.0;               // -d/dx log_normal.log_pdf(x)
+                    const double g = (-acc + hyp) * sigmoid_d(raw);
+                    if (j < Q) d_gat_raw[k * Q + j] = g;
+                    else if (j == Q) d_aat_raw[k] = g;
+                    else d_bat_raw[k] = g;
+                } else {
+                    sphi_s[k] = acc;
+                }
             }
         }
         __syncthreads();
-        // q(V): thread k < T-1 needs sum_d phi[d,k] and sum_d tail[d,k]: recompute (cheap) rather than pass through LDS
+        // q(V): thread k < T-1 needs sum_d phi[d,k] and sum_d tail[d,k], tail[d,k] = sum_{k' > k} phi[d,k']
         if (t < T - 1) {
             const int k = t;
-            double sphi = 0.0, stail = 0.0;
-            for (int d = 0; d < D; ++d) {
-                sphi += phi[(size_t)d * T + k];
-                for (int kk = k + 1; kk < T; ++kk) stail += phi[(size_t)d * T + kk];
-            }
+            const double sphi = sphi_s[k];
+            double stail = 0.0;
+            for (int kk = k + 1; kk < T; ++kk) stail += sphi_s[kk];
             const double g1 = softplus_d(g1_raw[k]), g2 = softplus_d(g2_raw[k]);
             const double t1 = trigamma_d(g1), t2 = trigamma_d(g2), t12 = trigamma_d(g1 + g2);
             double e1 = sphi * (t1 - t12) - stail * t12, e2 = -sphi * t12 + stail * (t2 - t12);

@@ -1183,12 +1183,16 @@ __global__ __launch_bounds__(256) void psi2_plain_kernel(int N, int M, int Q, co
 // tile (z rows broadcast from LDS), the two lane halves combined, and per observation a DPP reduction over the columns.
 // Outputs are partial sums per workgroup, added up in fixed order by psi2_grad_reduce_* (deterministic).
 // ===============================================================================================================
+// W_LO (template parameter of the kernel): 1: the products w go to the second MFMA product as f16 hi + lo pairs (what the
+// launcher uses); 0: rounded to f16, 0.8 ms faster at config 3 and 4e-6 of the largest gradient entry off there, but the sums
+// over (a, m') cancel heavily when K_uu is ill-conditioned (G = -B^-1/2 - ...): 5e-3 on a random M = 70 problem -- not used
 template <int KB> __host__ __device__ inline Psi2PLayout psi2g_layout(int Q) {
     typedef Psi2F16Lds<KB> G;
     Psi2PLayout L;
     L.SL = 32 * ((6 * Q + 2 + 31) / 32);
     L.QS = G::KQ;
-    L.off_bimg = 2 * G::PS * G::ZLD + 2 * (DPGP_MAX_Q + 2);
+    // [G' tiles 64 x 64 floats; the row block of z lives in its first PS * ZLD words during the prologue][column block of z]
+    L.off_bimg = 64 * 64 + G::PS * G::ZLD + 2 * (DPGP_MAX_Q + 2);
     L.off_wave = L.off_bimg;                                   // (column image read from global memory)
     L.o_aimg = 16 * G::XLD;
     L.o_cq = L.o_aimg + 16 * L.SL / 2;
@@ -1214,8 +1218,8 @@ __device__ __forceinline__ float half_sum_dpp(float x) {
     return __builtin_bit_cast(float, v);
 }
 
-template <int KB>
-__global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
+template <int KB, int PSI2G_W_LO>
+__global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
                                                            const double *__restrict__ mu, const double *__restrict__ s,
                                                            const double *__restrict__ gamma, const double *__restrict__ alpha,
                                                            const double *__restrict__ GP, int Mp, int n_per_split,
@@ -1230,8 +1234,10 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
     const int nps = (Mp + 63) / 64, npatch = nps * nps;
     const int item = blockIdx.x, b = item % B, sp = (item / B) % n_splits, patch = item / (B * n_splits);
     const int pi = patch / nps, pj = patch - pi * nps;
-    float *zs = reinterpret_cast<float *>(smem_raw);          // [2*PS][ZLD] centred z rows: row block pi, then column block pj
-    float *zc = zs + 2 * PS * ZLD;
+    float *zs = reinterpret_cast<float *>(smem_raw);          // [PS][ZLD] centred z rows of the row block pi (prologue only), then
+    float *gl = zs;                                           // G' tiles [tile 2 I + J][v / 4][lane][v % 4] in the same place
+    float *zcb = zs + 64 * 64;                                // [PS][ZLD] centred z rows of the column block pj
+    float *zc = zcb + PS * ZLD;
     float *gq = zc + DPGP_MAX_Q + 2;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
     const int m_base = pi * PS, mp_base = pj * PS;
@@ -1251,7 +1257,7 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
     for (int e = t; e < 2 * PS * (ZLD / 4); e += 256) {
         const int r = e / (ZLD / 4), k4 = e - r * (ZLD / 4);
         const int m = (r < PS) ? (m_base + r) : (mp_base + r - PS);
-        reinterpret_cast<f32x4 *>(zs)[e] = reinterpret_cast<const f32x4 *>(zs_g + (size_t)m * ZLD)[k4];
+        reinterpret_cast<f32x4 *>(r < PS ? zs : zcb - PS * ZLD)[e] = reinterpret_cast<const f32x4 *>(zs_g + (size_t)m * ZLD)[k4];
     }
     for (int e = lane; e < 16 * SL / 2; e += 64) reinterpret_cast<unsigned *>(aimg)[e] = 0u;
     if (lane < 2) pw[CONST_ONE + 32 * lane] = DPGP_H2_ONES;
@@ -1267,8 +1273,8 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
         for (int I = 0; I < 2; ++I) {
             zA[I][ks][0] = (q0 < Q) ? zs[(32 * I + li5) * ZLD + q0] : 0.0f;
             zA[I][ks][1] = (q0 + 1 < Q) ? zs[(32 * I + li5) * ZLD + q0 + 1] : 0.0f;
-            const float b0 = (q0 < Q) ? zs[(PS + 32 * I + li5) * ZLD + q0] : 0.0f;
-            const float b1 = (q0 + 1 < Q) ? zs[(PS + 32 * I + li5) * ZLD + q0 + 1] : 0.0f;
+            const float b0 = (q0 < Q) ? zcb[(32 * I + li5) * ZLD + q0] : 0.0f;
+            const float b1 = (q0 + 1 < Q) ? zcb[(32 * I + li5) * ZLD + q0 + 1] : 0.0f;
             const _Float16 h0 = (_Float16)b0, h1 = (_Float16)b1;
             dpgp_h2 hv = {h0, h1};
             bh[I][ks] = __builtin_bit_cast(unsigned, hv);
@@ -1281,57 +1287,36 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
     const float *xaq = xa + 2 * k2;
 
     // G' tiles in the 32x32 MFMA result layout: register v of lane l = (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
-    f32x16 g[2][2];
+    // (wave w computes tile (w / 2, w % 2); they go to LDS, scaled by a common power of two so that the products
+    //  w = G' psi2 fit f16 hi/lo pairs: max |G'| -> [2^13, 2^14))
+    float gt[16];
+    float unscale = 1.0f, gscale = 1.0f;
     {
+        const int I = wv >> 1, J = wv & 1;
         const float al = (float)alpha[b], al2 = al * al;
         const double *Gd = GP + (size_t)b * Mp * Mp;
-#pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int J = 0; J < 2; ++J)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int row = 32 * I + 8 * (v >> 2) + 4 * k2 + (v & 3), col = 32 * J + li5;
-                    const int m = m_base + row, mp = mp_base + col;
-                    float val = 0.0f;
-                    if (m < M && mp < M) {
-                        const float *z1 = zs + row * ZLD, *z2 = zs + (PS + col) * ZLD;
-                        float bsum = 0;
-                        for (int q = 0; q < Q; ++q) {
-                            const float dd = z1[q] - z2[q];
-                            bsum += gq[q] * dd * dd;
-                        }
-                        const double gv = Gd[(size_t)(m >= mp ? m : mp) * Mp + (m >= mp ? mp : m)];
-                        val = (float)gv * al2 * dpgp_exp2((float)(-0.25 * DPGP_LOG2E) * bsum);
-                    }
-                    g[I][J][v] = val;
-                }
-    }
-    // common power-of-two scale of the tiles (the products w = G' psi2 go through f16 hi/lo pairs): max |G'| -> [2^13, 2^14)
-    float unscale = 1.0f;
-    {
         float mx = 0.0f;
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int J = 0; J < 2; ++J)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) mx = fmaxf(mx, fabsf(g[I][J][v]));
+        for (int v = 0; v < 16; ++v) {
+            const int row = 32 * I + 8 * (v >> 2) + 4 * k2 + (v & 3), col = 32 * J + li5;
+            const int m = m_base + row, mp = mp_base + col;
+            float val = 0.0f;
+            if (m < M && mp < M) {
+                const float *z1 = zs + row * ZLD, *z2 = zcb + col * ZLD;
+                float bsum = 0;
+                for (int q = 0; q < Q; ++q) {
+                    const float dd = z1[q] - z2[q];
+                    bsum += gq[q] * dd * dd;
+                }
+                const double gv = Gd[(size_t)(m >= mp ? m : mp) * Mp + (m >= mp ? mp : m)];
+                val = (float)gv * al2 * dpgp_exp2((float)(-0.25 * DPGP_LOG2E) * bsum);
+            }
+            gt[v] = val;
+            mx = fmaxf(mx, fabsf(val));
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (mx > 0.0f && mx < 3.0e38f) {
-            int ex;
-            (void)frexpf(mx, &ex);
-            ex = max(-100, min(100, ex));
-            const float sc = ldexpf(1.0f, 14 - ex);
-            unscale = ldexpf(1.0f, ex - 14);
-#pragma unroll
-            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                for (int J = 0; J < 2; ++J)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) g[I][J][v] *= sc;
-        }
+        if (lane == 0) zc[DPGP_MAX_Q + 2 + KQ + wv] = mx;      // (behind gq[KQ]; KQ + 4 <= DPGP_MAX_Q + 2)
     }
     // Second product on the matrix pipe: per observation  T'^T[slot, m'] = sum_a Zt[slot, a] w[a, m'],  the w tile taken as
     // the B operand straight from the registers the exponent tile arrived in (k-slot 8 (l / 32) + j of step s <-> register
@@ -1357,11 +1342,28 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
                     za[I][s_][j] = val;
                 }
     }
+    __syncthreads();                                            // every wave is done with the row block of z: tiles may overwrite it
+    {
+        const float *mxs = zc + DPGP_MAX_Q + 2 + KQ;
+        const float mx = fmaxf(fmaxf(mxs[0], mxs[1]), fmaxf(mxs[2], mxs[3]));
+        if (mx > 0.0f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);
+            ex = max(-100, min(100, ex));
+            gscale = ldexpf(1.0f, 14 - ex);
+            unscale = ldexpf(1.0f, ex - 14);
+        }
+#pragma unroll
+        for (int vq = 0; vq < 4; ++vq)
+            *reinterpret_cast<f32x4 *>(gl + ((wv * 4 + vq) * 64 + lane) * 4) =
+                (f32x4){gt[4 * vq] * gscale, gt[4 * vq + 1] * gscale, gt[4 * vq + 2] * gscale, gt[4 * vq + 3] * gscale};
+    }
+    __syncthreads();
     float dz[2][QH], dgam[QH];                                  // lane = column (l % 32), half l / 32 owns q = QH (l / 32) + i
 #pragma unroll
     for (int i = 0; i < QH; ++i) { dz[0][i] = 0.0f; dz[1][i] = 0.0f; dgam[i] = 0.0f; }
     const int qb = QH * k2;
-    const float *zcol[2] = {zs + (PS + li5) * ZLD + qb, zs + (PS + 32 + li5) * ZLD + qb};
+    const float *zcol[2] = {zcb + li5 * ZLD + qb, zcb + (32 + li5) * ZLD + qb};
     const size_t slot = (size_t)b * npatch + patch;
 
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
@@ -1477,6 +1479,7 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- phase C': per row, w = G' exp2(E) tile by tile, T'^T += Zt w on the matrix pipe; then the finishing step ----
+        // (a hand-made software pipeline over the tiles as in the forward kernel was slower here: 8.0 vs 7.1 ms at config 3)
 #pragma unroll 1
         for (int r = 0; r < NR; ++r) {
             dpgp_f2 xk[KB];
@@ -1491,6 +1494,9 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
             f32x16 acc[2];
 #pragma unroll
             for (int v = 0; v < 16; ++v) { acc[0][v] = 0.0f; acc[1][v] = 0.0f; }
+            int goff = lane * 4;                                 // (opaque per row: keeps the 64 tile values out of registers)
+            asm volatile("" : "+v"(goff));
+            const float *glane = gl + goff;
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
                 dpgp_u4 aop[KB];
@@ -1502,6 +1508,9 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
                 }
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
+                    f32x4 gv[4];
+#pragma unroll
+                    for (int vq = 0; vq < 4; ++vq) gv[vq] = *reinterpret_cast<const f32x4 *>(glane + ((2 * I + J) * 4 + vq) * 256);
                     f32x16 c;
 #pragma unroll
                     for (int v = 0; v < 16; ++v) c[v] = 0.0f;
@@ -1516,29 +1525,37 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
                         dpgp_u4 whi, wlo;
 #pragma unroll
                         for (int j = 0; j < 8; j += 2) {
-                            const float w0 = g[I][J][8 * s_ + j] * dpgp_exp2(c[8 * s_ + j]);
-                            const float w1 = g[I][J][8 * s_ + j + 1] * dpgp_exp2(c[8 * s_ + j + 1]);
-                            unsigned h, l;
-                            float l0, l1;
+                            const float w0 = gv[2 * s_ + (j >> 2)][j & 3] * dpgp_exp2(c[8 * s_ + j]);
+                            const float w1 = gv[2 * s_ + (j >> 2)][(j & 3) + 1] * dpgp_exp2(c[8 * s_ + j + 1]);
+                            unsigned h;
                             asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(w0), "v"(w1));
-                            asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(w0), "v"(h));
-                            asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(w1), "v"(h));
-                            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(l0), "v"(l1));
                             whi[j >> 1] = h;
-                            wlo[j >> 1] = l;
+                            if (PSI2G_W_LO) {
+                                unsigned l;
+                                float l0, l1;
+                                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(w0), "v"(h));
+                                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(w1), "v"(h));
+                                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(l0), "v"(l1));
+                                wlo[j >> 1] = l;
+                            }
                         }
                         acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, whi), acc[J], 0, 0, 0);
-                        acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, wlo), acc[J], 0, 0, 0);
+                        if (PSI2G_W_LO)
+                            acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, wlo), acc[J], 0, 0, 0);
                     }
                 }
             }
             // finishing: this lane = column l % 32 of both column tiles, latent dims q = qb + i
             const int n = nc + 4 * r;
             const float cs[2] = {acc[0][2 * QH], acc[1][2 * QH]};
-            float s0 = (k2 == 0) ? (cs[0] + cs[1]) : 0.0f, s1[QH], s2[QH], s3[QH];
+            // (d/dgamma is linear in the column sums with coefficients that depend on (n, q) only: it accumulates per lane and
+            //  is summed over the lanes once at the end; per row only S0, S1_q and (S2_q + S3_q) / 2 are reduced over the columns)
+            const float c01 = cs[0] + cs[1];
+            float s0 = (k2 == 0) ? c01 : 0.0f, s1[QH], sA[QH];
 #pragma unroll
             for (int i = 0; i < QH; ++i) {
                 const float gg = gq[qb + i], a2 = xa[r * XLD + qb + i] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + qb + i];
+                const float sv = sss[r * XLD + qb + i];
                 float a1 = 0.0f, a2s = 0.0f, a3 = 0.0f;
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
@@ -1548,23 +1565,24 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
                     a2s += cs[J] * zq * zq;
                     a3 += zq * tq;
                 }
-                s1[i] = a1; s2[i] = a2s; s3[i] = a3;
+                const float A2 = 0.5f * (a2s + a3), id2 = (gg > 0.0f) ? a2 / gg : 0.0f;
+                s1[i] = a1;
+                sA[i] = A2;
+                dgam[i] += -sv * id2 * c01 - id2 * id2 * (mq * mq * c01 - 2.0f * mq * a1 + A2) - 0.5f * (a2s - a3);
             }
             s0 = half_sum_dpp(s0);
 #pragma unroll
-            for (int i = 0; i < QH; ++i) { s1[i] = half_sum_dpp(s1[i]); s2[i] = half_sum_dpp(s2[i]); s3[i] = half_sum_dpp(s3[i]); }
+            for (int i = 0; i < QH; ++i) { s1[i] = half_sum_dpp(s1[i]); sA[i] = half_sum_dpp(sA[i]); }
             const float S0 = __shfl(s0, 31, 64);                 // (the total over the columns lives in the first half)
             if (li5 == 31 && n < nend) {
 #pragma unroll
                 for (int i = 0; i < QH; ++i) {
                     const int q = qb + i;
                     if (q < Q) {
-                        const float gg = gq[q], a2 = xa[r * XLD + q] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + q], sv = sss[r * XLD + q];
-                        const float id2 = a2 / gg, A2 = 0.5f * (s2[i] + s3[i]);
-                        const float q2 = mq * mq * S0 - 2.0f * mq * s1[i] + A2;
+                        const float a2 = xa[r * XLD + q] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + q];
+                        const float q2 = mq * mq * S0 - 2.0f * mq * s1[i] + sA[i];
                         dmu_part[(slot * N + n) * Q + q] = unscale * (-2.0f * a2 * (mq * S0 - s1[i]));
                         ds_part[(slot * N + n) * Q + q] = unscale * (-a2 * S0 + 2.0f * a2 * a2 * q2);
-                        dgam[i] += -sv * id2 * S0 - q2 * id2 * id2 - 0.5f * (s2[i] - s3[i]);
                     }
                 }
             }
@@ -1586,6 +1604,8 @@ __global__ __launch_bounds__(256, 1) void psi2_grad_kernel(int N, int M, int Q, 
         dz_part[(((size_t)(pi * n_splits + sp) * B + b) * (nps * 64) + 64 * pj + col) * Q + q] = (double)(unscale * v);
     }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < QH; ++i) dgam[i] = half_sum_dpp(dgam[i]);
     if (li5 == 31)
 #pragma unroll
         for (int i = 0; i < QH; ++i) red[wv * KQ + qb + i] = dgam[i];
@@ -1606,7 +1626,7 @@ size_t psi2_grad_part_elems(int B, int N, int M, int Q) {
     return (size_t)B * np * N * Q + 2 + (size_t)B * np * ns * 64 * Q + (size_t)np * ns * B * Q;
 }
 
-template <int KB>
+template <int KB, int W_LO>
 static int launch_psi2_grad_kb(int B, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
                                const double *gamma, const double *alpha, const double *GP, double *part, double *stage,
                                double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
@@ -1617,7 +1637,7 @@ static int launch_psi2_grad_kb(int B, int N, int M, int Q, const unsigned char *
     double *dz_part = part + slab + 2;                          // (2 float slabs = `slab` doubles, + alignment slack)
     double *dg_part = dz_part + (size_t)B * np * ns * 64 * Q;
     const size_t lds = sizeof(float) * (size_t)psi2g_layout<KB>(Q).elems;
-    auto kern = psi2_grad_kernel<KB>;
+    auto kern = psi2_grad_kernel<KB, W_LO>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
@@ -1639,7 +1659,7 @@ int launch_psi2_grad(int B, int N, int M, int Q, const unsigned char *consts, co
                      double *ds, double *dz, double *dgamma, hipStream_t st) {
     if (!psi2_grad_supported(M, Q)) return -4;
     switch (dpgp_ceil_div(Q, 4)) {
-#define CASE(k) case k: return launch_psi2_grad_kb<k>(B, N, M, Q, consts, mu, s, gamma, alpha, GP, part, stage, dmu, ds, dz, dgamma, st);
+#define CASE(k) case k: return launch_psi2_grad_kb<k, 1>(B, N, M, Q, consts, mu, s, gamma, alpha, GP, part, stage, dmu, ds, dz, dgamma, st);
         CASE(1) CASE(2) CASE(3)
 #undef CASE
     }

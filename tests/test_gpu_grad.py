@@ -212,3 +212,34 @@ def test_model_gradients_odd_shapes(dev, shape, prec):
         have = got[raw_name].cpu().numpy().reshape(-1)[:want.size].reshape(want.shape)
         np.testing.assert_allclose(have, want, rtol=tol, atol=tol * max(1.0, np.abs(want).max()), err_msg=ref_name)
     np.testing.assert_allclose(got['dp_w'].cpu().numpy(), [float(ref['w_1_raw']), float(ref['w_2_raw'])], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('shape', [(300, 16, 100, 10), (500, 8, 128, 12), (200, 6, 70, 4), (150, 5, 130, 7)])
+def test_matrix_pipe_stage_b_against_fp64(dev, shape):
+    """Mixed precision, Q <= 12: the Psi2 term of stage B runs on the matrix pipe (psi2_grad_kernel), Psi1 in the reduction-free kernels.  Against the fp64 kernel
+    (itself at 1e-8 of the oracle's autograd, tests above) on the same stage-A adjoints; M = 130: the backward pass has no M > 128
+    version yet (stage A keeps B in LDS): the call must say so instead of computing something else."""
+    n, d, m, q = shape
+    rng = np.random.default_rng(n + m)
+    y = rng.standard_normal((n, d))
+    z = rng.standard_normal((m, q)) * 1.5
+    mu = rng.standard_normal((n, q))
+    s = np.exp(0.3 * rng.standard_normal((n, q)))
+    gamma = np.exp(0.4 * rng.standard_normal((d, q))) * 0.5
+    alpha = np.exp(0.2 * rng.standard_normal(d))
+    beta = np.exp(0.2 * rng.standard_normal(d)) * 2.0
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    args = [t(a) for a in (y, z, mu, s, gamma, alpha, beta)]
+    out = {}
+    for prec in ('f64', 'mixed'):
+        w = ops.ElboWorkspace(d, n, m, q, prec, dev)
+        ops.elbo_fhat(*args, prec=prec, workspace=w)
+        if m > 128:
+            with pytest.raises(ValueError):
+                ops.elbo_grad_chain(args[5], args[6], w)
+            return
+        gp, wk, gv, dab, info = ops.elbo_grad_chain(args[5], args[6], w)
+        assert int(info.abs().max()) == 0
+        out[prec] = [a.cpu().numpy() for a in ops.elbo_grad_psi(args[0], args[1], args[2], args[3], args[4], args[5], gp, wk, gv, prec=prec)]
+    for name, want, got in zip(('d mu', 'd S', 'd z', 'd gamma'), out['f64'], out['mixed']):
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * np.abs(want).max(), err_msg=name)
