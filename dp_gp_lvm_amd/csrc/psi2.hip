@@ -1363,7 +1363,14 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
 #pragma unroll
     for (int i = 0; i < QH; ++i) { dz[0][i] = 0.0f; dz[1][i] = 0.0f; dgam[i] = 0.0f; }
     const int qb = QH * k2;
-    const float *zcol[2] = {zcb + li5 * ZLD + qb, zcb + (32 + li5) * ZLD + qb};
+    float zcr[2][QH], gqr[QH], igq[QH];                         // this lane's columns' z', gamma and 1 / gamma of its latent dims
+#pragma unroll
+    for (int i = 0; i < QH; ++i) {
+        zcr[0][i] = zcb[li5 * ZLD + qb + i];
+        zcr[1][i] = zcb[(32 + li5) * ZLD + qb + i];
+        gqr[i] = gq[qb + i];
+        igq[i] = gqr[i] > 0.0f ? 1.0f / gqr[i] : 0.0f;
+    }
     const size_t slot = (size_t)b * npatch + patch;
 
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
@@ -1539,53 +1546,68 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
                                 wlo[j >> 1] = l;
                             }
                         }
+#ifdef PSI2G_DIAG_SKIP_MFMA2          // (timing experiment only: wrong results)
+                        acc[J][s_] += __builtin_bit_cast(float, whi[0] ^ whi[1] ^ whi[2] ^ whi[3] ^ wlo[0] ^ wlo[1] ^ wlo[2] ^ wlo[3]);
+#else
                         acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, whi), acc[J], 0, 0, 0);
                         if (PSI2G_W_LO)
                             acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, wlo), acc[J], 0, 0, 0);
+#endif
                     }
                 }
             }
             // finishing: this lane = column l % 32 of both column tiles, latent dims q = qb + i
-            const int n = nc + 4 * r;
-            const float cs[2] = {acc[0][2 * QH], acc[1][2 * QH]};
-            // (d/dgamma is linear in the column sums with coefficients that depend on (n, q) only: it accumulates per lane and
-            //  is summed over the lanes once at the end; per row only S0, S1_q and (S2_q + S3_q) / 2 are reduced over the columns)
-            const float c01 = cs[0] + cs[1];
-            float s0 = (k2 == 0) ? c01 : 0.0f, s1[QH], sA[QH];
+#ifndef PSI2G_DIAG_SKIP_FINISH      // (timing experiments only: wrong results)
+            // Per (n, q) everything is linear in the column sums, with coefficients that depend on (n, q) only: each lane forms
+            // its columns' share of d/dmu_nq, d/dS_nq (summed over the 32 lanes of the half: 2 QH DPP chains per row, results
+            // staged in the consumed P row of the observation and written out after the 16 rows) and of d/dgamma_q (accumulated
+            // per lane, summed over the lanes once at the very end).   a2 = gamma / den2, id2 = 1 / den2:
+            //   d/dmu = -2 a2 (mu' S0 - S1),  d/dS = -a2 S0 + 2 a2^2 q2,  q2 = mu'^2 S0 - 2 mu' S1 + (S2 + S3) / 2,
+            //   d/dgamma = -S id2 S0 - id2^2 q2 - (S2 - S3) / 2     (S0 = sum C, S1 = sum C z', S2 = sum C z'^2, S3 = sum z' T')
+            const float cs[2] = {acc[0][2 * QH], acc[1][2 * QH]}, c01 = cs[0] + cs[1];
+            float xs[QH], ys[QH];
 #pragma unroll
             for (int i = 0; i < QH; ++i) {
-                const float gg = gq[qb + i], a2 = xa[r * XLD + qb + i] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + qb + i];
+                const float gg = gqr[i], a2 = xa[r * XLD + qb + i] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + qb + i];
                 const float sv = sss[r * XLD + qb + i];
+                const float cT = gg - a2, c2n = gg + a2, tt = 2.0f * a2 * mq;
                 float a1 = 0.0f, a2s = 0.0f, a3 = 0.0f;
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
-                    const float tq = acc[J][i] + acc[J][QH + i], zq = zcol[J][i];
-                    dz[J][i] += (gg - a2) * tq + (2.0f * a2 * mq - (gg + a2) * zq) * cs[J];
-                    a1 += cs[J] * zq;
-                    a2s += cs[J] * zq * zq;
+                    const float tq = acc[J][i] + acc[J][QH + i], zq = zcr[J][i];
+                    dz[J][i] += cT * tq + (tt - c2n * zq) * cs[J];
+                    const float cz = cs[J] * zq;
+                    a1 += cz;
+                    a2s += cz * zq;
                     a3 += zq * tq;
                 }
-                const float A2 = 0.5f * (a2s + a3), id2 = (gg > 0.0f) ? a2 / gg : 0.0f;
-                s1[i] = a1;
-                sA[i] = A2;
-                dgam[i] += -sv * id2 * c01 - id2 * id2 * (mq * mq * c01 - 2.0f * mq * a1 + A2) - 0.5f * (a2s - a3);
+                const float A2 = 0.5f * (a2s + a3), Dh = 0.5f * (a2s - a3);
+                const float q2 = mq * (mq * c01 - 2.0f * a1) + A2;
+                xs[i] = 2.0f * a2 * (a1 - mq * c01);
+                ys[i] = a2 * (2.0f * a2 * q2 - c01);
+                const float id2 = a2 * igq[i];
+                dgam[i] -= sv * id2 * c01 + id2 * id2 * q2 + Dh;
             }
-            s0 = half_sum_dpp(s0);
 #pragma unroll
-            for (int i = 0; i < QH; ++i) { s1[i] = half_sum_dpp(s1[i]); sA[i] = half_sum_dpp(sA[i]); }
-            const float S0 = __shfl(s0, 31, 64);                 // (the total over the columns lives in the first half)
-            if (li5 == 31 && n < nend) {
+            for (int i = 0; i < QH; ++i) { xs[i] = half_sum_dpp(xs[i]); ys[i] = half_sum_dpp(ys[i]); }
+            if (li5 == 31) {
 #pragma unroll
                 for (int i = 0; i < QH; ++i) {
-                    const int q = qb + i;
-                    if (q < Q) {
-                        const float a2 = xa[r * XLD + q] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + q];
-                        const float q2 = mq * mq * S0 - 2.0f * mq * s1[i] + sA[i];
-                        dmu_part[(slot * N + n) * Q + q] = unscale * (-2.0f * a2 * (mq * S0 - s1[i]));
-                        ds_part[(slot * N + n) * Q + q] = unscale * (-a2 * S0 + 2.0f * a2 * a2 * q2);
-                    }
+                    pw[r * PLD + qb + i] = __builtin_bit_cast(unsigned, xs[i]);
+                    pw[r * PLD + KQ + qb + i] = __builtin_bit_cast(unsigned, ys[i]);
                 }
             }
+#else
+            dz[0][0] += acc[0][0] + acc[1][1];
+#endif
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = lane; e < NR * 2 * KQ; e += 64) {
+            const int r = e / (2 * KQ), c = e - r * (2 * KQ), q = c < KQ ? c : c - KQ, n = nc + 4 * r;
+            if (n < nend && q < Q)
+                (c < KQ ? dmu_part : ds_part)[(slot * N + n) * Q + q] = unscale * __builtin_bit_cast(float, pw[r * PLD + c]);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
