@@ -1218,6 +1218,21 @@ __device__ __forceinline__ float half_sum_dpp(float x) {
     return __builtin_bit_cast(float, v);
 }
 
+// the same for four values at once as fused v_add_f32_dpp (the builtin form costs a v_mov of the `old` value, the DPP move
+// and the add per step); the s_nop covers the 2 wait states a DPP read needs after a VALU write of its source
+__device__ __forceinline__ void half_sum_dpp4(float &a, float &b, float &c, float &d) {
+#define DPP_STEP4(ctrl)                                                                                                \
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl \
+        "\n\tv_add_f32_dpp %3, %3, %3 " ctrl                                                                           \
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+    DPP_STEP4("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    DPP_STEP4("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    DPP_STEP4("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    DPP_STEP4("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    DPP_STEP4("row_bcast:15 row_mask:0xa bank_mask:0xf");
+#undef DPP_STEP4
+}
+
 template <int KB, int PSI2G_W_LO>
 __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
                                                            const double *__restrict__ mu, const double *__restrict__ s,
@@ -1589,7 +1604,7 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
                 dgam[i] -= sv * id2 * c01 + id2 * id2 * q2 + Dh;
             }
 #pragma unroll
-            for (int i = 0; i < QH; ++i) { xs[i] = half_sum_dpp(xs[i]); ys[i] = half_sum_dpp(ys[i]); }
+            for (int i = 0; i < QH; i += 2) half_sum_dpp4(xs[i], ys[i], xs[i + 1], ys[i + 1]);
             if (li5 == 31) {
 #pragma unroll
                 for (int i = 0; i < QH; ++i) {
