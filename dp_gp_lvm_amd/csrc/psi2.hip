@@ -1234,7 +1234,7 @@ __device__ __forceinline__ void half_sum_dpp4(float &a, float &b, float &c, floa
 }
 
 template <int KB, int PSI2G_W_LO>
-__global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
+__global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
                                                            const double *__restrict__ mu, const double *__restrict__ s,
                                                            const double *__restrict__ gamma, const double *__restrict__ alpha,
                                                            const double *__restrict__ GP, int Mp, int n_per_split,
@@ -1242,7 +1242,12 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
                                                            float *__restrict__ ds_part, double *__restrict__ dz_part,
                                                            double *__restrict__ dg_part) {
     typedef Psi2F16Lds<KB> G;
-    constexpr int PS = G::PS, XLD = G::XLD, ZLD = G::ZLD, PLD = G::PLD, NR = 16, KQ = G::KQ, QH = KQ / 2;
+    constexpr int PS = G::PS, XLD = G::XLD, ZLD = G::ZLD, PLD = G::PLD, NR = 16, KQ = G::KQ;
+    // latent dims per lane half, and the form of the second product: up to 12 latent dims z_hi, z_lo and the ones are 2 QH + 1
+    // <= 13 of the 16 result rows a lane half owns (one A operand); beyond that z_hi and z_lo are two A operands (QH + 1 rows,
+    // one more MFMA per step) and the kernel runs one workgroup per CU (register budget)
+    constexpr bool SPLITZ = KB > 3;
+    constexpr int QH = KQ / 2 > 15 ? 15 : KQ / 2, QHE = QH + (QH & 1), ONES = SPLITZ ? QH : 2 * QH;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const Psi2PLayout L = psi2g_layout<KB>(Q);
     const int SL = L.SL, QS = L.QS, kf1 = SL / 32;
@@ -1331,16 +1336,17 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (lane == 0) zc[DPGP_MAX_Q + 2 + KQ + wv] = mx;      // (behind gq[KQ]; KQ + 4 <= DPGP_MAX_Q + 2)
+        if (lane == 0) xa[0] = mx;                             // (this wave's own area, not in use before phase A)
     }
     // Second product on the matrix pipe: per observation  T'^T[slot, m'] = sum_a Zt[slot, a] w[a, m'],  the w tile taken as
     // the B operand straight from the registers the exponent tile arrived in (k-slot 8 (l / 32) + j of step s <-> register
     // 8 s + j <-> patch row 8 (2 s + j / 4) + 4 (l / 32) + j % 4, the A operand is permuted to match).  Output rows (slots,
-    // 16 per lane half h): u < QH: z_hi[., QH h + u];  QH <= u < 2 QH: z_lo[., QH h + u - QH];  u = 2 QH: ones (column sums).
-    dpgp_h8 za[2][2];
+    // 16 per lane half h): u < QH: z_hi[., QH h + u];  QH <= u < 2 QH: z_lo[., QH h + u - QH];  u = 2 QH: ones (column sums);
+    // split form (more than 12 latent dims): u < QH: z_hi resp. z_lo in two operands, u = QH: ones.
+    dpgp_h8 za[2][2], zal[SPLITZ ? 2 : 1][2];                  // (zal: the z_lo operand of the split form)
     {
         const int rho = li5, u = 4 * (rho >> 3) + (rho & 3), hh = (rho >> 2) & 1;
-        const int qq = QH * hh + (u < QH ? u : u - QH);
+        const int qq = QH * hh + (SPLITZ ? u : (u < QH ? u : u - QH));
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -1348,19 +1354,20 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int a = 32 * I + 8 * (2 * s_ + (j >> 2)) + 4 * k2 + (j & 3);
-                    const float zv = (qq < Q) ? zs[a * ZLD + qq] : 0.0f;
-                    const _Float16 zh = (_Float16)zv;
+                    const float zv = (qq < Q && u < (SPLITZ ? QH : 2 * QH)) ? zs[a * ZLD + qq] : 0.0f;
+                    const _Float16 zh = (_Float16)zv, zl = (_Float16)(zv - (float)zh);
                     _Float16 val = (_Float16)0.0f;
                     if (u < QH) val = zh;
-                    else if (u < 2 * QH) val = (_Float16)(zv - (float)zh);
-                    else if (u == 2 * QH) val = (_Float16)1.0f;
+                    else if (!SPLITZ && u < 2 * QH) val = zl;
+                    else if (u == ONES) val = (_Float16)1.0f;
                     za[I][s_][j] = val;
+                    if (SPLITZ) zal[I][s_][j] = (u < QH) ? zl : (_Float16)0.0f;
                 }
     }
     __syncthreads();                                            // every wave is done with the row block of z: tiles may overwrite it
     {
-        const float *mxs = zc + DPGP_MAX_Q + 2 + KQ;
-        const float mx = fmaxf(fmaxf(mxs[0], mxs[1]), fmaxf(mxs[2], mxs[3]));
+        const float *mxs = zs + L.off_wave;
+        const float mx = fmaxf(fmaxf(mxs[0], mxs[L.wsz]), fmaxf(mxs[2 * L.wsz], mxs[3 * L.wsz]));
         if (mx > 0.0f && mx < 3.0e38f) {
             int ex;
             (void)frexpf(mx, &ex);
@@ -1565,6 +1572,8 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
                         acc[J][s_] += __builtin_bit_cast(float, whi[0] ^ whi[1] ^ whi[2] ^ whi[3] ^ wlo[0] ^ wlo[1] ^ wlo[2] ^ wlo[3]);
 #else
                         acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, whi), acc[J], 0, 0, 0);
+                        if (SPLITZ)
+                            acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(zal[SPLITZ ? I : 0][s_], __builtin_bit_cast(dpgp_h8, whi), acc[J], 0, 0, 0);
                         if (PSI2G_W_LO)
                             acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(za[I][s_], __builtin_bit_cast(dpgp_h8, wlo), acc[J], 0, 0, 0);
 #endif
@@ -1579,8 +1588,10 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
             // per lane, summed over the lanes once at the very end).   a2 = gamma / den2, id2 = 1 / den2:
             //   d/dmu = -2 a2 (mu' S0 - S1),  d/dS = -a2 S0 + 2 a2^2 q2,  q2 = mu'^2 S0 - 2 mu' S1 + (S2 + S3) / 2,
             //   d/dgamma = -S id2 S0 - id2^2 q2 - (S2 - S3) / 2     (S0 = sum C, S1 = sum C z', S2 = sum C z'^2, S3 = sum z' T')
-            const float cs[2] = {acc[0][2 * QH], acc[1][2 * QH]}, c01 = cs[0] + cs[1];
-            float xs[QH], ys[QH];
+            const float cs[2] = {acc[0][ONES], acc[1][ONES]}, c01 = cs[0] + cs[1];
+            float xs[QHE], ys[QHE];
+            xs[QHE - 1] = 0.0f;
+            ys[QHE - 1] = 0.0f;
 #pragma unroll
             for (int i = 0; i < QH; ++i) {
                 const float gg = gqr[i], a2 = xa[r * XLD + qb + i] * (float)(-2.0 / DPGP_LOG2E), mq = mus[r * XLD + qb + i];
@@ -1589,7 +1600,7 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
                 float a1 = 0.0f, a2s = 0.0f, a3 = 0.0f;
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
-                    const float tq = acc[J][i] + acc[J][QH + i], zq = zcr[J][i];
+                    const float tq = SPLITZ ? acc[J][i] : acc[J][i] + acc[J][QH + i], zq = zcr[J][i];
                     dz[J][i] += cT * tq + (tt - c2n * zq) * cs[J];
                     const float cz = cs[J] * zq;
                     a1 += cz;
@@ -1604,7 +1615,7 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
                 dgam[i] -= sv * id2 * c01 + id2 * id2 * q2 + Dh;
             }
 #pragma unroll
-            for (int i = 0; i < QH; i += 2) half_sum_dpp4(xs[i], ys[i], xs[i + 1], ys[i + 1]);
+            for (int i = 0; i < QHE; i += 2) half_sum_dpp4(xs[i], ys[i], xs[i + 1], ys[i + 1]);
             if (li5 == 31) {
 #pragma unroll
                 for (int i = 0; i < QH; ++i) {
@@ -1650,7 +1661,7 @@ __global__ __launch_bounds__(256, 2) void psi2_grad_kernel(int N, int M, int Q, 
     if (t < Q) dg_part[((size_t)(patch * n_splits + sp) * B + b) * Q + t] = (double)(unscale * (red[t] + red[KQ + t] + red[2 * KQ + t] + red[3 * KQ + t]));
 }
 
-bool psi2_grad_supported(int M, int Q) { return Q <= 12 && M >= 1; }
+bool psi2_grad_supported(int M, int Q) { return Q <= DPGP_MAX_Q && M >= 1; }
 int psi2_grad_nsplit(int B, int N, int M) {
     const int nps = dpgp_ceil_div(dpgp_round_up(M, 16), 64);
     int ns = dpgp_ceil_div(1024, B * nps * nps);
@@ -1697,7 +1708,7 @@ int launch_psi2_grad(int B, int N, int M, int Q, const unsigned char *consts, co
     if (!psi2_grad_supported(M, Q)) return -4;
     switch (dpgp_ceil_div(Q, 4)) {
 #define CASE(k) case k: return launch_psi2_grad_kb<k, 1>(B, N, M, Q, consts, mu, s, gamma, alpha, GP, part, stage, dmu, ds, dz, dgamma, st);
-        CASE(1) CASE(2) CASE(3)
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     }
     return -4;
