@@ -599,7 +599,8 @@ __global__ __launch_bounds__(256) void psi1_grad_n_kernel(int D, int N, int M, i
             }
 }
 
-template <int QP>
+// AL = lanes over the inducing points (64 for M <= 64, else 128); the 256 / AL groups of lanes share the observations
+template <int QP, int AL>
 __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, int Q, const double *__restrict__ y, int ldy,
                                                           const unsigned char *__restrict__ consts, const double *__restrict__ mu,
                                                           const double *__restrict__ s, const double *__restrict__ gamma,
@@ -608,10 +609,11 @@ __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, i
     constexpr int FS = 2 * QP + 4;                              // per observation: a1[QP], mu'[QP], e0, y, pad
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *fac = reinterpret_cast<float *>(smem_raw);           // [64][FS]
-    float *comb = fac + 64 * FS;                                // [128][QP] (end: the two observation lanes of a row)
+    constexpr int NLN = 256 / AL;
+    float *comb = fac + 64 * FS;                                // [NLN - 1][AL][QP] (end: the observation lanes of a row)
     const Psi2Consts C = psi2_consts_layout(M, Q);
     const float *zs_g = reinterpret_cast<const float *>(consts + C.off_zs), *zc = reinterpret_cast<const float *>(consts);
-    const int t = threadIdx.x, a = t & 127, nl = t >> 7;
+    const int t = threadIdx.x, a = t % AL, nl = t / AL;
     float za[QP], dza[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, i
                 }
             }
             __syncthreads();
-            for (int i = nl; i < 64; i += 2) {
+            for (int i = nl; i < 64; i += NLN) {
                 const float *f = fac + i * FS;
                 float c[QP], a1[QP], e = f[2 * QP];
 #pragma unroll
@@ -669,14 +671,18 @@ __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, i
         }
     }
     __syncthreads();
-    if (nl == 1)
+    if (nl > 0)
 #pragma unroll
-        for (int q = 0; q < QP; ++q) comb[a * QP + q] = dza[q];
+        for (int q = 0; q < QP; ++q) comb[((nl - 1) * AL + a) * QP + q] = dza[q];
     __syncthreads();
     if (nl == 0 && a < M)
 #pragma unroll
         for (int q = 0; q < QP; ++q)
-            if (q < Q) dz_part[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * M + a) * Q + q] = (double)(dza[q] + comb[a * QP + q]);
+            if (q < Q) {
+                float v = dza[q];
+                for (int k = 0; k < NLN - 1; ++k) v += comb[(k * AL + a) * QP + q];
+                dz_part[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * M + a) * Q + q] = (double)v;
+            }
 }
 
 // workspace (doubles) of launch_psi1_grad: d/dmu, d/dS partials [DC][N][Q] float; d/dgamma [NB][D][Q]; d/dz [DC ns][M][Q]
@@ -712,12 +718,12 @@ int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const
     void (*kz)(int, int, int, int, const double *, int, const unsigned char *, const double *, const double *, const double *,
                const double *, const double *, int, int, int, double *) = nullptr;
     switch (QPr / 4) {
-#define CASE(k) case k: kn = psi1_grad_n_kernel<4 * k>; kz = psi1_grad_z_kernel<4 * k>; break;
+#define CASE(k) case k: kn = psi1_grad_n_kernel<4 * k>; kz = Mp <= 64 ? psi1_grad_z_kernel<4 * k, 64> : psi1_grad_z_kernel<4 * k, 128>; break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     }
     if (!kn) return -4;
-    const size_t lds_n = sizeof(float) * ((size_t)M * QPr + Mp + 4 * QPr), lds_z = sizeof(float) * ((size_t)64 * (2 * QPr + 4) + 128 * QPr);
+    const size_t lds_n = sizeof(float) * ((size_t)M * QPr + Mp + 4 * QPr), lds_z = sizeof(float) * ((size_t)64 * (2 * QPr + 4) + 192 * QPr);
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(kn, dim3(NB, DC), dim3(256), lds_n, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, Mp, dpw,
                        dmu_part, ds_part, dg_part);
     DPGP_LAUNCH_CHECK();
