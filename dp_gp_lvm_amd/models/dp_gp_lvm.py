@@ -283,3 +283,144 @@ def dp_gp_lvm(y_train,
             raise NotImplementedError('prediction paths (dp_gp_lvm.py:233-500) are SURVEY.md §8(f) row 2: not built yet')
 
     return DP_GP_LVM()
+
+
+def dp_gp_lvm_t(y_train,
+                num_latent_dims=GP_LVM_DEFAULT_LATENT_DIMENSIONS,
+                num_inducing_points=GP_LVM_DEFAULT_NUM_INDUCING_POINTS,
+                truncation_level=DP_DEFAULT_TRUNCATION_LEVEL,
+                alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
+                mask_size=1,
+                seed=0,
+                device=None, precision='mixed', initial_values=None):
+    """
+    Over-T formulation — mirror of the reference's ``dp_gp_lvm_t`` factory (src/models/dp_gp_lvm.py:513-676), SURVEY.md
+    §8(f) row 3: the kernel batch is the T atoms, the mixture weights phi [T x D] enter outside the kernel, so an evaluation
+    needs T Psi2's instead of D.  A different objective from ``dp_gp_lvm`` away from equal atoms (equal at the reference's
+    initialisation, test/unittests/dpgplvm_unitttests.py:544-548).  Objective only (forward); composed of the library's
+    operators in the B_t = K_t + beta_t Psi2_t algebra of DESIGN.md §2:
+
+        Psi1 [T,N,M], Psi2 [T,M,M], K_uu [T,M,M]       dpgp_psi1 / dpgp_psi2 / dpgp_ard_rbf_gram      (:611-620)
+        L_K, L_B = chol(K), chol(K + beta Psi2)         dpgp_potrf_batched                             (:620,633)
+        <K^-1, Psi2> by two triangular solves           dpgp_trsm_batched                              (:622-629)
+        V = Psi1^T Y  [T,M,D]                           one plain fp64 GEMM (rocBLAS through torch.matmul)
+        C = L_B^-1 V, 1/2 sum_td phi_td beta_t^2 |C_td|^2   dpgp_trsm_batched                          (:638-658)
+
+    precision: 'f64', or 'mixed' = the Psi statistics in fp32 (f16-split MFMA kernels), everything after them in fp64.
+    """
+    num_samples, num_dimensions = np.shape(y_train)
+    assert 0 < num_latent_dims < num_dimensions, \
+        'Number of latent dimensions must be postive and less than the dimensionality of the observed data.'
+    assert 0 < num_inducing_points <= num_samples, \
+        'Number of inducing points must be positive and less than or equal to the number of observations in the ' \
+        'observed data.'
+    assert 0 < truncation_level <= min(num_samples, num_dimensions), \
+        'The truncation level must be positive and less than or equal to the dimensionality of the observed data and ' \
+        'less than or equal to the number of observations.'
+    assert isinstance(seed, int) and seed >= 0, 'Seed must be a 32-bit unsigned integer, i.e., 0 <= seed <= 2^32 - 1.'
+    assert precision in ('mixed', 'f64'), "precision must be 'mixed' or 'f64'"
+    np.random.seed(seed=seed)
+    device = default_device() if device is None else torch.device(device)
+    iv = dict(initial_values or {})
+
+    def _t(a):
+        return torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=TORCH_DTYPE, device=device).contiguous()
+
+    def _raw_pos(name, init, shape):
+        if name in iv:
+            return _t(np.log(np.expm1(np.asarray(iv[name], dtype=np.float64).reshape(shape))))
+        return create_positive_variable(init, shape, device=device)
+
+    x_init = np.asarray(iv['x_mean'], dtype=np.float64) if 'x_mean' in iv else \
+        pca(np.asarray(y_train), num_latent_dimensions=num_latent_dims)
+    x_mean = _t(x_init)
+    x_var_raw = _raw_pos('x_var', 1.0, (num_samples, num_latent_dims))
+    x_u = _t(iv['x_u']) if 'x_u' in iv else \
+        _t(np.random.permutation(x_init)[:num_inducing_points] +
+           np.random.normal(loc=0.0, scale=0.01, size=(num_inducing_points, num_latent_dims)))
+    dp_model = dirichlet_process(num_samples=num_dimensions, alpha_prior_params=alpha_prior_params,
+                                 truncation_level=truncation_level, mask_size=mask_size, device=device)
+    for key, name in (('logits', 'phi_logits'), ('gamma_1', 'gamma_1'), ('gamma_2', 'gamma_2')):
+        if name in iv:
+            v = np.asarray(iv[name], dtype=np.float64)
+            dp_model.raw[key].copy_(_t(v if key == 'logits' else np.log(np.expm1(v))).reshape(dp_model.raw[key].shape))
+    for i, name in enumerate(('w_1', 'w_2')):
+        if name in iv:
+            dp_model.raw['w'][i] = float(np.log(np.expm1(float(iv[name]))))
+    gamma_atoms_raw = _raw_pos('gamma_atoms', GP_INIT_GAMMA, (truncation_level, num_latent_dims))
+    sig_var_atoms_raw = _raw_pos('alpha_atoms', GP_INIT_ALPHA, (truncation_level, 1))
+    beta_atoms_raw = _raw_pos('beta_atoms', GP_INIT_BETA, (truncation_level, 1))
+    y_dev = _t(np.asarray(y_train))
+    yy = torch.sum(y_dev * y_dev, dim=0)                                       # [D]
+    from ..distributions.log_normal import log_pdf as log_normal_log_pdf
+
+    def evaluate():
+        """(objective, f_hat, KL, DP objective, hyper-prior log-likelihood) as a device tensor."""
+        gat, aat, bat = F.softplus(gamma_atoms_raw), F.softplus(sig_var_atoms_raw)[:, 0], F.softplus(beta_atoms_raw)[:, 0]
+        s = F.softplus(x_var_raw)
+        phit = dp_model.assignments.transpose(0, 1)                              # [T x D]
+        pt = torch.float32 if precision == 'mixed' else TORCH_DTYPE
+        cast = lambda a: a.to(pt).contiguous()
+        psi_1 = ops.psi1(cast(x_u), cast(x_mean), cast(s), cast(gat), cast(aat)).to(TORCH_DTYPE)     # [T x N x M]
+        psi_2 = ops.psi2(cast(x_u), cast(x_mean), cast(s), cast(gat), cast(aat)).to(TORCH_DTYPE)     # [T x M x M]
+        k_uu = ops.ard_rbf_gram(x_u, None, gat, aat, bat, include_noise=False, include_jitter=True,
+                                jitter=GP_DEFAULT_JITTER)                                             # [T x M x M]
+        l_k, info_k = ops.potrf_batched(k_uu)
+        l_b, info_b = ops.potrf_batched(k_uu + bat[:, None, None] * psi_2)
+        h = ops.trsm_batched(l_k, psi_2)                                         # L^-1 Psi2
+        tr = torch.diagonal(ops.trsm_batched(l_k, h.transpose(1, 2).contiguous()), dim1=-2, dim2=-1).sum(-1)
+        logdet = torch.log(torch.diagonal(l_b, dim1=-2, dim2=-1)).sum(-1) - torch.log(torch.diagonal(l_k, dim1=-2, dim2=-1)).sum(-1)
+        c = ops.trsm_batched(l_b, torch.matmul(psi_1.transpose(1, 2), y_dev))    # [T x M x D]
+        quad = bat[:, None] ** 2 * torch.sum(c * c, dim=1)                       # [T x D]
+        per_t = 0.5 * (num_samples * torch.log(bat) + bat * (tr - num_samples * aat)) - logdet
+        f_hat = -0.5 * num_samples * num_dimensions * np.log(2.0 * np.pi) + torch.sum(phit * per_t[:, None]) \
+            - 0.5 * torch.sum(phit * bat[:, None] * yy[None, :]) + 0.5 * torch.sum(phit * quad)
+        kl = ops.kl_qx(x_mean, s)
+        hyper = torch.sum(log_normal_log_pdf(gat)) + torch.sum(log_normal_log_pdf(aat)) + torch.sum(log_normal_log_pdf(bat))
+        dp_obj = dp_model.objective
+        out = torch.stack([dp_obj - (f_hat - kl) - hyper, f_hat, kl, dp_obj, hyper])
+        return out, torch.maximum(info_k.abs().max(), info_b.abs().max())
+
+    class DP_GP_LVM_T(Trainable):
+        """Accessors as in the reference (dp_gp_lvm.py:679-740); the kernel has batch size T here."""
+        raw = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw,
+                   beta_atoms=beta_atoms_raw, **{'dp_' + k: v for k, v in dp_model.raw.items()})
+
+        @property
+        def assignments(self):
+            return dp_model.assignments
+
+        @property
+        def dp(self):
+            return dp_model
+
+        @property
+        def dp_atoms(self):
+            return F.softplus(gamma_atoms_raw), F.softplus(sig_var_atoms_raw), F.softplus(beta_atoms_raw)
+
+        @property
+        def kernel(self):
+            return k_ard_rbf(gamma=F.softplus(gamma_atoms_raw), alpha=F.softplus(sig_var_atoms_raw),
+                             beta=F.softplus(beta_atoms_raw))
+
+        @property
+        def inducing_input(self):
+            return x_u
+
+        @property
+        def q_x(self):
+            return x_mean, torch.diag_embed(F.softplus(x_var_raw))
+
+        @property
+        def objective(self):
+            return evaluate()[0][0].clone()
+
+        @property
+        def objective_terms(self):
+            return evaluate()[0]
+
+        @property
+        def cholesky_info(self):
+            return evaluate()[1]
+
+    return DP_GP_LVM_T()

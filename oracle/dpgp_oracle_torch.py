@@ -167,3 +167,83 @@ def objective_and_gradients(y, raw_values, s_1=1.0, s_2=1.0, mask_size=1, jitter
     out = {k: (np.zeros_like(np.asarray(raw_values[k], dtype=np.float64)) if g is None else g.numpy().copy())
            for k, g in zip(NAMES, grads)}
     return float(obj), out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Over-T formulation (reference dp_gp_lvm.py:513-676): the kernel batch is the T atoms instead of the
+# D mixed hyper-parameter rows, the mixture weights phi enter outside the kernel.  Pinned by oracle/gen_golden_t.py
+# (the reference's own dp_gp_lvm_t constructor under the PyTorch stand-in): objective rtol 1e-11, gradients rtol 1e-7.
+# --------------------------------------------------------------------------------------------------------------------
+def psi_pieces_t(y, z, mu, s, gamma, alpha, jitter=GP_DEFAULT_JITTER, chunk=64):
+    """As psi_pieces for T hyper-parameter rows, but Psi1 contracted with ALL columns of y: V [T,M,D] = Psi1_t^T Y."""
+    n, d = y.shape
+    t, m = gamma.shape[0], z.shape[0]
+    zd = z[:, None, :] - z[None, :, :]
+    zbar = 0.5 * (z[:, None, :] + z[None, :, :])
+    sq = torch.einsum('dq,ijq->dij', gamma, zd * zd)
+    k_uu = alpha[:, None, None] * torch.exp(-0.5 * sq) + jitter * torch.eye(m, dtype=y.dtype)
+    v = torch.zeros((t, m, d), dtype=y.dtype)
+    p2 = torch.zeros((t, m, m), dtype=y.dtype)
+    t1 = 0.25 * sq
+    for n0 in range(0, n, chunk):
+        mu_c, s_c, y_c = mu[n0:n0 + chunk], s[n0:n0 + chunk], y[n0:n0 + chunk]
+        den1 = gamma[:, None, :] * s_c[None] + 1.0
+        e1 = torch.einsum('cmq,dcq->dcm', (mu_c[:, None, :] - z[None]) ** 2, gamma[:, None, :] / den1) \
+            + torch.sum(torch.log(den1), dim=-1)[:, :, None]
+        p1 = alpha[:, None, None] * torch.exp(-0.5 * e1)                                     # [T,c,M]
+        v = v + torch.einsum('tcm,cd->tmd', p1, y_c)
+        den2 = 2.0 * gamma[:, None, :] * s_c[None] + 1.0
+        num = (mu_c[:, None, None, :] - zbar[None]) ** 2
+        e2 = torch.einsum('cijq,dcq->dcij', num, gamma[:, None, :] / den2)
+        lp = 2.0 * torch.log(alpha)[:, None, None, None] - (0.5 * torch.sum(torch.log(den2), dim=-1)[:, :, None, None]
+                                                             + t1[:, None] + e2)
+        p2 = p2 + torch.sum(torch.exp(lp), dim=1)
+    return k_uu, p2, v
+
+
+def fhat_t(y, z, mu, s, phi, gamma, alpha, beta, jitter=GP_DEFAULT_JITTER, chunk=64):
+    """f_hat of dp_gp_lvm.py:617-667 in the B_t = K_t + beta_t Psi2_t form:
+        -1/2 N D log 2 pi + sum_td phi_td [ 1/2 (N log beta_t + beta_t (<K_t^-1, Psi2_t> - N alpha_t)) - (log|L_B| - log|L_K|) ]
+        - 1/2 sum_td phi_td beta_t y_d^T y_d + 1/2 sum_td phi_td beta_t^2 || L_B,t^-1 Psi1_t^T y_d ||^2     (phi [D,T])"""
+    n, d = y.shape
+    k_uu, p2, v = psi_pieces_t(y, z, mu, s, gamma, alpha, jitter=jitter, chunk=chunk)
+    l_k = torch.linalg.cholesky(k_uu)
+    l_b = torch.linalg.cholesky(k_uu + beta[:, None, None] * p2)
+    logdet_k = torch.sum(torch.log(torch.diagonal(l_k, dim1=-2, dim2=-1)), dim=-1)
+    logdet_b = torch.sum(torch.log(torch.diagonal(l_b, dim1=-2, dim2=-1)), dim=-1)
+    tr = torch.sum(torch.cholesky_solve(p2, l_k).diagonal(dim1=-2, dim2=-1), dim=-1)
+    c = torch.linalg.solve_triangular(l_b, v, upper=False)                                   # [T,M,D]
+    quad = beta[:, None] ** 2 * torch.sum(c * c, dim=1)                                      # [T,D]
+    per_t = 0.5 * (n * torch.log(beta) + beta * (tr - alpha * n)) - (logdet_b - logdet_k)    # [T]
+    phit = phi.transpose(0, 1)                                                               # [T,D]
+    yy = torch.sum(y * y, dim=0)
+    return -0.5 * n * d * LOG_2PI + torch.sum(phit * per_t[:, None]) - 0.5 * torch.sum(phit * beta[:, None] * yy[None, :]) \
+        + 0.5 * torch.sum(phit * quad)
+
+
+def objective_t(y, raw, s_1=1.0, s_2=1.0, mask_size=1, jitter=GP_DEFAULT_JITTER):
+    """dp_gp_lvm.py:560-676 (dp_gp_lvm_t) as a function of the same eleven raw variables."""
+    mu, z = raw['x_mean'], raw['x_u']
+    s = _softplus(raw['x_var_raw'])
+    phi = torch.softmax(raw['dp_logits'], dim=-1)
+    if mask_size != 1:
+        phi = torch.repeat_interleave(phi, int(mask_size), dim=0)
+    g1, g2 = _softplus(raw['gamma_1_raw']).reshape(-1), _softplus(raw['gamma_2_raw']).reshape(-1)
+    w1, w2 = _softplus(raw['w_1_raw']).reshape(()), _softplus(raw['w_2_raw']).reshape(())
+    gat, aat, bat = (_softplus(raw[k]) for k in ('gamma_atoms_raw', 'alpha_atoms_raw', 'beta_atoms_raw'))
+    f = fhat_t(y, z, mu, s, phi, gat, aat[:, 0], bat[:, 0], jitter=jitter)
+    kl = 0.5 * (torch.sum(mu * mu) + torch.sum(s - torch.log(s)) - mu.shape[0] * mu.shape[1])
+    hyper = sum(torch.sum(_log_normal_log_pdf(a)) for a in (gat, aat, bat))
+    dp = dp_objective(phi, g1, g2, w1, w2, float(s_1), float(s_2))
+    return dp - (f - kl) - hyper, dict(f_hat=f, kl=kl, hyperprior=hyper, dp_objective=dp)
+
+
+def objective_t_and_gradients(y, raw_values, s_1=1.0, s_2=1.0, mask_size=1, jitter=GP_DEFAULT_JITTER):
+    yt = torch.as_tensor(np.asarray(y), dtype=torch.float64)
+    raw = {k: torch.tensor(np.asarray(raw_values[k], dtype=np.float64), dtype=torch.float64, requires_grad=True)
+           for k in NAMES}
+    obj, _ = objective_t(yt, raw, s_1=s_1, s_2=s_2, mask_size=mask_size, jitter=jitter)
+    grads = torch.autograd.grad(obj, [raw[k] for k in NAMES], allow_unused=True)
+    out = {k: (np.zeros_like(np.asarray(raw_values[k], dtype=np.float64)) if g is None else g.numpy().copy())
+           for k, g in zip(NAMES, grads)}
+    return float(obj), out

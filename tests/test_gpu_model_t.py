@@ -1,0 +1,66 @@
+"""GPU tests of the over-T formulation ``dp_gp_lvm_t`` (reference src/models/dp_gp_lvm.py:513-676):
+the objective composed of the library's operators against fixtures produced by the reference's own constructor
+(oracle/gen_golden_t.py -> tests/golden/model_t_ref_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def softplus(x):
+    return np.logaddexp(0.0, x)
+
+
+def values(g, prefix=''):
+    sp = softplus
+    return dict(x_mean=g[prefix + 'x_mean'], x_var=sp(g[prefix + 'x_var_raw']), x_u=g[prefix + 'x_u'],
+                phi_logits=g[prefix + 'dp_logits'], gamma_atoms=sp(g[prefix + 'gamma_atoms_raw']),
+                alpha_atoms=sp(g[prefix + 'alpha_atoms_raw']), beta_atoms=sp(g[prefix + 'beta_atoms_raw']),
+                gamma_1=sp(g[prefix + 'gamma_1_raw']), gamma_2=sp(g[prefix + 'gamma_2_raw']),
+                w_1=float(sp(g[prefix + 'w_1_raw'])), w_2=float(sp(g[prefix + 'w_2_raw'])))
+
+
+def build(factory, g, dev, prec, prefix=''):
+    return factory(g['y'], num_latent_dims=g['x_mean'].shape[1], num_inducing_points=g['x_u'].shape[0],
+                   truncation_level=g['dp_logits'].shape[1], alpha_prior_params=np.array([float(g['s_1']), float(g['s_2'])]),
+                   device=dev, precision=prec, initial_values=values(g, prefix))
+
+
+@pytest.mark.parametrize('fixture', ['model_t_ref_40_6_12_3_T4', 'model_t_ref_60_10_15_4_T5'])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_objective_matches_the_reference(dev, fixture, prec):
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+    g = golden(fixture)
+    model = build(dp_gp_lvm_t, g, dev, prec)
+    assert int(model.cholesky_info) == 0
+    np.testing.assert_allclose(float(model.objective), float(g['objective']), rtol=1e-10 if prec == 'f64' else 2e-6)
+
+
+@pytest.mark.parametrize('fixture', ['model_t_ref_40_6_12_3_T4', 'model_t_ref_60_10_15_4_T5'])
+def test_equal_atoms_known_answer(dev, fixture):
+    """The reference's own check of this model (test/unittests/dpgplvm_unitttests.py:544-548): at the initialisation, where
+    all atoms are equal, the over-T and the over-D objectives coincide — here with both HIP paths."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm, dp_gp_lvm_t
+    g = golden(fixture)
+    m_t, m_d = build(dp_gp_lvm_t, g, dev, 'f64', 'init_'), build(dp_gp_lvm, g, dev, 'f64', 'init_')
+    o_t, o_d = float(m_t.objective), float(m_d.objective)
+    np.testing.assert_allclose(o_t, float(g['objective_init']), rtol=1e-10)
+    np.testing.assert_allclose(o_d, o_t, rtol=1e-9)
+
+
+def test_accessors_and_shapes(dev):
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal((50, 9))
+    y = (y - y.mean(0)) / y.std(0)
+    model = dp_gp_lvm_t(y, num_latent_dims=3, num_inducing_points=10, truncation_level=4, device=dev, seed=1)
+    terms = model.objective_terms
+    assert terms.shape == (5,) and bool(torch.isfinite(terms).all())
+    np.testing.assert_allclose(float(terms[0]), float(terms[3] - (terms[1] - terms[2]) - terms[4]), rtol=1e-12)
+    assert model.assignments.shape == (9, 4) and model.inducing_input.shape == (10, 3)
+    assert model.kernel.covariance_matrix(model.inducing_input, None).shape == (4, 10, 10)
+    with pytest.raises(AssertionError):
+        dp_gp_lvm_t(y, num_latent_dims=9, num_inducing_points=10, truncation_level=4, device=dev)

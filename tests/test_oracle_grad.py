@@ -61,3 +61,32 @@ def test_gradient_is_consistent_with_finite_differences_of_the_numpy_oracle(path
     fd = (f({k: raw[k] + h * dirs[k] for k in raw}) - f({k: raw[k] - h * dirs[k] for k in raw})) / (2 * h)
     an = sum(float(np.sum(grads[k] * dirs[k])) for k in raw)
     assert abs(fd - an) <= 1e-6 * max(1.0, abs(an))
+
+
+# ---- over-T formulation: fixtures from the reference's own dp_gp_lvm_t (oracle/gen_golden_t.py) ----
+FIXTURES_T = sorted(glob.glob(os.path.join(GOLDEN, 'model_t_ref_*.npz')))
+
+
+def test_over_t_fixtures_exist():
+    assert len(FIXTURES_T) >= 2
+
+
+@pytest.mark.parametrize('path', FIXTURES_T, ids=[os.path.basename(p) for p in FIXTURES_T])
+def test_torch_oracle_reproduces_the_over_t_reference(path):
+    g = np.load(path)
+    obj, grads = ot.objective_t_and_gradients(g['y'], {k: g[k] for k in ot.NAMES}, s_1=float(g['s_1']), s_2=float(g['s_2']),
+                                              mask_size=int(g['mask_size']))
+    np.testing.assert_allclose(obj, float(g['objective']), rtol=1e-11)
+    for k in ot.NAMES:
+        ref = g['grad_' + k]
+        np.testing.assert_allclose(grads[k], ref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=k)
+    # the reference's known answer (dpgplvm_unitttests.py:544-548): with equal atoms the over-T and the over-D objectives agree
+    init = {k: g['init_' + k] for k in ot.NAMES}
+    o_t, _ = ot.objective_t_and_gradients(g['y'], init, s_1=float(g['s_1']), s_2=float(g['s_2']))
+    o_d, _ = ot.objective_and_gradients(g['y'], init, s_1=float(g['s_1']), s_2=float(g['s_2']))
+    np.testing.assert_allclose(o_t, float(g['objective_init']), rtol=1e-11)
+    np.testing.assert_allclose(o_d, o_t, rtol=1e-9)
+    # away from equal atoms they are different models
+    o_d2, _ = ot.objective_and_gradients(g['y'], {k: g[k] for k in ot.NAMES}, s_1=float(g['s_1']), s_2=float(g['s_2']))
+    np.testing.assert_allclose(o_d2, float(g['objective_over_d']), rtol=1e-10)
+    assert abs(o_d2 - obj) > 1e-3
