@@ -141,13 +141,12 @@ def main():
     n, d, m, q = shape
     p = make_problem(a.config)
     t = p['phi'].shape[1]
+    init = dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']), gamma_atoms=p['gamma_atoms'],
+                alpha_atoms=p['alpha_atoms'], beta_atoms=p['beta_atoms'], gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'],
+                w_2=p['w2'])
     model = dp_gp_lvm(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=t,
                       alpha_prior_params=np.array([p['s1'], p['s2']]), device=dev, precision=a.prec,
-                      process_group=group,
-                      initial_values=dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']),
-                                          gamma_atoms=p['gamma_atoms'], alpha_atoms=p['alpha_atoms'],
-                                          beta_atoms=p['beta_atoms'], gamma_1=p['g1'], gamma_2=p['g2'],
-                                          w_1=p['w1'], w_2=p['w2']))
+                      process_group=group, initial_values=init)
     lib = _lib.lib()
     d_lo, d_hi = model.shard
     outs = torch.zeros((a.steps, 5), dtype=torch.float64, device=dev)   # every step's objective breakdown stays on the device
@@ -233,18 +232,35 @@ def main():
         if world == 1 and not a.no_secondary:
             res['secondary'] = secondary(dev, shape, p)
         if world == 1 and not a.no_grad and a.prec != 'f32' and m <= 128:
-            # side measurement, not the headline metric: one objective evaluation + the gradients of all raw variables
-            # (first version of the backward pass; what one Adam iteration of the reference needs)
+            # side measurements, not the headline metric: (1) one objective evaluation + the gradients of all raw variables
+            # (backward pass; what one Adam iteration of the reference needs); (2) one objective evaluation
+            # of the over-T formulation dp_gp_lvm_t on the same data (8f row 3: T Psi2's instead of D)
             for _ in range(2):
                 model.gradients()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            reps = 5
+            reps = 10
             for _ in range(reps):
                 model.gradients()
             torch.cuda.synchronize()
             res['objective_and_gradients'] = {'ms': 1e3 * (time.perf_counter() - t0) / reps, 'reps': reps,
-                                              'note': 'first, unoptimised backward pass (plain VALU streaming kernel)'}
+                                              'note': 'stage B of the backward pass on the matrix pipe in mixed precision '
+                                                      '(psi2_grad_kernel), plain kernel in f64; DESIGN.md 7.1'}
+            if a.prec in ('mixed', 'f64'):
+                from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+                model_t = dp_gp_lvm_t(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=p['phi'].shape[1],
+                                      alpha_prior_params=np.array([p['s1'], p['s2']]), device=dev, precision=a.prec,
+                                      initial_values=init)
+                for _ in range(2):
+                    model_t.objective_terms
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    model_t.objective_terms
+                torch.cuda.synchronize()
+                res['objective_over_t'] = {'ms': 1e3 * (time.perf_counter() - t0) / reps, 'reps': reps,
+                                           'truncation_level': int(p['phi'].shape[1]),
+                                           'note': 'dp_gp_lvm_t objective, composed of the library operators (not fused)'}
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(a.config, p, shape, a.cpu_dims)
         print(json.dumps(res))
