@@ -1737,10 +1737,14 @@ template <typename T, int KS> static size_t psi2_lds_bytes() {
 }
 
 int psi2_nsplit(int B, int N, int M) {
-    // Split the observations so that the workgroups fill whole "rounds" of the GPU: R = 256 CUs x 2 resident workgroups
-    // (the fp32 kernel holds 2 waves per SIMD).  With W = B * patches * ns workgroups of N / ns rows each, the makespan
-    // is ~ ceil(W / R) * N / ns: take the ns (<= 8, >= 128 rows per split) that minimises it.
-    const int np64 = dpgp_ceil_div(M, 64), patches = np64 * (np64 + 1) / 2, R = 512;
+    // Split the observations so that the workgroups fill whole "rounds" of the GPU: R = 256 CUs x 2 resident workgroups.
+    // Jobs: W = B * patches * ns patch workgroups of L = ceil(N / ns) rows (rounded up to the 64 rows the 4 waves take per
+    // step) and, when the K_uu branch rides in the same dispatch (LDS-resident sizes, M <= 128), B chain tasks of ~60 us =
+    // CK row-equivalents each -- before the patches for B < 256, after them otherwise (psi2_task_1d).  The makespan of that
+    // list schedule, in rows, is minimised over ns <= 8 (>= 128 rows per split).  Config 2 (B = 64): 8 splits are 1536 + 64
+    // workgroups = 3 rounds and a 4th one for the chain tasks (4 x 256 rows); 5 splits are 1024 = 2 rounds of 448 rows.
+    const int np64 = dpgp_ceil_div(M, 64), patches = np64 * (np64 + 1) / 2, R = 512, CK = 250;
+    const long long nchain = (M <= 128) ? B : 0;
     int max_ns = N / 128;
     if (max_ns > 8) max_ns = 8;
     if (max_ns < 1) max_ns = 1;
@@ -1748,7 +1752,28 @@ int psi2_nsplit(int B, int N, int M) {
     double best_t = 1e300;
     for (int ns = 1; ns <= max_ns; ++ns) {
         const long long W = (long long)B * patches * ns;
-        const double t = (double)((W + R - 1) / R) / (double)ns;
+        long long L = dpgp_round_up(dpgp_ceil_div(N, ns), 64);
+        if (L > N) L = N;
+        double t;
+        if (nchain == 0) {
+            t = (double)((W + R - 1) / R) * (double)L;
+        } else if (B >= 256) {                                   // patches first, chain tasks fill up behind them
+            const long long f = W / R, rem = W % R, free_slots = R - rem;
+            const double tail = (double)f * L + (double)((nchain + free_slots - 1) / free_slots) * CK;
+            const double body = (double)(rem ? f + 1 : f) * L;
+            t = tail > body ? tail : body;
+        } else {                                                 // chain tasks first on B slots, patches on the earliest free slot
+            const long long busy = nchain < R ? nchain : R;
+            t = 1e300;
+            for (long long k = 1; k <= W; ++k) {                 // candidate makespans k L and CK + k L
+                const double t1 = (double)k * L;
+                const long long k_busy1 = t1 >= CK ? (long long)((t1 - CK) / L) : 0;
+                if ((R - busy) * k + busy * k_busy1 >= W && t1 < t) t = t1;
+                const double t2 = (double)CK + (double)k * L;
+                if ((R - busy) * (long long)(t2 / L) + busy * k >= W && t2 < t) t = t2;
+                if (t < 1e299 && t1 > t) break;
+            }
+        }
         if (t < best_t * 0.999) { best_t = t; best = ns; }
     }
     return best;
