@@ -154,9 +154,14 @@ extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, i
         // of the work) on the matrix pipe -- where those apply; otherwise everything by the plain kernel
         const bool fast = psi2_grad_supported(M, Q) && !getenv("DPGP_GRAD_PLAIN");
         hipStream_t st = (hipStream_t)stream;
-        int rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu,
-                                        d_s, d_z, d_gamma, fast ? 0 : 1, st);
-        if (rc != DPGP_OK || !fast) return rc;
+        const bool big = dpgp_round_up(M, 16) > 128;             // the plain kernel holds one row of the M x M statistics per thread
+        if (big && !fast) return -30;
+        int rc = DPGP_OK;
+        if (!big) {
+            rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
+                                        d_z, d_gamma, fast ? 0 : 1, st);
+            if (rc != DPGP_OK || !fast) return rc;
+        }
         const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
         unsigned char *consts = (unsigned char *)ws + dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
         double *part = reinterpret_cast<double *>(consts + dpgp_align256(psi2_consts_bytes(M, Q)));
@@ -165,10 +170,15 @@ extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, i
         (void)mx;
         rc = launch_psi2_consts<double>(z, M, Q, consts, st);
         if (rc != DPGP_OK) return rc;
+        if (big) {                                               // K_uu term for any M (partials in the plain kernel's workspace)
+            rc = launch_kuu_grad(D, M, Q, consts, gamma, w_kuu, (double *)ws, stage, d_z, d_gamma, st);
+            if (rc != DPGP_OK) return rc;
+        }
         rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, ws1, stage, d_mu, d_s, d_z, d_gamma, st);
         if (rc != DPGP_OK) return rc;
         return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, part, stage, d_mu, d_s, d_z, d_gamma, st);
     }
+    if (dpgp_round_up(M, 16) > 128) return -30;
     return launch_psi_grad<double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
                                    d_z, d_gamma, 1, (hipStream_t)stream);
 }

@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, i
     float *comb = fac + 64 * FS;                                // [NLN - 1][AL][QP] (end: the observation lanes of a row)
     const Psi2Consts C = psi2_consts_layout(M, Q);
     const float *zs_g = reinterpret_cast<const float *>(consts + C.off_zs), *zc = reinterpret_cast<const float *>(consts);
-    const int t = threadIdx.x, a = t % AL, nl = t / AL;
+    const int t = threadIdx.x, a = blockIdx.z * AL + t % AL, al_ = t % AL, nl = t / AL;
     float za[QP], dza[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
@@ -673,16 +673,100 @@ __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, i
     __syncthreads();
     if (nl > 0)
 #pragma unroll
-        for (int q = 0; q < QP; ++q) comb[((nl - 1) * AL + a) * QP + q] = dza[q];
+        for (int q = 0; q < QP; ++q) comb[((nl - 1) * AL + al_) * QP + q] = dza[q];
     __syncthreads();
     if (nl == 0 && a < M)
 #pragma unroll
         for (int q = 0; q < QP; ++q)
             if (q < Q) {
                 float v = dza[q];
-                for (int k = 0; k < NLN - 1; ++k) v += comb[(k * AL + a) * QP + q];
+                for (int k = 0; k < NLN - 1; ++k) v += comb[(k * AL + al_) * QP + q];
                 dz_part[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * M + a) * Q + q] = (double)v;
             }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_uu term of stage B for any M (the plain kernel above holds one row per thread, M <= 128): wk = (df/dK_uu) .* (K_uu - jitter I)
+// symmetric,  R[a] = sum_m' wk[a,m'],  T[a,q] = sum_m' wk[a,m'] z_m'q:   d/dz_aq = -2 gamma_q (z_aq R - T),
+// d/dgamma_q = -sum_a (R z_aq^2 - z_aq T).   Workgroup = (64 rows a, output dim), 4 lane groups share the columns m'.
+// ---------------------------------------------------------------------------------------------------------------
+template <int QP>
+__global__ __launch_bounds__(256) void kuu_grad_kernel(int D, int M, int Mp, int Q, const unsigned char *__restrict__ consts,
+                                                       const double *__restrict__ gamma, const double *__restrict__ WK,
+                                                       double *__restrict__ dz_part, double *__restrict__ dg_part) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *zs = reinterpret_cast<float *>(smem_raw);            // [M][QP] centred
+    float *comb = zs + (size_t)M * QP;                          // [3][64][QP + 1]
+    float *red = comb + 3 * 64 * (QP + 1);                      // [QP]
+    const Psi2Consts C = psi2_consts_layout(M, Q);
+    const float *zs_g = reinterpret_cast<const float *>(consts + C.off_zs);
+    const int t = threadIdx.x, al = t & 63, part = t >> 6, a = blockIdx.x * 64 + al, d = blockIdx.y;
+    for (int e = t; e < M * QP; e += 256) {
+        const int r = e / QP, q = e - r * QP;
+        zs[e] = (q < C.ZLD) ? zs_g[(size_t)r * C.ZLD + q] : 0.0f;
+    }
+    if (t < QP) red[t] = 0.0f;
+    __syncthreads();
+    const double *W = WK + (size_t)d * Mp * Mp;
+    float R = 0.0f, T[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) T[q] = 0.0f;
+    if (a < M)
+        for (int mp = part; mp < M; mp += 4) {
+            const float w = (float)((a >= mp) ? W[(size_t)a * Mp + mp] : W[(size_t)mp * Mp + a]);
+            R += w;
+#pragma unroll
+            for (int q = 0; q < QP; ++q) T[q] += w * zs[mp * QP + q];
+        }
+    if (part > 0) {
+        float *c = comb + ((part - 1) * 64 + al) * (QP + 1);
+        c[QP] = R;
+#pragma unroll
+        for (int q = 0; q < QP; ++q) c[q] = T[q];
+    }
+    __syncthreads();
+    if (part == 0) {
+        for (int k = 0; k < 3; ++k) {
+            const float *c = comb + (k * 64 + al) * (QP + 1);
+            R += c[QP];
+#pragma unroll
+            for (int q = 0; q < QP; ++q) T[q] += c[q];
+        }
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const float za = (a < M) ? zs[a * QP + q] : 0.0f;
+            const float g = (q < Q) ? (float)gamma[(size_t)d * Q + q] : 0.0f;
+            if (a < M && q < Q) dz_part[((size_t)d * M + a) * Q + q] = (double)(-2.0f * g * (za * R - T[q]));
+            float x = (a < M) ? -(R * za * za - za * T[q]) : 0.0f;
+            x = wave_sum(x);
+            if (al == 0) red[q] = x;
+        }
+    }
+    __syncthreads();
+    if (t < Q) dg_part[((size_t)blockIdx.x * D + d) * Q + t] = (double)red[t];
+}
+// dz [M,Q], dgamma [D,Q] overwritten.  ws: D M Q + ceil(M / 64) D Q doubles
+int launch_kuu_grad(int D, int M, int Q, const unsigned char *consts, const double *gamma, const double *WK, double *ws,
+                    double *stage, double *dz, double *dgamma, hipStream_t st) {
+    const int Mp = dpgp_round_up(M, 16), nblk = dpgp_ceil_div(M, 64), QPr = 4 * dpgp_ceil_div(Q, 4);
+    double *dz_part = ws, *dg_part = ws + (size_t)D * M * Q;
+    void (*k)(int, int, int, int, const unsigned char *, const double *, const double *, double *, double *) = nullptr;
+    switch (QPr / 4) {
+#define CASE(kk) case kk: k = kuu_grad_kernel<4 * kk>; break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    if (!k) return -4;
+    const size_t lds = sizeof(float) * ((size_t)M * QPr + 3 * 64 * (QPr + 1) + QPr);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DPGP_ERR_LAUNCH;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(k, dim3(nblk, D), dim3(256), lds, st, D, M, Mp, Q, consts, gamma, WK, dz_part, dg_part);
+    DPGP_LAUNCH_CHECK();
+    const size_t mq = (size_t)M * Q, dq = (size_t)D * Q;
+    int rc = launch_reduce_rows<double>(mq, mq, D, dz_part, dz, 0, stage, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(dq, dq, nblk, dg_part, dgamma, 0, stage, st);
+    return rc;
 }
 
 // workspace (doubles) of launch_psi1_grad: d/dmu, d/dS partials [DC][N][Q] float; d/dgamma [NB][D][Q]; d/dz [DC ns][M][Q]
@@ -706,7 +790,6 @@ int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const
                      const double *s, const double *gamma, const double *alpha, const double *Gv, double *ws, double *stage,
                      double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16);
-    if (Mp > 128) return -30;
     int dpw, DC, NB, ns, nper;
     psi1_grad_shape(D, N, &dpw, &DC, &NB, &ns, &nper);
     const size_t slab = (size_t)DC * N * Q;
@@ -724,10 +807,13 @@ int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const
     }
     if (!kn) return -4;
     const size_t lds_n = sizeof(float) * ((size_t)M * QPr + Mp + 4 * QPr), lds_z = sizeof(float) * ((size_t)64 * (2 * QPr + 4) + 192 * QPr);
+    if (lds_n > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n) != hipSuccess)
+        return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(kn, dim3(NB, DC), dim3(256), lds_n, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, Mp, dpw,
                        dmu_part, ds_part, dg_part);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kz, dim3(ns, DC), dim3(256), lds_z, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, Mp, dpw,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kz, dim3(ns, DC, Mp <= 64 ? 1 : dpgp_ceil_div(M, 128)), dim3(256), lds_z, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, Mp, dpw,
                        nper, dz_part);
     DPGP_LAUNCH_CHECK();
     const size_t nq = (size_t)N * Q, mq = (size_t)M * Q, dq = (size_t)D * Q;

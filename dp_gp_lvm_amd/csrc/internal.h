@@ -85,6 +85,9 @@ size_t psi1_grad_ws_elems(int D, int N, int M, int Q);
 int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const unsigned char *consts, const double *mu,
                      const double *s, const double *gamma, const double *alpha, const double *Gv, double *ws, double *stage,
                      double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st);
+// grad.hip: the K_uu term for any M (mixed precision): dz, dgamma overwritten.  ws: D M Q + ceil(M / 64) D Q doubles
+int launch_kuu_grad(int D, int M, int Q, const unsigned char *consts, const double *gamma, const double *WK, double *ws,
+                    double *stage, double *dz, double *dgamma, hipStream_t st);
 size_t reduce_rows_stage_elems(size_t n);
 template <typename TP>
 int launch_reduce_rows(size_t n, size_t pitch, int nk, const TP *part, double *out, int accumulate, double *stage, hipStream_t st);

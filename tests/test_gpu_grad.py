@@ -244,3 +244,30 @@ def test_matrix_pipe_stage_b_against_fp64(dev, shape):
         out[prec] = [a.cpu().numpy() for a in ops.elbo_grad_psi(args[0], args[1], args[2], args[3], args[4], args[5], gp, wk, gv, prec=prec)]
     for name, want, got in zip(('d mu', 'd S', 'd z', 'd gamma'), out['f64'], out['mixed']):
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-4 * np.abs(want).max(), err_msg=name)
+
+
+@pytest.mark.parametrize('shape', [(150, 4, 130, 5), (260, 3, 200, 7), (300, 2, 257, 14)])
+def test_stage_b_beyond_128_inducing_points(dev, shape):
+    """Stage B alone for M > 128 (K_uu term by kuu_grad_kernel, Psi1 kernels over row blocks, psi2_grad_kernel over an
+    nps x nps patch grid), fed with the stage-A adjoints of the oracle; against autograd of the oracle."""
+    n, d, m, q = shape
+    rng = np.random.default_rng(m)
+    y = rng.standard_normal((n, d))
+    z = rng.standard_normal((m, q)) * 2.0
+    mu = rng.standard_normal((n, q)) * 1.5
+    s = np.exp(0.3 * rng.standard_normal((n, q)))
+    gamma = np.exp(0.3 * rng.standard_normal((d, q))) * 1.5
+    alpha = np.exp(0.2 * rng.standard_normal(d))
+    beta = np.exp(0.2 * rng.standard_normal(d)) * 2.0
+    ref = ot.fhat_input_gradients(y, z, mu, s, gamma, alpha, beta)
+    adj = ot.chain_adjoints(y, z, mu, s, gamma, alpha, beta)
+    mp = 16 * ((m + 15) // 16)
+    pad = lambda a: np.pad(a, ((0, 0), (0, mp - m), (0, mp - m)))
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    gp, wk = t(pad(adj['g_psi2'])), t(pad(adj['g_kuu'] * (adj['k_uu'] - 1e-8 * np.eye(m))))
+    gv = t(np.pad(adj['g_v'], ((0, 0), (0, mp - m))))
+    dmu, ds, dz, dg = ops.elbo_grad_psi(t(y), t(z), t(mu), t(s), t(gamma), t(alpha), gp, wk, gv, prec='mixed')
+    for name, got, want in (('d mu', dmu, ref['d_mu']), ('d S', ds, ref['d_s']), ('d z', dz, ref['d_z']), ('d gamma', dg, ref['d_gamma'])):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=3e-4 * np.abs(want).max(), err_msg=name)
+    with pytest.raises(ValueError):
+        ops.elbo_grad_psi(t(y), t(z), t(mu), t(s), t(gamma), t(alpha), gp, wk, gv, prec='f64')
