@@ -26,6 +26,7 @@ SIGNATURES = {
     'dpgp_potrf_workspace_bytes': (_sz, [_i, _i, _i]),
     'dpgp_trsm_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'dpgp_elbo_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'dpgp_elbo_workspace_layout': (_i, [_i, _i, _i, _i, _i, _vp]),
     'dpgp_elbo_fhat': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp, _sz,
                             _vp]),
     'dpgp_elbo_fhat_ex': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp, _sz,

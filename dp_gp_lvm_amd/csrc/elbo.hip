@@ -38,6 +38,19 @@ extern "C" size_t dpgp_elbo_workspace_bytes(int D, int N, int M, int Q, int prec
     return elbo_layout(D, N, M, Q, prec).total;
 }
 
+// Where a finished dpgp_elbo_fhat call left its streaming results inside `ws` (for stage A of the backward pass composed on
+// the host side when M > 128): out[8] = { byte offset of the Psi2 partial slabs [ns2][D][Mp][Mp] (lower patches), ns2, their
+// element size (4 or 8), Mp, byte offset of the Psi1^T y partial slabs [ns1][D][M] (fp64), ns1, byte offset of the y^T y
+// partial slabs [nyy][D] (fp64), nyy }
+extern "C" int dpgp_elbo_workspace_layout(int D, int N, int M, int Q, int prec, size_t *out) {
+    if (D <= 0 || N <= 0 || M <= 0 || Q <= 0 || prec < 0 || prec > 2) return -1;
+    if (!out) return -6;
+    const ElboLayout L = elbo_layout(D, N, M, Q, prec);
+    out[0] = L.off_p2; out[1] = (size_t)L.ns2; out[2] = (prec == DPGP_PREC_F64) ? 8 : 4; out[3] = (size_t)L.Mp;
+    out[4] = L.off_v;  out[5] = (size_t)L.ns1; out[6] = L.off_yy; out[7] = DPGP_YY_NCH;
+    return DPGP_OK;
+}
+
 template <typename TP, typename TL>
 static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                     const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,

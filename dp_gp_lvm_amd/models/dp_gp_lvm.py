@@ -163,7 +163,8 @@ def dp_gp_lvm(y_train,
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
         evaluate()
         r = dp_model.raw
-        gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER)
+        gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER, z=x_u,
+                                                 gamma=buf['gamma'])
         dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
                                             prec=precision)
         rows = r['logits'].shape[0]

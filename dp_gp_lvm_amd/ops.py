@@ -236,9 +236,11 @@ def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='
     return w.terms, w.sums, w.info
 
 
-def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8):
+def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None):
     """Backward pass, stage A: adjoints of the per-output dense algebra from the workspace of a finished ``elbo_fhat`` call
-    (dp_gp_lvm.py:108-145 differentiated; first version, M <= 128, prec mixed / f64).
+    (dp_gp_lvm.py:108-145 differentiated; prec mixed / f64).  M <= 128: one HIP kernel per output dim with B in LDS
+    (dpgp_elbo_grad_chain).  M > 128 (needs z and gamma, mixed only downstream): composed here from the library's batched
+    Cholesky / triangular solves and plain fp64 GEMMs (``_elbo_grad_chain_large``).
     Returns (g_psi2 [D,Mp,Mp], w_kuu [D,Mp,Mp], g_v [D,Mp], d_alpha_beta [D,2], info [D]); see include/dpgp.h."""
     f64 = torch.float64
     d, n, m, q = workspace.shape
@@ -246,6 +248,8 @@ def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8):
     beta = _prep(beta, f64, 'beta').reshape(-1)
     assert alpha.numel() == d and beta.numel() == d
     mp = 16 * ((m + 15) // 16)
+    if mp > 128 and z is not None and gamma is not None:
+        return _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma)
     dev = workspace.ws.device
     gp = torch.empty((d, mp, mp), dtype=f64, device=dev)
     wk = torch.empty((d, mp, mp), dtype=f64, device=dev)
@@ -257,6 +261,55 @@ def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8):
                                                gp.data_ptr(), wk.data_ptr(), gv.data_ptr(), dab.data_ptr(), info.data_ptr(),
                                                _stream()), 'dpgp_elbo_grad_chain')
     return gp, wk, gv, dab, info
+
+
+def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma):
+    """Stage A for M > 128 (first version): the same adjoints as chain_grad_kernel (grad.hip), with B^-1 and K^-1 formed
+    explicitly from the library's Cholesky factors — L^-1 by dpgp_trsm_batched on the identity, the M x M products as plain
+    fp64 GEMMs (rocBLAS through torch.matmul), element-wise work in torch.  Reads Psi2, Psi1^T y and y^T y from the
+    workspace of the forward evaluation (dpgp_elbo_workspace_layout); K_uu is rebuilt (one gram launch).
+        G_B = -1/2 B^-1 - 1/2 beta^2 w w^T,  w = B^-1 v;   G_K = 1/2 K^-1 - 1/2 beta K^-1 P K^-1 + G_B;
+        G_P = 1/2 beta K^-1 + beta G_B;   G_v = beta^2 w;   d/dalpha, d/dbeta complete (see chain_grad_kernel)."""
+    import ctypes
+    f64 = torch.float64
+    d, n, m, q = workspace.shape
+    dev = workspace.ws.device
+    lay = (ctypes.c_size_t * 8)()
+    _lib.check(_lib.lib().dpgp_elbo_workspace_layout(d, n, m, q, _lib.PREC[workspace.prec], ctypes.cast(lay, ctypes.c_void_p)),
+               'dpgp_elbo_workspace_layout')
+    off_p2, ns2, esz, mp, off_v, ns1, off_yy, nyy = (int(v) for v in lay)
+    raw = workspace.ws
+    pdt = torch.float32 if esz == 4 else f64
+    p2 = raw[off_p2:off_p2 + esz * ns2 * d * mp * mp].view(pdt).view(ns2, d, mp, mp).sum(dim=0, dtype=f64)[:, :m, :m]
+    p2 = torch.tril(p2) + torch.tril(p2, -1).transpose(1, 2)                    # (lower patches are what the kernel writes)
+    v = raw[off_v:off_v + 8 * ns1 * d * m].view(f64).view(ns1, d, m).sum(dim=0)
+    yy = raw[off_yy:off_yy + 8 * nyy * d].view(f64).view(nyy, d).sum(dim=0)
+    k_uu = ard_rbf_gram(_prep(z, f64, 'z'), None, gamma, alpha, beta, include_noise=False, include_jitter=True, jitter=jitter)
+    eye = torch.eye(m, dtype=f64, device=dev).expand(d, m, m).contiguous()
+    l_k, info_k = potrf_batched(k_uu)
+    l_b, info_b = potrf_batched(k_uu + beta[:, None, None] * p2)
+    li = trsm_batched(l_k, eye)
+    k_inv = torch.matmul(li.transpose(1, 2), li)
+    li = trsm_batched(l_b, eye)
+    b_inv = torch.matmul(li.transpose(1, 2), li)
+    del li
+    w = torch.matmul(b_inv, v[:, :, None])[:, :, 0]
+    vw = torch.sum(v * w, dim=1)
+    x = torch.matmul(torch.matmul(k_inv, p2), k_inv)
+    be = beta[:, None, None]
+    gb = -0.5 * b_inv - 0.5 * be * be * w[:, :, None] * w[:, None, :]
+    gk = 0.5 * k_inv - 0.5 * be * x + gb
+    gp_ = 0.5 * be * k_inv + be * gb
+    wk_ = gk * (k_uu - float(jitter) * torch.eye(m, dtype=f64, device=dev))
+    s_k, s_p = wk_.sum(dim=(1, 2)), (gp_ * p2).sum(dim=(1, 2))
+    s_gbp, tr = (gb * p2).sum(dim=(1, 2)), (k_inv * p2).sum(dim=(1, 2))
+    dab = torch.stack([-0.5 * beta * n + (s_k + 2.0 * s_p + beta * beta * vw) / alpha,
+                       0.5 * n / beta + 0.5 * (tr - alpha * n) - 0.5 * yy + beta * vw + s_gbp], dim=1).contiguous()
+    pad = (0, mp - m, 0, mp - m)
+    gp = torch.nn.functional.pad(gp_, pad).contiguous()
+    wk = torch.nn.functional.pad(wk_, pad).contiguous()
+    gv = torch.nn.functional.pad(beta[:, None] ** 2 * w, (0, mp - m)).contiguous()
+    return gp, wk, gv, dab, torch.maximum(info_k, info_b)
 
 
 def elbo_grad_psi(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, prec='mixed'):

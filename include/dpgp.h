@@ -117,6 +117,11 @@ int dpgp_kl_qx_f64(int N, int Q, const double *mu, const double *s, double *out,
  *                   info[D]    (see top of file)
  *   ws: dpgp_elbo_workspace_bytes(D,N,M,Q,prec).  algo: DPGP_ALGO_*.                                               */
 size_t dpgp_elbo_workspace_bytes(int D, int N, int M, int Q, int prec);
+/* where a finished dpgp_elbo_fhat call left its streaming results inside ws: out[8] = { byte offset of the Psi2 partial slabs
+ * [ns2][D][Mp][Mp] (lower 64x64 patches; their sum over the slabs is Psi2), ns2, element size of the slabs (4 or 8), Mp,
+ * byte offset of the Psi1^T y partial slabs [ns1][D][M] (fp64), ns1, byte offset of the y^T y partial slabs [nyy][D] (fp64), nyy }.
+ * Used by the host-side composition of the backward pass's stage A for M > 128 (ops.elbo_grad_chain). */
+int dpgp_elbo_workspace_layout(int D, int N, int M, int Q, int prec, size_t *out);
 int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                    const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                    int prec, int algo, double *terms, double *sums, int *info, void *ws, size_t ws_bytes,

@@ -178,13 +178,16 @@ def test_sharding_arithmetic_on_one_gpu(dev, world):
         np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(ref).max()), err_msg=k)
 
 
-@pytest.mark.parametrize('shape', [(33, 5, 17, 5, 1, 1), (70, 9, 33, 9, 3, 3), (80, 8, 64, 6, 4, 2), (45, 14, 20, 13, 3, 1)])
+@pytest.mark.parametrize('shape', [(33, 5, 17, 5, 1, 1), (70, 9, 33, 9, 3, 3), (80, 8, 64, 6, 4, 2), (45, 14, 20, 13, 3, 1),
+                                   (160, 6, 140, 5, 3, 1), (300, 9, 200, 8, 2, 3)])
 @pytest.mark.parametrize('prec', ['f64', 'mixed'])
 def test_model_gradients_odd_shapes(dev, shape, prec):
     """Shapes off the tile sizes (M not a multiple of 16, Q not a multiple of 4, T = 1, mask_size > 1) against the pinned
     autograd oracle at random raw variables."""
     from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
     n, d, m, q, t, mask = shape
+    if m > 128 and prec == 'f64':
+        pytest.skip('backward pass for M > 128 exists in mixed precision only')
     rng = np.random.default_rng(n + d)
     y = rng.standard_normal((n, d))
     y = (y - y.mean(0)) / y.std(0)
