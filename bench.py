@@ -231,7 +231,7 @@ def main():
         }
         if world == 1 and not a.no_secondary:
             res['secondary'] = secondary(dev, shape, p)
-        if world == 1 and not a.no_grad and a.prec != 'f32' and m <= 128:
+        if world == 1 and not a.no_grad and (a.prec == 'mixed' or (a.prec == 'f64' and m <= 128)):
             # side measurements, not the headline metric: (1) one objective evaluation + the gradients of all raw variables
             # (backward pass; what one Adam iteration of the reference needs); (2) one objective evaluation
             # of the over-T formulation dp_gp_lvm_t on the same data (8f row 3: T Psi2's instead of D)

@@ -220,9 +220,10 @@ def test_model_gradients_odd_shapes(dev, shape, prec):
 @pytest.mark.parametrize('shape', [(300, 16, 100, 10), (500, 8, 128, 12), (200, 6, 70, 4), (150, 5, 130, 7), (200, 6, 64, 20),
                                    (120, 5, 40, 30), (150, 4, 96, 17), (90, 3, 33, 29), (130, 7, 128, 13)])
 def test_matrix_pipe_stage_b_against_fp64(dev, shape):
-    """Mixed precision: the Psi2 term of stage B runs on the matrix pipe (psi2_grad_kernel), Psi1 in the reduction-free kernels.  Against the fp64 kernel
-    (itself at 1e-8 of the oracle's autograd, tests above) on the same stage-A adjoints; M = 130: the backward pass has no M > 128
-    version yet (stage A keeps B in LDS): the call must say so instead of computing something else."""
+    """Mixed precision: the Psi2 term of stage B runs on the matrix pipe (psi2_grad_kernel), Psi1 in the reduction-free
+    kernels.  Against the fp64 kernel (itself at 1e-8 of the oracle's autograd, tests above) on the same stage-A adjoints;
+    M = 130: the HIP stage A keeps B in LDS (M <= 128) — without z and gamma for the host-side composition the call must
+    say so instead of computing something else."""
     n, d, m, q = shape
     rng = np.random.default_rng(n + m)
     y = rng.standard_normal((n, d))
