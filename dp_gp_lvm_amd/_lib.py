@@ -35,6 +35,8 @@ SIGNATURES = {
     'dpgp_elbo_grad_psi_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'dpgp_elbo_grad_psi': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp,
                                 _vp, _vp]),
+    'dpgp_elbo_grad_psi_ex': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp,
+                                   _vp, _vp, _vp]),
     'dpgp_event_create': (_vp, []),
     'dpgp_event_destroy': (None, [_vp]),
     'dpgp_event_elapsed_ms': (ctypes.c_float, [_vp, _vp]),

@@ -137,16 +137,29 @@ extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q)
     }
     return b;
 }
+extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                                     const double *s, const double *gamma, const double *alpha, const double *g_psi2,
+                                     const double *w_kuu, const double *g_v, const double *g_psi1, int prec, void *ws,
+                                     size_t ws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream);
 extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                                   const double *s, const double *gamma, const double *alpha, const double *g_psi2,
                                   const double *w_kuu, const double *g_v, int prec, void *ws, size_t ws_bytes,
                                   double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream) {
+    return dpgp_elbo_grad_psi_ex(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, nullptr, prec, ws, ws_bytes,
+                                 d_mu, d_s, d_z, d_gamma, stream);
+}
+// g_psi1 != NULL: a full adjoint [D][N][Mp] of Psi1 replaces the rank-1 form g_v[d][a] y[n][d] (then y may be NULL and g_v is
+// not read): the over-T model's data-fit term couples every atom with all columns of y.  Mixed precision only.
+extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                                     const double *s, const double *gamma, const double *alpha, const double *g_psi2,
+                                     const double *w_kuu, const double *g_v, const double *g_psi1, int prec, void *ws,
+                                     size_t ws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream) {
     if (D <= 0) return -1;
     if (N <= 0) return -2;
     if (M <= 0 || M > N) return -3;
     if (Q <= 0 || Q > DPGP_MAX_Q) return -4;
-    if (!y) return -5;
-    if (ldy < D) return -6;
+    if (!y && !g_psi1) return -5;
+    if (y && ldy < D) return -6;
     if (!z) return -7;
     if (!mu) return -8;
     if (!s) return -9;
@@ -154,8 +167,9 @@ extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, i
     if (!alpha) return -11;
     if (!g_psi2) return -12;
     if (!w_kuu) return -13;
-    if (!g_v) return -14;
+    if (!g_v && !g_psi1) return -14;
     if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_F64) return -15;
+    if (g_psi1 && (prec != DPGP_PREC_MIXED || !psi2_grad_supported(M, Q))) return -15;
     if (!ws) return -16;
     if (ws_bytes < dpgp_elbo_grad_psi_workspace_bytes(D, N, M, Q)) return -17;
     if (!d_mu) return -18;
@@ -171,8 +185,9 @@ extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, i
         if (big && !fast) return -30;
         int rc = DPGP_OK;
         if (!big) {
-            rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
-                                        d_z, d_gamma, fast ? 0 : 1, st);
+            if (g_psi1 && !fast) return -15;
+            rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v ? g_v : w_kuu, (double *)ws,
+                                        d_mu, d_s, d_z, d_gamma, fast ? 0 : 1, st);
             if (rc != DPGP_OK || !fast) return rc;
         }
         const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
@@ -187,7 +202,7 @@ extern "C" int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, i
             rc = launch_kuu_grad(D, M, Q, consts, gamma, w_kuu, (double *)ws, stage, d_z, d_gamma, st);
             if (rc != DPGP_OK) return rc;
         }
-        rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, ws1, stage, d_mu, d_s, d_z, d_gamma, st);
+        rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, g_psi1, ws1, stage, d_mu, d_s, d_z, d_gamma, st);
         if (rc != DPGP_OK) return rc;
         return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, part, stage, d_mu, d_s, d_z, d_gamma, st);
     }

@@ -517,9 +517,11 @@ template <int QP>
 __global__ __launch_bounds__(256) void psi1_grad_n_kernel(int D, int N, int M, int Q, const double *__restrict__ y, int ldy,
                                                           const unsigned char *__restrict__ consts, const double *__restrict__ mu,
                                                           const double *__restrict__ s, const double *__restrict__ gamma,
-                                                          const double *__restrict__ alpha, const double *__restrict__ Gv, int Mp,
+                                                          const double *__restrict__ alpha, const double *__restrict__ Gv,
+                                                          const double *__restrict__ G1, int Mp,
                                                           int d_per_wg, float *__restrict__ dmu_part, float *__restrict__ ds_part,
                                                           double *__restrict__ dg_part) {
+    // G1 != nullptr: a full adjoint G1[d][n][Mp] of Psi1_d takes the place of the rank-1 form g_d[a] y_nd (over-T model)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *zs = reinterpret_cast<float *>(smem_raw);            // [M][QP] centred
     float *gv = zs + (size_t)M * QP;                            // [M] g_d
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256) void psi1_grad_n_kernel(int D, int N, int M, i
     const int d0 = blockIdx.y * d_per_wg, d1 = min(D, d0 + d_per_wg);
     for (int d = d0; d < d1; ++d) {
         __syncthreads();
-        for (int a = t; a < M; a += 256) gv[a] = (float)Gv[(size_t)d * Mp + a];
+        for (int a = t; a < M; a += 256) gv[a] = G1 ? 1.0f : (float)Gv[(size_t)d * Mp + a];
         __syncthreads();
         float a1[QP], l1 = 0.0f;
 #pragma unroll
@@ -570,12 +572,12 @@ __global__ __launch_bounds__(256) void psi1_grad_n_kernel(int D, int N, int M, i
                     e += h[q] * cc[q];
                 }
             }
-            const float w = gv[a] * dpgp_exp2(e);
+            const float w = (G1 ? (live ? (float)G1[((size_t)d * N + n) * Mp + a] : 0.0f) : gv[a]) * dpgp_exp2(e);
             V0 += w;
 #pragma unroll
             for (int q = 0; q < QP; ++q) { U1[q] += w * c[q]; U2[q] += w * cc[q]; }
         }
-        const float yv = live ? (float)y[(size_t)n * ldy + d] : 0.0f;
+        const float yv = G1 ? 1.0f : (live ? (float)y[(size_t)n * ldy + d] : 0.0f);
         V0 *= yv;
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
@@ -604,7 +606,8 @@ template <int QP, int AL>
 __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, int Q, const double *__restrict__ y, int ldy,
                                                           const unsigned char *__restrict__ consts, const double *__restrict__ mu,
                                                           const double *__restrict__ s, const double *__restrict__ gamma,
-                                                          const double *__restrict__ alpha, const double *__restrict__ Gv, int Mp,
+                                                          const double *__restrict__ alpha, const double *__restrict__ Gv,
+                                                          const double *__restrict__ G1, int Mp,
                                                           int d_per_wg, int n_per_split, double *__restrict__ dz_part) {
     constexpr int FS = 2 * QP + 4;                              // per observation: a1[QP], mu'[QP], e0, y, pad
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, i
     const int nbeg = blockIdx.x * n_per_split, nend = min(N, nbeg + n_per_split);
     const int fn = t >> 2, fp = t & 3;                          // factor computation: observation fn of the chunk, q = fp, fp + 4, ...
     for (int d = d0; d < d1; ++d) {
-        const float gva = (a < M) ? (float)Gv[(size_t)d * Mp + a] : 0.0f;
+        const float gva = (a < M) ? (G1 ? 1.0f : (float)Gv[(size_t)d * Mp + a]) : 0.0f;
         const float l2al = __builtin_amdgcn_logf((float)alpha[d]);
         for (int nc = nbeg; nc < nend; nc += 64) {
             __syncthreads();
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, i
                 l1 += __shfl_xor(l1, 2, 64);
                 if (fp == 0) {
                     fac[fn * FS + 2 * QP] = l2al - 0.5f * l1;
-                    fac[fn * FS + 2 * QP + 1] = (n < nend) ? (float)y[(size_t)n * ldy + d] : 0.0f;
+                    fac[fn * FS + 2 * QP + 1] = (n < nend) ? (G1 ? 1.0f : (float)y[(size_t)n * ldy + d]) : 0.0f;
                 }
             }
             __syncthreads();
@@ -664,7 +667,8 @@ __global__ __launch_bounds__(256) void psi1_grad_z_kernel(int D, int N, int M, i
                         e += (float)(-0.5 * DPGP_LOG2E) * a1[q] * c[q] * c[q];
                     }
                 }
-                const float w = gva * f[2 * QP + 1] * dpgp_exp2(e);
+                float w = gva * f[2 * QP + 1] * dpgp_exp2(e);
+                if (G1) w *= (nc + i < nend && a < M) ? (float)G1[((size_t)d * N + nc + i) * Mp + a] : 0.0f;
 #pragma unroll
                 for (int q = 0; q < QP; ++q) dza[q] += w * a1[q] * c[q];
             }
@@ -787,8 +791,8 @@ size_t psi1_grad_ws_elems(int D, int N, int M, int Q) {
 }
 // dmu, ds: overwritten; dz, dgamma: added to
 int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const unsigned char *consts, const double *mu,
-                     const double *s, const double *gamma, const double *alpha, const double *Gv, double *ws, double *stage,
-                     double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+                     const double *s, const double *gamma, const double *alpha, const double *Gv, const double *G1,
+                     double *ws, double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16);
     int dpw, DC, NB, ns, nper;
     psi1_grad_shape(D, N, &dpw, &DC, &NB, &ns, &nper);
@@ -797,9 +801,9 @@ int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const
     double *dg_part = ws + slab + 2, *dz_part = dg_part + (size_t)NB * D * Q;
     const int QPr = 4 * dpgp_ceil_div(Q, 4);
     void (*kn)(int, int, int, int, const double *, int, const unsigned char *, const double *, const double *, const double *,
-               const double *, const double *, int, int, float *, float *, double *) = nullptr;
+               const double *, const double *, const double *, int, int, float *, float *, double *) = nullptr;
     void (*kz)(int, int, int, int, const double *, int, const unsigned char *, const double *, const double *, const double *,
-               const double *, const double *, int, int, int, double *) = nullptr;
+               const double *, const double *, const double *, int, int, int, double *) = nullptr;
     switch (QPr / 4) {
 #define CASE(k) case k: kn = psi1_grad_n_kernel<4 * k>; kz = Mp <= 64 ? psi1_grad_z_kernel<4 * k, 64> : psi1_grad_z_kernel<4 * k, 128>; break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -810,10 +814,10 @@ int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const
     if (lds_n > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n) != hipSuccess)
         return DPGP_ERR_LAUNCH;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kn, dim3(NB, DC), dim3(256), lds_n, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, Mp, dpw,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kn, dim3(NB, DC), dim3(256), lds_n, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, G1, Mp, dpw,
                        dmu_part, ds_part, dg_part);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kz, dim3(ns, DC, Mp <= 64 ? 1 : dpgp_ceil_div(M, 128)), dim3(256), lds_z, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, Mp, dpw,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kz, dim3(ns, DC, Mp <= 64 ? 1 : dpgp_ceil_div(M, 128)), dim3(256), lds_z, st, D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, Gv, G1, Mp, dpw,
                        nper, dz_part);
     DPGP_LAUNCH_CHECK();
     const size_t nq = (size_t)N * Q, mq = (size_t)M * Q, dq = (size_t)D * Q;

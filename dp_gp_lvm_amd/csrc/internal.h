@@ -83,8 +83,9 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
 // stage: reduce_rows_stage_elems(max(N Q, M Q, D Q)) doubles, consts as below
 size_t psi1_grad_ws_elems(int D, int N, int M, int Q);
 int launch_psi1_grad(int D, int N, int M, int Q, const double *y, int ldy, const unsigned char *consts, const double *mu,
-                     const double *s, const double *gamma, const double *alpha, const double *Gv, double *ws, double *stage,
-                     double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st);
+                     const double *s, const double *gamma, const double *alpha, const double *Gv, const double *G1,
+                     double *ws, double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st);
+// (G1 != nullptr: full adjoint [D][N][Mp] of Psi1 instead of the rank-1 form Gv[d][a] y[n][d])
 // grad.hip: the K_uu term for any M (mixed precision): dz, dgamma overwritten.  ws: D M Q + ceil(M / 64) D Q doubles
 int launch_kuu_grad(int D, int M, int Q, const unsigned char *consts, const double *gamma, const double *WK, double *ws,
                     double *stage, double *dz, double *dgamma, hipStream_t st);

@@ -298,7 +298,7 @@ def dp_gp_lvm_t(y_train,
     Over-T formulation — mirror of the reference's ``dp_gp_lvm_t`` factory (src/models/dp_gp_lvm.py:513-676), SURVEY.md
     §8(f) row 3: the kernel batch is the T atoms, the mixture weights phi [T x D] enter outside the kernel, so an evaluation
     needs T Psi2's instead of D.  A different objective from ``dp_gp_lvm`` away from equal atoms (equal at the reference's
-    initialisation, test/unittests/dpgplvm_unitttests.py:544-548).  Objective only (forward); composed of the library's
+    initialisation, test/unittests/dpgplvm_unitttests.py:544-548).  Objective and gradients, composed of the library's
     operators in the B_t = K_t + beta_t Psi2_t algebra of DESIGN.md §2:
 
         Psi1 [T,N,M], Psi2 [T,M,M], K_uu [T,M,M]       dpgp_psi1 / dpgp_psi2 / dpgp_ard_rbf_gram      (:611-620)
@@ -354,33 +354,135 @@ def dp_gp_lvm_t(y_train,
     y_dev = _t(np.asarray(y_train))
     yy = torch.sum(y_dev * y_dev, dim=0)                                       # [D]
     from ..distributions.log_normal import log_pdf as log_normal_log_pdf
+    from ..distributions.beta import entropy as beta_dist_entropy
+    from ..distributions.gamma import entropy as gamma_dist_entropy
+    from ..distributions.multinomial import entropy as multinomial_dist_entropy
+    s_1, s_2 = dp_model.prior
+    n_, d_, m_ = num_samples, num_dimensions, num_inducing_points
+    mp_ = 16 * ((m_ + 15) // 16)
+    last_info = [torch.zeros((), dtype=torch.int32, device=device)]
 
-    def evaluate():
-        """(objective, f_hat, KL, DP objective, hyper-prior log-likelihood) as a device tensor."""
-        gat, aat, bat = F.softplus(gamma_atoms_raw), F.softplus(sig_var_atoms_raw)[:, 0], F.softplus(beta_atoms_raw)[:, 0]
-        s = F.softplus(x_var_raw)
-        phit = dp_model.assignments.transpose(0, 1)                              # [T x D]
+    def _chain(x_u_, x_mean_, s_, gat, aat, bat):
+        """Psi statistics and the Cholesky factors of the T atoms (library operators)."""
         pt = torch.float32 if precision == 'mixed' else TORCH_DTYPE
         cast = lambda a: a.to(pt).contiguous()
-        psi_1 = ops.psi1(cast(x_u), cast(x_mean), cast(s), cast(gat), cast(aat)).to(TORCH_DTYPE)     # [T x N x M]
-        psi_2 = ops.psi2(cast(x_u), cast(x_mean), cast(s), cast(gat), cast(aat)).to(TORCH_DTYPE)     # [T x M x M]
-        k_uu = ops.ard_rbf_gram(x_u, None, gat, aat, bat, include_noise=False, include_jitter=True,
-                                jitter=GP_DEFAULT_JITTER)                                             # [T x M x M]
+        psi_1 = ops.psi1(cast(x_u_), cast(x_mean_), cast(s_), cast(gat), cast(aat)).to(TORCH_DTYPE)   # [T x N x M]
+        psi_2 = ops.psi2(cast(x_u_), cast(x_mean_), cast(s_), cast(gat), cast(aat)).to(TORCH_DTYPE)   # [T x M x M]
+        k_uu = ops.ard_rbf_gram(x_u_, None, gat, aat, bat, include_noise=False, include_jitter=True,
+                                jitter=GP_DEFAULT_JITTER)                                              # [T x M x M]
         l_k, info_k = ops.potrf_batched(k_uu)
         l_b, info_b = ops.potrf_batched(k_uu + bat[:, None, None] * psi_2)
-        h = ops.trsm_batched(l_k, psi_2)                                         # L^-1 Psi2
-        tr = torch.diagonal(ops.trsm_batched(l_k, h.transpose(1, 2).contiguous()), dim1=-2, dim2=-1).sum(-1)
-        logdet = torch.log(torch.diagonal(l_b, dim1=-2, dim2=-1)).sum(-1) - torch.log(torch.diagonal(l_k, dim1=-2, dim2=-1)).sum(-1)
-        c = ops.trsm_batched(l_b, torch.matmul(psi_1.transpose(1, 2), y_dev))    # [T x M x D]
-        quad = bat[:, None] ** 2 * torch.sum(c * c, dim=1)                       # [T x D]
-        per_t = 0.5 * (num_samples * torch.log(bat) + bat * (tr - num_samples * aat)) - logdet
-        f_hat = -0.5 * num_samples * num_dimensions * np.log(2.0 * np.pi) + torch.sum(phit * per_t[:, None]) \
-            - 0.5 * torch.sum(phit * bat[:, None] * yy[None, :]) + 0.5 * torch.sum(phit * quad)
-        kl = ops.kl_qx(x_mean, s)
+        last_info[0] = torch.maximum(info_k.abs().max(), info_b.abs().max())
+        return psi_1, psi_2, k_uu, l_k, l_b
+
+    class _FHatT(torch.autograd.Function):
+        """f_hat of dp_gp_lvm.py:617-667 as a differentiable function of (x_mean, S, x_u, gamma/alpha/beta atoms, phi^T):
+        forward = the library's operators; backward = the adjoints of the per-atom dense algebra (torch, T small) and the
+        library's streaming stage B (dpgp_elbo_grad_psi_ex: Psi2 term on the matrix pipe, Psi1 term with the full adjoint
+        beta^2 Y diag(phi_t) W_t^T, K_uu term)."""
+
+        @staticmethod
+        def forward(ctx, x_mean_, s_, x_u_, gat, aat, bat, phit):
+            psi_1, psi_2, k_uu, l_k, l_b = _chain(x_u_, x_mean_, s_, gat, aat, bat)
+            h = ops.trsm_batched(l_k, psi_2)
+            tr = torch.diagonal(ops.trsm_batched(l_k, h.transpose(1, 2).contiguous()), dim1=-2, dim2=-1).sum(-1)
+            logdet = torch.log(torch.diagonal(l_b, dim1=-2, dim2=-1)).sum(-1) - \
+                torch.log(torch.diagonal(l_k, dim1=-2, dim2=-1)).sum(-1)
+            v = torch.matmul(psi_1.transpose(1, 2), y_dev)                       # [T x M x D]
+            c = ops.trsm_batched(l_b, v)
+            quad = bat[:, None] ** 2 * torch.sum(c * c, dim=1)                   # [T x D]
+            per_t = 0.5 * (n_ * torch.log(bat) + bat * (tr - n_ * aat)) - logdet
+            ctx.save_for_backward(x_mean_, s_, x_u_, gat, aat, bat, phit, psi_2, k_uu, l_k, l_b, v, per_t, quad, tr)
+            return -0.5 * n_ * d_ * np.log(2.0 * np.pi) + torch.sum(phit * per_t[:, None]) \
+                - 0.5 * torch.sum(phit * bat[:, None] * yy[None, :]) + 0.5 * torch.sum(phit * quad)
+
+        @staticmethod
+        def backward(ctx, g_out):
+            x_mean_, s_, x_u_, gat, aat, bat, phit, p2, k_uu, l_k, l_b, v, per_t, quad, tr = ctx.saved_tensors
+            t_ = gat.shape[0]
+            eye = torch.eye(m_, dtype=TORCH_DTYPE, device=device)
+            eyes = eye.expand(t_, m_, m_).contiguous()
+            li = ops.trsm_batched(l_k, eyes)
+            k_inv = torch.matmul(li.transpose(1, 2), li)
+            li = ops.trsm_batched(l_b, eyes)
+            b_inv = torch.matmul(li.transpose(1, 2), li)
+            st = phit.sum(dim=1)[:, None, None]                                  # s_t = sum_d phi_td
+            be = bat[:, None, None]
+            w = torch.matmul(b_inv, v)                                           # [T x M x D]
+            wphi = w * phit[:, None, :]
+            vwphi = torch.sum(v * wphi, dim=(1, 2))                              # sum_d phi_td v_td^T B^-1 v_td
+            gb = -0.5 * st * b_inv - 0.5 * be * be * torch.matmul(wphi, w.transpose(1, 2))
+            x = torch.matmul(torch.matmul(k_inv, p2), k_inv)
+            gk = 0.5 * st * k_inv - 0.5 * st * be * x + gb
+            gp = 0.5 * st * be * k_inv + be * gb
+            wk = gk * (k_uu - GP_DEFAULT_JITTER * eye)
+            g1 = be * be * torch.matmul(y_dev, wphi.transpose(1, 2))             # [T x N x M] adjoint of Psi1
+            pad2 = (0, mp_ - m_, 0, mp_ - m_)
+            dmu, ds, dz, dgam = ops.elbo_grad_psi(None, x_u_, x_mean_, s_, gat, aat,
+                                                  torch.nn.functional.pad(gp, pad2).contiguous(),
+                                                  torch.nn.functional.pad(wk, pad2).contiguous(), None, prec='mixed',
+                                                  g_psi1=torch.nn.functional.pad(g1, (0, mp_ - m_)).contiguous())
+            s_k, s_p = wk.sum(dim=(1, 2)), (gp * p2).sum(dim=(1, 2))
+            s_gbp = (gb * p2).sum(dim=(1, 2))
+            stv = st[:, 0, 0]
+            d_alpha = -0.5 * bat * n_ * stv + (s_k + 2.0 * s_p + bat * bat * vwphi) / aat
+            d_beta = stv * (0.5 * n_ / bat + 0.5 * (tr - aat * n_)) - 0.5 * torch.sum(phit * yy[None, :], dim=1) \
+                + bat * vwphi + s_gbp
+            d_phit = per_t[:, None] - 0.5 * bat[:, None] * yy[None, :] + 0.5 * quad
+            return (g_out * dmu, g_out * ds, g_out * dz, g_out * dgam, g_out * d_alpha, g_out * d_beta, g_out * d_phit)
+
+    def _dp_objective(phi, g1, g2, w1, w2):
+        """-ELBO of the DP (dirichlet_process.py:64-88) as a function of its arguments (for autograd)."""
+        t_ = truncation_level
+        dg12 = torch.digamma(g1 + g2)
+        tail = (torch.flip(torch.cumsum(torch.flip(phi, [-1]), dim=-1), [-1]) - phi)[:, 0:-1]
+        ev_z = torch.sum(phi[:, 0:-1] * (torch.digamma(g1) - dg12) + tail * (torch.digamma(g2) - dg12))
+        ev_v = (t_ - 1.0) * (torch.digamma(w1) - torch.log(w2)) + ((w1 / w2) - 1.0) * torch.sum(torch.digamma(g2) - dg12)
+        ev_a = s_1 * np.log(s_2) - float(torch.lgamma(torch.tensor(s_1, dtype=TORCH_DTYPE))) + \
+            (s_1 - 1.0) * (torch.digamma(w1) - torch.log(w2)) - s_2 * (w1 / w2)
+        return -(ev_z + ev_v + ev_a + torch.sum(multinomial_dist_entropy(phi)) + torch.sum(beta_dist_entropy(g1, g2)) +
+                 gamma_dist_entropy(w1, w2))
+
+    def _objective_of(r):
+        """(objective, f_hat, KL, DP objective, hyper-prior) from a dict of raw variables (torch graph when they require grad)."""
+        gat, aat, bat = F.softplus(r['gamma_atoms']), F.softplus(r['alpha_atoms'])[:, 0], F.softplus(r['beta_atoms'])[:, 0]
+        s = F.softplus(r['x_var'])
+        phi = torch.softmax(r['dp_logits'], dim=-1)
+        if mask_size != 1:
+            phi = torch.repeat_interleave(phi, mask_size, dim=0)
+        f_hat = _FHatT.apply(r['x_mean'], s, r['x_u'], gat, aat, bat, phi.transpose(0, 1).contiguous())
+        mu = r['x_mean']
+        kl = 0.5 * (torch.sum(mu * mu) + torch.sum(s - torch.log(s)) - mu.shape[0] * mu.shape[1])     # gp_expressions.py:10-24
         hyper = torch.sum(log_normal_log_pdf(gat)) + torch.sum(log_normal_log_pdf(aat)) + torch.sum(log_normal_log_pdf(bat))
-        dp_obj = dp_model.objective
-        out = torch.stack([dp_obj - (f_hat - kl) - hyper, f_hat, kl, dp_obj, hyper])
-        return out, torch.maximum(info_k.abs().max(), info_b.abs().max())
+        w = F.softplus(r['dp_w'])
+        dp_obj = _dp_objective(phi, F.softplus(r['dp_gamma_1']), F.softplus(r['dp_gamma_2']), w[0], w[1])
+        return torch.stack([dp_obj - (f_hat - kl) - hyper, f_hat, kl, dp_obj, hyper])
+
+    raw_vars = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw,
+                    beta_atoms=beta_atoms_raw, **{'dp_' + k: v for k, v in dp_model.raw.items()})
+
+    def evaluate():
+        with torch.no_grad():
+            out = _objective_of(raw_vars)
+        return out, last_info[0]
+
+    def _gradients():
+        """d objective / d raw variable for all raw variables: torch autograd around the library-backed f_hat (above)."""
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in raw_vars.items()}
+        obj = _objective_of(leaves)[0]
+        grads = torch.autograd.grad(obj, list(leaves.values()), allow_unused=True)
+        return {k: (torch.zeros_like(v) if g is None else g) for (k, v), g in zip(leaves.items(), grads)}
+
+    def _optimise(num_iterations, learning_rate=0.01, callback=None):
+        """Adam on the raw variables (the reference: tf.train.AdamOptimizer(...).minimize(objective))."""
+        opt = torch.optim.Adam(list(raw_vars.values()), lr=learning_rate)
+        for it in range(num_iterations):
+            g = _gradients()
+            for k, p_ in raw_vars.items():
+                p_.grad = g[k].reshape(p_.shape)
+            opt.step()
+            if callback is not None:
+                callback(it)
 
     class DP_GP_LVM_T(Trainable):
         """Accessors as in the reference (dp_gp_lvm.py:679-740); the kernel has batch size T here."""
@@ -423,5 +525,8 @@ def dp_gp_lvm_t(y_train,
         @property
         def cholesky_info(self):
             return evaluate()[1]
+
+        gradients = staticmethod(_gradients)
+        optimise = staticmethod(_optimise)
 
     return DP_GP_LVM_T()

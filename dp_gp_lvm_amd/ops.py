@@ -312,23 +312,29 @@ def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma):
     return gp, wk, gv, dab, torch.maximum(info_k, info_b)
 
 
-def elbo_grad_psi(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, prec='mixed'):
+def elbo_grad_psi(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, prec='mixed', g_psi1=None):
     """Backward pass, stage B: d f_hat / d (mu [N,Q], s [N,Q], z [M,Q], gamma [D,Q]) from the stage-A adjoints
-    (rbf_kernel.py:58-199 differentiated; first version, M <= 128)."""
+    (rbf_kernel.py:58-199 differentiated).  g_psi1 [D,N,Mp] (mixed precision only): a full adjoint of Psi1 in place of the
+    rank-1 form g_v[d,a] y[n,d] — then y and g_v may be None."""
     f64 = torch.float64
     z, mu, s = _prep(z, f64, 'z'), _prep(mu, f64, 'mu'), _prep(s, f64, 's')
     gamma, alpha, _, d = _hyp(gamma, alpha, None, f64)
-    if y.dtype != f64 or y.stride(1) != 1:
-        y = y.to(f64).contiguous()
     n, m, q = mu.shape[0], z.shape[0], z.shape[1]
+    if y is not None and (y.dtype != f64 or y.stride(1) != 1):
+        y = y.to(f64).contiguous()
+    if g_psi1 is not None:
+        g_psi1 = _prep(g_psi1, f64, 'g_psi1')
+        assert g_psi1.shape == (d, n, g_psi2.shape[1])
     dev = mu.device
     l = _lib.lib()
     wsb = l.dpgp_elbo_grad_psi_workspace_bytes(d, n, m, q)
     ws = _ws(wsb, dev)
     dmu, ds = torch.empty((n, q), dtype=f64, device=dev), torch.empty((n, q), dtype=f64, device=dev)
     dz, dg = torch.empty((m, q), dtype=f64, device=dev), torch.empty((d, q), dtype=f64, device=dev)
-    _lib.check(l.dpgp_elbo_grad_psi(d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(), s.data_ptr(),
-                                    gamma.data_ptr(), alpha.data_ptr(), g_psi2.data_ptr(), w_kuu.data_ptr(), g_v.data_ptr(),
-                                    _lib.PREC[prec], ws.data_ptr(), wsb, dmu.data_ptr(), ds.data_ptr(), dz.data_ptr(),
-                                    dg.data_ptr(), _stream()), 'dpgp_elbo_grad_psi')
+    _lib.check(l.dpgp_elbo_grad_psi_ex(d, n, m, q, y.data_ptr() if y is not None else None, y.stride(0) if y is not None else 0,
+                                       z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(),
+                                       g_psi2.data_ptr(), w_kuu.data_ptr(), g_v.data_ptr() if g_v is not None else None,
+                                       g_psi1.data_ptr() if g_psi1 is not None else None, _lib.PREC[prec], ws.data_ptr(), wsb,
+                                       dmu.data_ptr(), ds.data_ptr(), dz.data_ptr(), dg.data_ptr(), _stream()),
+               'dpgp_elbo_grad_psi_ex')
     return dmu, ds, dz, dg

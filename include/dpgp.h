@@ -166,6 +166,13 @@ int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, con
                        const double *s, const double *gamma, const double *alpha, const double *g_psi2,
                        const double *w_kuu, const double *g_v, int prec, void *ws, size_t ws_bytes, double *d_mu,
                        double *d_s, double *d_z, double *d_gamma, void *stream);
+/* as dpgp_elbo_grad_psi with a full adjoint g_psi1[D][N][Mp] of Psi1 (may be NULL) in place of the rank-1 form
+ * g_v[d][a] y[n][d]: then y and g_v may be NULL.  Mixed precision only.  (The over-T model, reference dp_gp_lvm.py:513-676,
+ * couples every atom with all columns of y.) */
+int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                       const double *s, const double *gamma, const double *alpha, const double *g_psi2,
+                       const double *w_kuu, const double *g_v, const double *g_psi1, int prec, void *ws, size_t ws_bytes, double *d_mu,
+                       double *d_s, double *d_z, double *d_gamma, void *stream);
 
 /* hipEvent helpers for hosts without their own HIP binding */
 void *dpgp_event_create(void);

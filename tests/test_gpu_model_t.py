@@ -64,3 +64,34 @@ def test_accessors_and_shapes(dev):
     assert model.kernel.covariance_matrix(model.inducing_input, None).shape == (4, 10, 10)
     with pytest.raises(AssertionError):
         dp_gp_lvm_t(y, num_latent_dims=9, num_inducing_points=10, truncation_level=4, device=dev)
+
+
+REF2RAW = dict(x_mean='x_mean', x_var_raw='x_var', x_u='x_u', dp_logits='dp_logits', gamma_1_raw='dp_gamma_1',
+               gamma_2_raw='dp_gamma_2', gamma_atoms_raw='gamma_atoms', alpha_atoms_raw='alpha_atoms', beta_atoms_raw='beta_atoms')
+
+
+@pytest.mark.parametrize('fixture', ['model_t_ref_40_6_12_3_T4', 'model_t_ref_60_10_15_4_T5'])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_gradients_match_the_reference(dev, fixture, prec):
+    """model.gradients() against tf.gradients of the reference's own dp_gp_lvm_t objective (the streaming stage of the
+    backward pass runs in mixed precision for either forward precision)."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+    g = golden(fixture)
+    model = build(dp_gp_lvm_t, g, dev, prec)
+    got = model.gradients()
+    tol = 5e-4
+    for ref_name, raw_name in REF2RAW.items():
+        want = g['grad_' + ref_name]
+        have = got[raw_name].cpu().numpy().reshape(want.shape)
+        np.testing.assert_allclose(have, want, rtol=tol, atol=tol * max(1.0, np.abs(want).max()), err_msg=ref_name)
+    np.testing.assert_allclose(got['dp_w'].cpu().numpy(), [float(g['grad_w_1_raw']), float(g['grad_w_2_raw'])], rtol=tol, atol=tol)
+
+
+def test_adam_decreases_the_over_t_objective(dev):
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+    g = golden('model_t_ref_60_10_15_4_T5')
+    model = build(dp_gp_lvm_t, g, dev, 'mixed')
+    before = float(model.objective)
+    model.optimise(30, learning_rate=0.01)
+    after = float(model.objective)
+    assert np.isfinite(after) and after < before - 1.0, (before, after)
