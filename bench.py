@@ -261,6 +261,15 @@ def main():
                 res['objective_over_t'] = {'ms': 1e3 * (time.perf_counter() - t0) / reps, 'reps': reps,
                                            'truncation_level': int(p['phi'].shape[1]),
                                            'note': 'dp_gp_lvm_t objective, composed of the library operators (not fused)'}
+                if a.prec == 'mixed':
+                    for _ in range(2):
+                        model_t.gradients()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        model_t.gradients()
+                    torch.cuda.synchronize()
+                    res['objective_over_t']['with_gradients_ms'] = 1e3 * (time.perf_counter() - t0) / reps
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(a.config, p, shape, a.cpu_dims)
         print(json.dumps(res))
