@@ -217,7 +217,7 @@ extern "C" int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, in
                                  int *info, void *ws, size_t ws_bytes, void *stream, const dpgp_exec_t *exec) {
     if (D <= 0) return -1;
     if (N <= 0) return -2;
-    if (M <= 0 || M > N) return -3;
+    if (M <= 0) return -3;                                  // (M > N is legal: prediction evaluates f_hat on few test points)
     if (Q <= 0 || Q > DPGP_MAX_Q) return -4;
     if (!y) return -5;
     if (ldy < D) return -6;

@@ -205,6 +205,36 @@ def dp_gp_lvm(y_train,
         phi = dp_model.assignments                                               # [D x T], all output dims
         return (phi @ F.softplus(gamma_atoms_raw), phi @ F.softplus(sig_var_atoms_raw), phi @ F.softplus(beta_atoms_raw))
 
+    pred_state = {}
+
+    def _init_test_latents(y_test, y_ref, use_pca, x_test_mean, x_test_var):
+        """q(X*) as dp_gp_lvm.py:246-262: mean from PCA of y_test or from the nearest training neighbour (L2 over the given
+        columns) plus N(0, 0.01^2) noise, variances 1 — unless values are handed in."""
+        n_t = y_test.shape[0]
+        if x_test_mean is not None:
+            init = np.asarray(x_test_mean.detach().cpu() if torch.is_tensor(x_test_mean) else x_test_mean, dtype=np.float64)
+        elif use_pca:
+            init = pca(y_test, num_latent_dimensions=num_latent_dims)
+        else:
+            d2 = ((y_ref[:, None, :] - y_test[None, :, :]) ** 2).sum(-1)            # [N x N*]  (utils/expressions.py:28-44)
+            init = x_mean.detach().cpu().numpy()[np.argmin(d2, axis=0)] + \
+                np.random.normal(scale=0.01, size=(n_t, num_latent_dims))
+        if x_test_var is not None:
+            var = np.asarray(x_test_var.detach().cpu() if torch.is_tensor(x_test_var) else x_test_var, dtype=np.float64)
+        else:
+            var = np.ones((n_t, num_latent_dims))
+        return _t(init), _t(var.reshape(n_t, num_latent_dims))
+
+    def _fhat_on(y_t, xt, st_, dims=None):
+        """f_hat (fused ELBO, dpgp_elbo_fhat) of the first `dims` output dims on (y_t, q(X*)) with the trained kernel and
+        inducing inputs, and KL(q(X*) || p(X*)); uses the mixed hyper-parameters of the last evaluate()."""
+        dd = num_dimensions if dims is None else dims
+        ws_t = ops.ElboWorkspace(dd, y_t.shape[0], num_inducing_points, num_latent_dims, precision, device)
+        terms_t, sums, info = ops.elbo_fhat(y_t, x_u, xt, st_, buf['gamma'][:dd].contiguous(), buf['alpha'][:dd].contiguous(),
+                                      buf['beta'][:dd].contiguous(), jitter=GP_DEFAULT_JITTER, prec=precision, workspace=ws_t)
+        pred_state['terms'] = terms_t.clone()
+        return sums[0].clone(), sums[1].clone()
+
     class DP_GP_LVM(Trainable):
         """Accessors as in the reference (dp_gp_lvm.py:161-231,502-508)."""
         raw = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw,
@@ -275,13 +305,81 @@ def dp_gp_lvm(y_train,
         gradients = staticmethod(_gradients)
         optimise = staticmethod(_optimise)
 
-        @staticmethod
-        def predict_new_latent_variables(y_test, use_pca=False):
-            raise NotImplementedError('prediction paths (dp_gp_lvm.py:233-500) are SURVEY.md §8(f) row 2: not built yet')
+        @property
+        def prediction_terms(self):
+            """[D* x 5] f_hat terms of the test points in the last predict_* call (the observed dims for missing data)."""
+            return pred_state.get('terms')
 
         @staticmethod
-        def predict_missing_data(y_test):
-            raise NotImplementedError('prediction paths (dp_gp_lvm.py:233-500) are SURVEY.md §8(f) row 2: not built yet')
+        def predict_new_latent_variables(y_test, use_pca=False, x_test_mean=None, x_test_var=None):
+            """Mirror of dp_gp_lvm.py:233-309: q(X*) for fully observed test data y_test [N* x D] and the prediction lower bound
+                f_hat + f_hat_test - KL(q(X)) - KL(q(X*)),    test log-likelihood = f_hat_test - KL(q(X*)),
+            (without the reference's broadcasting defect in its beta (trace - psi_0) term, dp_gp_lvm.py:292 — see
+            oracle/gen_golden_predict.py; tests reproduce the reference's number by adding that defect back)
+            where f_hat_test is the SAME fused ELBO evaluated on (y_test, q(X*)) with the trained kernel and inducing inputs
+            (one more dpgp_elbo_fhat call).  Returns (prediction_lower_bound, x_test_mean [N* x Q], x_test_covar [N* x Q x Q],
+            test_log_likelihood) at the initial q(X*): nearest training neighbour + N(0, 0.01^2) noise, or PCA of y_test
+            (`use_pca`), or the given x_test_mean / x_test_var (values; what a caller's optimiser of q(X*) passes back in)."""
+            assert not sharded and world == 1, 'prediction paths run on one GPU'
+            y_test = np.asarray(y_test, dtype=np.float64)
+            num_test_points, test_dims = np.shape(y_test)
+            assert test_dims == num_dimensions, \
+                'Observed dimensionality for prediction must be equal to the dimensionality of the training data.'
+            xt, st_ = _init_test_latents(y_test, np.asarray(y_train), use_pca, x_test_mean, x_test_var)
+            out = evaluate().clone()                                                 # (objective, f_hat, KL, DP, hyper)
+            f_hat_test, kl_test = _fhat_on(_t(y_test), xt, st_)
+            lower_bound = out[1] + f_hat_test - out[2] - kl_test
+            return lower_bound, xt, torch.diag_embed(st_), f_hat_test - kl_test
+
+        @staticmethod
+        def predict_missing_data(y_test, use_pca=False, x_test_mean=None, x_test_var=None):
+            """Mirror of dp_gp_lvm.py:311-500: y_test [N* x Do] holds the FIRST Do output dims of the test points; returns
+            (missing_data_lower_bound, x_test_mean, x_test_covar, predicted_mean [N* x Du], predicted_covar [Du x N* x N*])
+            for the remaining Du = D - Do dims at the initial q(X*) (see predict_new_latent_variables).  Composed of the
+            library's operators (Psi statistics at q(X*), batched Cholesky / triangular solves) and plain fp64 GEMMs."""
+            assert not sharded and world == 1, 'prediction paths run on one GPU'
+            y_test = np.asarray(y_test, dtype=np.float64)
+            num_test_points, num_observed_dims = np.shape(y_test)
+            assert num_observed_dims < num_dimensions, \
+                'Observed dimensionality for missing data scenario must be less than total ' \
+                'dimensionality of training data.'
+            do, m_ = num_observed_dims, num_inducing_points
+            xt, st_ = _init_test_latents(y_test, np.asarray(y_train)[:, :do], use_pca, x_test_mean, x_test_var)
+            out = evaluate().clone()
+            gam, al, be = buf['gamma'], buf['alpha'][:, 0], buf['beta'][:, 0]
+            f_hat_test, kl_test = _fhat_on(_t(y_test), xt, st_, dims=do)
+            lower_bound = out[1] + f_hat_test - out[2] - kl_test
+            # predictive mean / covariance of the unobserved dims (:426-498), output dims do .. D-1 only
+            gu, au, bu = gam[do:].contiguous(), al[do:].contiguous(), be[do:].contiguous()
+            s_train = F.softplus(x_var_raw)
+            psi_1 = ops.psi1(x_u, x_mean, s_train, gu, au)                          # [Du x N x M]
+            psi_2 = ops.psi2(x_u, x_mean, s_train, gu, au)
+            psi_1t = ops.psi1(x_u, xt, st_, gu, au)                                  # [Du x N* x M]
+            psi_2t = ops.psi2(x_u, xt, st_, gu, au)
+            k_uu = ops.ard_rbf_gram(x_u, None, gu, au, bu, include_noise=False, include_jitter=True, jitter=GP_DEFAULT_JITTER)
+            l_uu, _ = ops.potrf_batched(k_uu)
+            h = ops.trsm_batched(l_uu, psi_2)
+            a_mat = bu[:, None, None] * ops.trsm_batched(l_uu, h.transpose(1, 2).contiguous()).transpose(1, 2) + \
+                torch.eye(m_, dtype=TORCH_DTYPE, device=device)
+            l_a, _ = ops.potrf_batched(a_mat.contiguous())
+            c = ops.trsm_batched(l_a, ops.trsm_batched(l_uu, psi_1.transpose(1, 2).contiguous()))          # [Du x M x N]
+            c_pred = ops.trsm_batched(l_a, ops.trsm_batched(l_uu, psi_1t.transpose(1, 2).contiguous()))   # [Du x M x N*]
+            y_u = _t(np.asarray(y_train)[:, do:]).transpose(0, 1).contiguous()[:, :, None]                 # [Du x N x 1]
+            cy = torch.matmul(c, y_u)                                                # [Du x M x 1]
+            predicted_mean = (bu[:, None] * torch.matmul(c_pred.transpose(1, 2), cy)[:, :, 0]).transpose(0, 1)   # [N* x Du]
+            eye = torch.eye(m_, dtype=TORCH_DTYPE, device=device).expand(num_dimensions - do, m_, m_).contiguous()
+            l_uu_inv, l_a_inv = ops.trsm_batched(l_uu, eye), ops.trsm_batched(l_a, eye)
+            ainv = torch.matmul(l_a_inv.transpose(1, 2), l_a_inv)                    # A^-1
+            g = psi_2t - torch.matmul(psi_1t.transpose(1, 2), psi_1t)               # [Du x M x M]
+            scale_yu = torch.matmul(torch.matmul(torch.matmul(l_uu_inv.transpose(1, 2), torch.matmul(ainv, l_uu_inv)),
+                                                 psi_1.transpose(1, 2)), y_u)       # [Du x M x 1]
+            yu_var = bu * bu * torch.matmul(scale_yu.transpose(1, 2), torch.matmul(g, scale_yu))[:, 0, 0]
+            tr_term = torch.diagonal(torch.matmul(torch.matmul(l_uu_inv.transpose(1, 2), torch.matmul(eye - ainv, l_uu_inv)),
+                                                  psi_2t), dim1=-2, dim2=-1).sum(-1)
+            psi_0t = ops.psi0(num_test_points, au)[:, 0]
+            predicted_covar = yu_var[:, None, None] + (psi_0t + 1.0 / bu + tr_term)[:, None, None] * \
+                torch.eye(num_test_points, dtype=TORCH_DTYPE, device=device)
+            return lower_bound, xt, torch.diag_embed(st_), predicted_mean, predicted_covar
 
     return DP_GP_LVM()
 

@@ -55,8 +55,10 @@ def test_bad_arguments_are_reported_by_index_before_any_launch():
     assert lib.dpgp_psi2_f32(0, 1, 1, 1, None, None, None, None, None, None, None, 0, 0, None) == -1
     assert lib.dpgp_psi2_f32(1, 1, 1, 31, None, None, None, None, None, None, None, 0, 0, None) == -4     # Q > DPGP_MAX_Q
     assert lib.dpgp_psi2_f32(1, 1, 1, 1, None, None, None, None, None, None, None, 0, 0, None) == -5       # null z
+    assert lib.dpgp_elbo_fhat(4, 10, 0, 2, None, 4, None, None, None, None, None, None, 1e-8, 1, 0, None, None, None,
+                              None, 0, None) == -3                                                           # M <= 0
     assert lib.dpgp_elbo_fhat(4, 10, 20, 2, None, 4, None, None, None, None, None, None, 1e-8, 1, 0, None, None, None,
-                              None, 0, None) == -3                                                           # M > N
+                              None, 0, None) == -5                                                           # M > N is legal (prediction)
     assert lib.dpgp_potrf_batched_f64(1, 0, None, None, None, 0, 0, None) == -2
     with pytest.raises(ValueError):
         _lib.check(-3, 'x')
