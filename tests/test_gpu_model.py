@@ -108,8 +108,10 @@ def test_constructor_assertions_and_default_init(dev):
     assert np.isfinite(o1)
     terms, info = model.per_dimension_terms
     assert int(info.abs().max()) == 0
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):                                    # all D dims observed is not a missing-data problem
         model.predict_missing_data(y)
+    lower_bound, x_test_mean, x_test_covar, mean, covar = model.predict_missing_data(y[:9, :8])
+    assert mean.shape == (9, y.shape[1] - 8) and covar.shape == (y.shape[1] - 8, 9, 9) and bool(torch.isfinite(lower_bound))
 
 
 def test_mask_size_groups_adjacent_dims(dev):
