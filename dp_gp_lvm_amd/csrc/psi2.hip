@@ -1743,6 +1743,10 @@ int psi2_nsplit(int B, int N, int M) {
     // CK row-equivalents each -- before the patches for B < 256, after them otherwise (psi2_task_1d).  The makespan of that
     // list schedule, in rows, is minimised over ns <= 8 (>= 128 rows per split).  Config 2 (B = 64): 8 splits are 1536 + 64
     // workgroups = 3 rounds and a 4th one for the chain tasks (4 x 256 rows); 5 splits are 1024 = 2 rounds of 448 rows.
+    if (const char *e = getenv("DPGP_PSI2_NS")) {                // (experiments only)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8 && N / v >= 1) return v;
+    }
     const int np64 = dpgp_ceil_div(M, 64), patches = np64 * (np64 + 1) / 2, R = 512, CK = 250;
     const long long nchain = (M <= 128) ? B : 0;
     int max_ns = N / 128;
