@@ -24,9 +24,11 @@ def main():
     ap.add_argument('--lr', type=float, default=0.01)
     ap.add_argument('--precision', default='mixed', choices=['mixed', 'f64'])
     ap.add_argument('--out', default='')
+    ap.add_argument('--over-t', action='store_true', help='train the over-T formulation dp_gp_lvm_t instead of dp_gp_lvm')
+    ap.add_argument('--predict', type=int, default=0, help='hold out this many rows and report their test log-likelihood')
     a = ap.parse_args()
     import torch
-    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm, dp_gp_lvm_t
 
     # three groups of output dims generated from different subsets of a shared latent space (what the DP should recover)
     rng = np.random.default_rng(a.seed)
@@ -39,8 +41,12 @@ def main():
         y[:, idx] = np.tanh(x[:, [gi, (gi + 1) % 3]]) @ w + 0.05 * rng.standard_normal((a.n, len(idx)))
     y = (y - y.mean(axis=0)) / y.std(axis=0)
 
-    model = dp_gp_lvm(y_train=y, num_inducing_points=a.m, num_latent_dims=a.q, truncation_level=a.t,
-                      device=torch.device('cuda', 0), precision=a.precision)
+    y_all = y
+    if a.predict:
+        y, y_held_out = y_all[:-a.predict], y_all[-a.predict:]
+    factory = dp_gp_lvm_t if a.over_t else dp_gp_lvm
+    model = factory(y_train=y, num_inducing_points=a.m, num_latent_dims=a.q, truncation_level=a.t,
+                    device=torch.device('cuda', 0), precision=a.precision)
     print('Training DP-GP-LVM: N=%d D=%d M=%d Q=%d T=%d, %d Adam iterations, lr %g' % (a.n, a.d, a.m, a.q, a.t, a.iters, a.lr))
     t0 = time.time()
 
@@ -50,13 +56,19 @@ def main():
     model.optimise(a.iters, learning_rate=a.lr, callback=log)
     train_opt_time = time.time() - t0
     print('Final iter {:5}:\n  GP-DP: {}\nTime to optimise: {} s'.format(a.iters - 1, float(model.objective), train_opt_time))
+    if a.predict and not a.over_t:
+        lower_bound, x_test_mean, _, test_ll = model.predict_new_latent_variables(y_held_out)
+        print('held-out rows: prediction lower bound {}, test log-likelihood {} (at the nearest-neighbour q(X*))'.format(
+            float(lower_bound), float(test_ll)))
     x_mean, x_covar = model.q_x
     gat, aat, bat = model.dp_atoms
     phi = model.assignments.cpu().numpy()
     print('group assignment of the output dims (argmax of q(Z)):', phi.argmax(axis=1))
     if a.out:
-        np.savez(a.out, y_train=y, ard_weights=model.ard_weights.cpu().numpy(), noise_precision=model.noise_precision.cpu().numpy(),
-                 signal_variance=model.signal_variance.cpu().numpy(), x_u=model.inducing_input.cpu().numpy(),
+        mixed = (model.assignments @ gat, model.assignments @ bat, model.assignments @ aat) if a.over_t else \
+            (model.ard_weights, model.noise_precision, model.signal_variance)
+        np.savez(a.out, y_train=y, ard_weights=mixed[0].cpu().numpy(), noise_precision=mixed[1].cpu().numpy(),
+                 signal_variance=mixed[2].cpu().numpy(), x_u=model.inducing_input.cpu().numpy(),
                  x_mean=x_mean.cpu().numpy(), x_covar=x_covar.cpu().numpy(), assignments=phi, gamma_atoms=gat.cpu().numpy(),
                  alpha_atoms=aat.cpu().numpy(), beta_atoms=bat.cpu().numpy(), train_opt_time=train_opt_time)
         print('saved', a.out)
