@@ -101,7 +101,7 @@ extern "C" int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *al
                                     double *d_alpha_beta, int *info, void *stream) {
     if (D <= 0) return -1;
     if (N <= 0) return -2;
-    if (M <= 0 || M > N) return -3;
+    if (M <= 0) return -3;
     if (Q <= 0 || Q > DPGP_MAX_Q) return -4;
     if (!alpha) return -5;
     if (!beta) return -6;
@@ -156,7 +156,7 @@ extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y
                                      size_t ws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream) {
     if (D <= 0) return -1;
     if (N <= 0) return -2;
-    if (M <= 0 || M > N) return -3;
+    if (M <= 0) return -3;
     if (Q <= 0 || Q > DPGP_MAX_Q) return -4;
     if (!y && !g_psi1) return -5;
     if (y && ldy < D) return -6;

@@ -332,6 +332,40 @@ def dp_gp_lvm(y_train,
             return lower_bound, xt, torch.diag_embed(st_), f_hat_test - kl_test
 
         @staticmethod
+        def test_latent_gradients(y_test, x_test_mean, x_test_var):
+            """d (f_hat_test - KL(q(X*))) / d (x_test_mean, x_test_var) with the trained model fixed — what TensorFlow's autograd
+            gives a caller of the reference who optimises q(X*) on the bounds returned by predict_*; y_test [N* x Do], Do <= D
+            (the first Do output dims).  Uses the backward pass of the fused ELBO (stages A and B) on the test points."""
+            assert not sharded and world == 1, 'prediction paths run on one GPU'
+            y_t = _t(np.asarray(y_test, dtype=np.float64))
+            dd = y_t.shape[1]
+            xt, st_ = _t(x_test_mean.detach().cpu().numpy() if torch.is_tensor(x_test_mean) else x_test_mean), \
+                _t(x_test_var.detach().cpu().numpy() if torch.is_tensor(x_test_var) else x_test_var)
+            evaluate()
+            gam, al, be = buf['gamma'][:dd].contiguous(), buf['alpha'][:dd].contiguous(), buf['beta'][:dd].contiguous()
+            ws_t = ops.ElboWorkspace(dd, y_t.shape[0], num_inducing_points, num_latent_dims, precision, device)
+            ops.elbo_fhat(y_t, x_u, xt, st_, gam, al, be, jitter=GP_DEFAULT_JITTER, prec=precision, workspace=ws_t)
+            gp, wk, gv, _, _ = ops.elbo_grad_chain(al, be, ws_t, jitter=GP_DEFAULT_JITTER, z=x_u, gamma=gam)
+            dmu, ds, _, _ = ops.elbo_grad_psi(y_t, x_u, xt, st_, gam, al, gp, wk, gv, prec=precision)
+            return dmu - xt, ds - 0.5 * (1.0 - 1.0 / st_)                        # minus the KL gradient (gp_expressions.py:10-24)
+
+        @staticmethod
+        def optimise_test_latents(y_test, num_iterations=200, learning_rate=0.01, use_pca=False, x_test_mean=None,
+                                  x_test_var=None):
+            """Adam on q(X*) (mean and softplus-parametrised variances) maximising f_hat_test - KL(q(X*)) for test points
+            observed in their first Do output dims; returns (x_test_mean, x_test_var) to hand to predict_*."""
+            y_test = np.asarray(y_test, dtype=np.float64)
+            xt, st_ = _init_test_latents(y_test, np.asarray(y_train)[:, :y_test.shape[1]], use_pca, x_test_mean, x_test_var)
+            raw = torch.log(torch.expm1(st_))
+            opt = torch.optim.Adam([xt, raw], lr=learning_rate)
+            for _ in range(num_iterations):
+                sv = F.softplus(raw)
+                g_mu, g_s = DP_GP_LVM.test_latent_gradients(y_test, xt, sv)
+                xt.grad, raw.grad = -g_mu, -g_s * torch.sigmoid(raw)
+                opt.step()
+            return xt, F.softplus(raw)
+
+        @staticmethod
         def predict_missing_data(y_test, use_pca=False, x_test_mean=None, x_test_var=None):
             """Mirror of dp_gp_lvm.py:311-500: y_test [N* x Do] holds the FIRST Do output dims of the test points; returns
             (missing_data_lower_bound, x_test_mean, x_test_covar, predicted_mean [N* x Du], predicted_covar [Du x N* x N*])

@@ -73,3 +73,37 @@ def test_default_initialisation_of_test_latents(dev):
         model.predict_new_latent_variables(y_test[:, :4])
     with pytest.raises(AssertionError):
         model.predict_missing_data(y_test)
+
+
+def test_test_latent_gradients_and_optimisation(dev):
+    """d (f_hat_test - KL) / d q(X*) from the HIP backward pass against central differences of the HIP forward (fp64), and
+    Adam on q(X*) improves the test log-likelihood."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    g = golden(FIXTURES[1])
+    model = build(dp_gp_lvm, g, dev, 'f64')
+    y_test = g['y_test']
+    xm, xv = g['new_x_test_mean'].copy(), 0.5 + np.random.default_rng(0).random(g['new_x_test_mean'].shape)
+    g_mu, g_s = (a.cpu().numpy() for a in model.test_latent_gradients(y_test, xm, xv))
+
+    def ll(xm_, xv_):
+        return float(model.predict_new_latent_variables(y_test, x_test_mean=xm_, x_test_var=xv_)[3])
+    rng = np.random.default_rng(1)
+    for _ in range(4):
+        e_mu, e_s = rng.standard_normal(xm.shape), rng.standard_normal(xv.shape)
+        h = 1e-5
+        fd = (ll(xm + h * e_mu, xv + h * e_s) - ll(xm - h * e_mu, xv - h * e_s)) / (2 * h)
+        an = float(np.sum(g_mu * e_mu) + np.sum(g_s * e_s))
+        assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)), (fd, an)
+    before = ll(xm, np.ones_like(xm))
+    xo, vo = model.optimise_test_latents(y_test, num_iterations=60, learning_rate=0.02, x_test_mean=xm)
+    after = ll(xo.cpu().numpy(), vo.cpu().numpy())
+    assert after > before + 1.0, (before, after)
+    # fewer test points than inducing points (N* = 7 < M = 12)
+    g0 = golden(FIXTURES[0])
+    m0 = build(dp_gp_lvm, g0, dev, 'mixed')
+    x0, v0 = m0.optimise_test_latents(g0['y_test'], num_iterations=5, x_test_mean=g0['new_x_test_mean'])
+    assert x0.shape == g0['new_x_test_mean'].shape and bool(torch.isfinite(x0).all()) and bool((v0 > 0).all())
+    # missing-data flavour: only the first Do dims observed
+    do = int(g['n_observed'])
+    gm2, gs2 = model.test_latent_gradients(y_test[:, :do], xm, xv)
+    assert gm2.shape == xm.shape and bool(torch.isfinite(gm2).all()) and bool(torch.isfinite(gs2).all())
