@@ -246,6 +246,19 @@ def main():
             res['objective_and_gradients'] = {'ms': 1e3 * (time.perf_counter() - t0) / reps, 'reps': reps,
                                               'note': 'stage B of the backward pass on the matrix pipe in mixed precision '
                                                       '(psi2_grad_kernel), plain kernel in f64; DESIGN.md 7.1'}
+            # breakdown of one more iteration (torch events on the launch stream): forward, stage A, stage B, chain rule; and
+            # the exponential rate of stage B (its Psi2 term evaluates the FULL M x M square of every (d, n))
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            evs[4].record()
+            model.gradients(events=evs[:4])
+            torch.cuda.synchronize()
+            t_fwd, t_a, t_b, t_c = (evs[4].elapsed_time(evs[0]), evs[0].elapsed_time(evs[1]), evs[1].elapsed_time(evs[2]),
+                                    evs[2].elapsed_time(evs[3]))
+            mp64 = 64 * ((m + 63) // 64)
+            exps_b = float(n) * (d_hi - d_lo) * mp64 * mp64
+            res['objective_and_gradients'].update({
+                'forward_ms': t_fwd, 'stage_a_ms': t_a, 'stage_b_ms': t_b, 'chain_rule_ms': t_c,
+                'stage_b_exp_per_s': exps_b / (t_b * 1e-3), 'stage_b_exp_frac_of_v_exp_rate': exps_b / (t_b * 1e-3) / exp_peak})
             if a.prec in ('mixed', 'f64'):
                 from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
                 model_t = dp_gp_lvm_t(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=p['phi'].shape[1],

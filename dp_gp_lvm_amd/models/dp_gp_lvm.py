@@ -154,19 +154,25 @@ def dp_gp_lvm(y_train,
     grad_names = ('x_mean', 'x_var', 'x_u', 'dp_logits', 'dp_gamma_1', 'dp_gamma_2', 'dp_w', 'gamma_atoms', 'alpha_atoms',
                   'beta_atoms')
 
-    def _gradients():
+    def _gradients(events=None):
         """d objective / d (raw trainable variables) — what tf.gradients(objective, trainable variables) gives the
         reference's optimiser (test/synthetic_data_hard_test.py:143-155).  First version of the backward pass: one forward
         evaluation, then dpgp_elbo_grad_chain, dpgp_elbo_grad_psi and dpgp_model_backward; sharded over D, the per-GPU
-        partial gradients are packed into one buffer and sum-all-reduced.  Returns {name: tensor} keyed like ``raw``."""
+        partial gradients are packed into one buffer and sum-all-reduced.  Returns {name: tensor} keyed like ``raw``.
+        events: optional list of 4 torch.cuda.Event(enable_timing=True), recorded after the forward evaluation, stage A,
+        stage B and the chain rule to the raw variables (bench.py's breakdown)."""
         assert precision in ('mixed', 'f64'), 'the backward pass exists for precision mixed and f64'
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+        mark = (lambda i: events[i].record()) if events is not None else (lambda i: None)
         evaluate()
+        mark(0)
         r = dp_model.raw
         gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER, z=x_u,
                                                  gamma=buf['gamma'])
+        mark(1)
         dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
                                             prec=precision)
+        mark(2)
         rows = r['logits'].shape[0]
         sizes = [num_samples * num_latent_dims, num_samples * num_latent_dims, num_inducing_points * num_latent_dims,
                  rows * truncation_level, max(truncation_level - 1, 1), max(truncation_level - 1, 1), 2,
@@ -180,6 +186,7 @@ def dp_gp_lvm(y_train,
             r['gamma_1'].data_ptr(), r['gamma_2'].data_ptr(), r['w'].data_ptr(), x_mean.data_ptr(), buf['phi'].data_ptr(),
             s_1, s_2, 1 if rank == 0 else 0, dmu.data_ptr(), ds.data_ptr(), dz.data_ptr(), dg.data_ptr(), dab.data_ptr(),
             *[p_.data_ptr() for p_ in parts], st), 'dpgp_model_backward')
+        mark(3)
         if sharded:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)      # one packed exchange (N Q x 2 + M Q + ...)
         shapes = [x_mean.shape, x_var_raw.shape, x_u.shape, r['logits'].shape, r['gamma_1'].shape, r['gamma_2'].shape,
