@@ -5,12 +5,12 @@ O=$R/gpurun_out/prof_final
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_trace_c3.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c2 -- python3 bench.py --steps 40 --warmup 5 --config 2 --no-cpu-baseline --no-secondary > $O/bench_trace_c2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc1 -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc1.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc2 -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary --no-grad > $O/bench_trace_c3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c2 -- python3 bench.py --steps 40 --warmup 5 --config 2 --no-cpu-baseline --no-secondary --no-grad > $O/bench_trace_c2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-grad > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-grad > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc1 -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-grad > $O/pmc1.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc2 -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-grad > $O/pmc2.log 2>&1
 python3 - <<PY
 import csv, glob, collections, os
 O="$O"
@@ -34,3 +34,6 @@ for tag in ("pmc_fetch","pmc_write","pmc1","pmc2"):
             for c,v in agg[k].items():
                 P("  %-42s %-28s %.5g" % (k, c, sum(v)/len(v)))
 PY
+find $O -name "*kernel_trace.csv" -delete
+find $O -name "*counter_collection.csv" -size +8M -delete
+du -sh $O
