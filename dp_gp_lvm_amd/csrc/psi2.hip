@@ -793,6 +793,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
     }
     P2_MARK(1);
     for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {
+        const int nr = min(NR, (nend - nc + 3) >> 2);               // rows of this wave in the batch that exist (>= 1)
         P2_BEGIN();
 #ifdef PSI2_DIAG_SKIP_AB      // timing experiment only (wrong results): phases A and B for the first chunk only
         if (nc != nbeg + wv) goto phase_c;
@@ -962,7 +963,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
                 // many latent dims: the operand registers of two row tiles plus four result tiles no longer fit 256 VGPRs
                 // (the pipelined form spills ~200 dwords per chunk); one row tile at a time, results read right away
 #pragma unroll 1
-                for (int r = 0; r < NR; ++r) {
+                for (int r = 0; r < nr; ++r) {
                     load_row(r, spB);
 #pragma unroll
                     for (int I = 0; I < 2; ++I) {
@@ -980,7 +981,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
             c0 = issue(a0, 0, spB);
             if (!DIAG) c1 = issue(a0, 1, spB);
 #pragma unroll 1
-            for (int r = 0; r < NR - 1; ++r) {
+            for (int r = 0; r < nr - 1; ++r) {            // (rows past the end of the split are skipped: they would add exp2(-30000) = 0)
                 c2 = issue(a1, 0, spB);
                 load_row(r + 1, spBn);
                 expacc(acc[0][0], c0);
@@ -1406,6 +1407,7 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
         pf_m[u] = ok ? (float)mu[(size_t)n * Q + k] : 0.0f;
     }
     for (int nc = nbeg + wv; nc < nend; nc += 4 * NR) {
+        const int nr = min(NR, (nend - nc + 3) >> 2);               // rows of this wave in the batch that exist (>= 1)
         // ---- phase A (as the forward kernel) + mu', S of the rows for the finishing step ----
 #pragma unroll
         for (int u = 0; u < NPA; ++u) {
@@ -1510,7 +1512,7 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
         // ---- phase C': per row, w = G' exp2(E) tile by tile, T'^T += Zt w on the matrix pipe; then the finishing step ----
         // (a hand-made software pipeline over the tiles as in the forward kernel was slower here: 8.0 vs 7.1 ms at config 3)
 #pragma unroll 1
-        for (int r = 0; r < NR; ++r) {
+        for (int r = 0; r < nr; ++r) {
             dpgp_f2 xk[KB];
             unsigned spA[2], spB[2];
 #pragma unroll
@@ -1679,7 +1681,7 @@ static int launch_psi2_grad_kb(int B, int N, int M, int Q, const unsigned char *
                                const double *gamma, const double *alpha, const double *GP, double *part, double *stage,
                                double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16), nps = dpgp_ceil_div(Mp, 64), np = nps * nps, ns = psi2_grad_nsplit(B, N, M);
-    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);
+    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 4);
     const size_t slab = (size_t)B * np * N * Q;
     float *dmu_part = reinterpret_cast<float *>(part), *ds_part = dmu_part + slab;
     double *dz_part = part + slab + 2;                          // (2 float slabs = `slab` doubles, + alignment slack)
@@ -1756,8 +1758,8 @@ int psi2_nsplit(int B, int N, int M) {
     double best_t = 1e300;
     for (int ns = 1; ns <= max_ns; ++ns) {
         const long long W = (long long)B * patches * ns;
-        long long L = dpgp_round_up(dpgp_ceil_div(N, ns), 64);
-        if (L > N) L = N;
+        long long L = dpgp_round_up(dpgp_ceil_div(N, ns), 4) + 8;   // (+ the per-chunk phases A and B, ~8 row-equivalents per split)
+        if (L > N + 8) L = N + 8;
         double t;
         if (nchain == 0) {
             t = (double)((W + R - 1) / R) * (double)L;
@@ -1830,7 +1832,7 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
         const int rc = launch_psi2_consts<TIN>(z, M, Q, consts, st);
         if (rc) return rc;
     }
-    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);      // 4 waves x 16-row chunks
+    const int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 4);       // even splits; a wave skips the rows of its last 16-row chunk that do not exist
     const long long nwg = (long long)B * ns * (nps * (nps + 1) / 2) + (task.ws ? B : 0);   // see psi2_task_1d
     if (nwg > 0x7fffffffLL) return -1;
     dim3 grid((unsigned)nwg);
