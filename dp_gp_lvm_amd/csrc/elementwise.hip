@@ -437,8 +437,12 @@ static int launch_psi1T_y_f16_kf(int B, int N, int M, int Q, const TIN *z, const
 }
 
 int psi1T_y_nsplit(int B, int N, int M) {
+    if (const char *e = getenv("DPGP_PSI1_NS")) {                // (experiments only)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64 && v <= dpgp_ceil_div(N, 4 * P1Y_NT)) return v;
+    }
     int wgs = B * dpgp_ceil_div(M, 128);
-    int ns = dpgp_ceil_div(1024, wgs);          // aim for >= ~4 workgroups per CU
+    int ns = dpgp_ceil_div(512, wgs);           // aim for ~2 workgroups per CU (measured: config 3 best with 1 split, config 2 with 8)
     int max_ns = dpgp_ceil_div(N, 4 * P1Y_NT);
     if (ns > max_ns) ns = max_ns;
     return ns < 1 ? 1 : ns;
