@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
         typedef TP tp4 __attribute__((ext_vector_type(4)));
         typedef TL tl4 __attribute__((ext_vector_type(4)));
         const int u = t >> 6, r = (t & 63) >> 2, c4 = (t & 3) * 4;
-#pragma unroll 2
+#pragma unroll 3
         for (int t0 = 0; t0 < nlow; t0 += 4) {
             const int tt = min(t0 + u, nlow - 1);
             int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
                     }
             }
             if (t0 + u < nlow) {
-                TL *dst = (mode == 0) ? tiles + lds_tile_index(I, J, nb) * TSZ + r * LDT + c4 : Wb + off;
+                // (the 2-per-CU instantiation is LDS-resident by construction: a destination that is provably not global
+                //  memory lets the loads of the next passes be issued ahead of these stores)
+                TL *dst = (OCC == 2 || mode == 0) ? tiles + lds_tile_index(I, J, nb) * TSZ + r * LDT + c4 : Wb + off;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int je = j + e;
