@@ -193,20 +193,62 @@ def dp_gp_lvm(y_train,
                   r['w'].shape, gamma_atoms_raw.shape, sig_var_atoms_raw.shape, beta_atoms_raw.shape]
         return {k: p_[:int(np.prod(sh))].reshape(sh) for k, p_, sh in zip(grad_names, parts, shapes)}
 
-    def _optimise(num_iterations, learning_rate=0.01, callback=None):
+    twin = {}
+
+    def _fp64_twin():
+        """A second model on the SAME raw variables (shared storage) that evaluates in fp64: the safety net of optimise()."""
+        if 'model' not in twin:
+            t_model = dp_gp_lvm(y_train, num_latent_dims=num_latent_dims, num_inducing_points=num_inducing_points,
+                                truncation_level=truncation_level, alpha_prior_params=alpha_prior_params, mask_size=mask_size,
+                                device=device, precision='f64', initial_values=dict(x_mean=x_mean.detach().cpu().numpy()))
+            mine = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw,
+                        beta_atoms=beta_atoms_raw, **{'dp_' + k: v for k, v in dp_model.raw.items()})
+            for k, v in t_model.raw.items():
+                v.data = mine[k].data                                            # same storage: updates are seen by both
+            twin['model'] = t_model
+        return twin['model']
+
+    def _optimise(num_iterations, learning_rate=0.01, callback=None, fallback_precision='f64', _force_fallback_at=()):
         """Adam on the raw variables with the HIP gradients (the reference: tf.train.AdamOptimizer(...).minimize(objective),
-        test/synthetic_data_hard_test.py:143-155).  torch.optim.Adam only applies the update (plumbing)."""
+        test/synthetic_data_hard_test.py:143-155).  torch.optim.Adam only applies the update (plumbing).
+        Mixed precision carries Psi2 in fp32: once training drives K_uu towards singularity (long length scales: its small
+        eigenvalues approach the 1e-8 jitter) the fp32 rounding of Psi2 (~1e-7 N alpha^2) exceeds the small eigenvalues of
+        B = K_uu + beta Psi2, the Cholesky factorisation fails or the gradients blow up, where the reference's fp64 graph
+        still works.  Every iteration therefore checks the Cholesky flags and the gradients; a bad step
+        is recomputed by an fp64 twin of the model on the same variables (`fallback_precision='f64'`, single GPU, M <= 128),
+        and after 3 such steps the rest of the run stays in fp64.  Returns {'fallback_steps': count, 'precision': final}."""
         params = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, dp_logits=dp_model.raw['logits'],
                       dp_gamma_1=dp_model.raw['gamma_1'], dp_gamma_2=dp_model.raw['gamma_2'], dp_w=dp_model.raw['w'],
                       gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw, beta_atoms=beta_atoms_raw)
         opt = torch.optim.Adam(list(params.values()), lr=learning_rate)
+        can_fall_back = (precision == 'mixed' and fallback_precision == 'f64' and not sharded and world == 1 and
+                         16 * ((num_inducing_points + 15) // 16) <= 128)
+        stats = {'fallback_steps': 0, 'precision': precision}
+        use_twin = False
         for it in range(num_iterations):
-            g = _gradients()
+            src = _fp64_twin() if use_twin else None
+            g = src.gradients() if use_twin else _gradients()
+            info_now = (src.per_dimension_terms[1] if use_twin else workspace.info)
+            bad = (info_now != 0).any() | ~torch.stack([torch.isfinite(v).all() for v in g.values()]).all()
+            if bool(bad) or (it in _force_fallback_at and not use_twin):      # (_force_fallback_at: test hook)
+                if use_twin or not can_fall_back:
+                    raise FloatingPointError('Cholesky factorisation failed or non-finite gradient at iteration %d '
+                                             '(precision %s)' % (it, 'f64' if use_twin else precision))
+                src = _fp64_twin()
+                g = src.gradients()
+                if bool((src.per_dimension_terms[1] != 0).any()) or not all(bool(torch.isfinite(v).all()) for v in g.values()):
+                    raise FloatingPointError('Cholesky factorisation failed or non-finite gradient at iteration %d in fp64 '
+                                             'as well' % it)
+                stats['fallback_steps'] += 1
+                if stats['fallback_steps'] >= 3:
+                    use_twin, stats['precision'] = True, 'f64'
+                    twin['active'] = True                                        # .objective follows (see the accessors)
             for k, p_ in params.items():
                 p_.grad = g[k].reshape(p_.shape).clone()
             opt.step()
             if callback is not None:
                 callback(it)
+        return stats
 
     def _mixed():
         phi = dp_model.assignments                                               # [D x T], all output dims
@@ -287,13 +329,14 @@ def dp_gp_lvm(y_train,
 
         @property
         def objective(self):
-            """dp.objective - (f_hat - KL) - hyper-prior (dp_gp_lvm.py:154): 0-d fp64 device tensor."""
-            return evaluate()[0].clone()
+            """dp.objective - (f_hat - KL) - hyper-prior (dp_gp_lvm.py:154): 0-d fp64 device tensor.  (After optimise() has
+            moved a mixed-precision run to its fp64 twin, the twin evaluates.)"""
+            return _fp64_twin().objective if twin.get('active') else evaluate()[0].clone()
 
         @property
         def objective_terms(self):
             """(objective, f_hat, KL, DP objective, hyper-prior log-likelihood) of one evaluation, as a device tensor."""
-            return evaluate().clone()
+            return _fp64_twin().objective_terms if twin.get('active') else evaluate().clone()
 
         @property
         def per_dimension_terms(self):
@@ -311,6 +354,7 @@ def dp_gp_lvm(y_train,
 
         gradients = staticmethod(_gradients)
         optimise = staticmethod(_optimise)
+        fp64_twin = staticmethod(_fp64_twin)     # the model on the same variables evaluated in fp64 (see optimise)
 
         @property
         def prediction_terms(self):

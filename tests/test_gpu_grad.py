@@ -275,3 +275,24 @@ def test_stage_b_beyond_128_inducing_points(dev, shape):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=3e-4 * np.abs(want).max(), err_msg=name)
     with pytest.raises(ValueError):
         ops.elbo_grad_psi(t(y), t(z), t(mu), t(s), t(gamma), t(alpha), gp, wk, gv, prec='f64')
+
+
+def test_optimise_falls_back_to_fp64_on_a_bad_step(dev):
+    """optimise() checks the Cholesky flags and the gradients every iteration; a bad mixed-precision step is recomputed by an
+    fp64 twin on the same variables, after 3 such steps the run stays in fp64 (hook: _force_fallback_at)."""
+    g = golden('grad_ref_60_10_15_4_T5')
+    model = build_model(g, dev, 'mixed')
+    before = float(model.objective)
+    stats = model.optimise(12, learning_rate=0.01)
+    assert stats == {'fallback_steps': 0, 'precision': 'mixed'}
+    stats = model.optimise(12, learning_rate=0.01, _force_fallback_at=(2, 5))
+    assert stats == {'fallback_steps': 2, 'precision': 'mixed'}
+    stats = model.optimise(12, learning_rate=0.01, _force_fallback_at=(0, 1, 2))
+    assert stats == {'fallback_steps': 3, 'precision': 'f64'}
+    twin = model.fp64_twin()
+    np.testing.assert_allclose(float(twin.objective), float(model.evaluate_()[0]), rtol=1e-5)   # same variables, two precisions
+    assert float(model.objective) == float(twin.objective)                                  # the accessor follows the twin now
+    assert float(model.objective) < before
+    model64 = build_model(g, dev, 'f64')
+    with pytest.raises(FloatingPointError):
+        model64.optimise(3, _force_fallback_at=(1,))                                       # nothing to fall back to
