@@ -41,7 +41,8 @@ def dp_gp_lvm(y_train,
               truncation_level=DP_DEFAULT_TRUNCATION_LEVEL,
               alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
               mask_size=1,
-              device=None, precision='mixed', process_group=None, initial_values=None, _shard_of=None):
+              device=None, precision='mixed', process_group=None, initial_values=None, backward_precision=None,
+              _shard_of=None):
     """
     :param y_train: [N x D] numpy array, columns normalised to zero mean / unit variance (dp_gp_lvm.py:30-32).
     :param num_latent_dims: Q.  :param num_inducing_points: M.  :param truncation_level: T.
@@ -50,6 +51,9 @@ def dp_gp_lvm(y_train,
     :param device: torch device of the parameters (default: current GPU).
     :param precision: 'mixed' (psi-statistics fp32 on the matrix cores, Cholesky chain fp64), 'f64' or 'f32'.
     :param process_group: torch.distributed group over which the D output dims are sharded (None: single GPU).
+    :param backward_precision: precision of the streaming stage (B) of the backward pass; default: `precision`.  'mixed' with
+           precision='f64' = fp64 forward and dense adjoints (accurate B^-1, K^-1 however ill-conditioned K_uu is), the
+           streaming stage on the matrix pipe (gradients to ~1e-4): what optimise() falls back to.
     :param initial_values: dict of post-initialisation parameter VALUES (x_mean, x_var, x_u, phi_logits, gamma_atoms,
            alpha_atoms, beta_atoms, gamma_1, gamma_2, w_1, w_2) that replace the random/PCA initialisation — used by the
            parity tests and the benchmark, which must not depend on PCA sign conventions or NumPy's global RNG.
@@ -63,6 +67,7 @@ def dp_gp_lvm(y_train,
         'The truncation level must be positive and less than the dimensionality of the observed data and ' \
         'less than the number of observations.'
     assert precision in _lib.PREC, 'precision must be one of %s' % sorted(_lib.PREC)
+    assert backward_precision in (None, 'mixed', 'f64'), "backward_precision must be None, 'mixed' or 'f64'"
     device = default_device() if device is None else torch.device(device)
     iv = dict(initial_values or {})
 
@@ -171,7 +176,7 @@ def dp_gp_lvm(y_train,
                                                  gamma=buf['gamma'])
         mark(1)
         dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
-                                            prec=precision)
+                                            prec=backward_precision or precision)
         mark(2)
         rows = r['logits'].shape[0]
         sizes = [num_samples * num_latent_dims, num_samples * num_latent_dims, num_inducing_points * num_latent_dims,
@@ -200,7 +205,8 @@ def dp_gp_lvm(y_train,
         if 'model' not in twin:
             t_model = dp_gp_lvm(y_train, num_latent_dims=num_latent_dims, num_inducing_points=num_inducing_points,
                                 truncation_level=truncation_level, alpha_prior_params=alpha_prior_params, mask_size=mask_size,
-                                device=device, precision='f64', initial_values=dict(x_mean=x_mean.detach().cpu().numpy()))
+                                device=device, precision='f64', backward_precision='mixed',
+                                initial_values=dict(x_mean=x_mean.detach().cpu().numpy()))
             mine = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw,
                         beta_atoms=beta_atoms_raw, **{'dp_' + k: v for k, v in dp_model.raw.items()})
             for k, v in t_model.raw.items():

@@ -296,3 +296,17 @@ def test_optimise_falls_back_to_fp64_on_a_bad_step(dev):
     model64 = build_model(g, dev, 'f64')
     with pytest.raises(FloatingPointError):
         model64.optimise(3, _force_fallback_at=(1,))                                       # nothing to fall back to
+
+
+@pytest.mark.parametrize('fixture', ['grad_ref_40_6_12_3_T4', 'grad_ref_60_10_15_4_T5'])
+def test_fp64_forward_with_matrix_pipe_stage_b(dev, fixture):
+    """precision='f64', backward_precision='mixed' (what optimise() falls back to): fp64 forward and dense adjoints, the
+    streaming stage on the matrix pipe; against the reference's tf.gradients."""
+    g = golden(fixture)
+    model = build_model(g, dev, 'f64', backward_precision='mixed')
+    np.testing.assert_allclose(float(model.objective), float(g['objective']), rtol=1e-10)
+    got = model.gradients()
+    for ref_name, raw_name in REF2RAW.items():
+        want = g['grad_' + ref_name]
+        have = got[raw_name].cpu().numpy().reshape(want.shape)
+        np.testing.assert_allclose(have, want, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(want).max()), err_msg=ref_name)
