@@ -259,6 +259,18 @@ def main():
             res['objective_and_gradients'].update({
                 'forward_ms': t_fwd, 'stage_a_ms': t_a, 'stage_b_ms': t_b, 'chain_rule_ms': t_c,
                 'stage_b_exp_per_s': exps_b / (t_b * 1e-3), 'stage_b_exp_frac_of_v_exp_rate': exps_b / (t_b * 1e-3) / exp_peak})
+            if a.prec == 'mixed' and m <= 128:
+                # what optimise() falls back to when fp32 Psi2 is no longer accurate enough: fp64 forward
+                # and dense adjoints, streaming stage B on the matrix pipe
+                tw = model.fp64_twin()
+                for _ in range(2):
+                    tw.gradients()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    tw.gradients()
+                torch.cuda.synchronize()
+                res['objective_and_gradients']['fp64_forward_matrix_pipe_stage_b_ms'] = 1e3 * (time.perf_counter() - t0) / 5
             if a.prec in ('mixed', 'f64'):
                 from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
                 model_t = dp_gp_lvm_t(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=p['phi'].shape[1],
