@@ -146,7 +146,8 @@ int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, cons
 /* Backward pass of the fused ELBO, stage A (first version; reference: tf.gradients(objective) as used by every training
  * script, test/synthetic_data_hard_test.py:143-155; the forward it differentiates: src/models/dp_gp_lvm.py:108-145).
  * Adjoints of the per-output dense algebra, computed from the workspace `ws` of a FINISHED dpgp_elbo_fhat[_ex] call with
- * the same D, N, M, Q, prec (prec = DPGP_PREC_MIXED or DPGP_PREC_F64; M <= 128).  Mp = 16 * ceil(M / 16).
+ * the same D, N, M, Q, prec (prec = DPGP_PREC_MIXED or DPGP_PREC_F64; M <= 128: B_d is kept in LDS; -30 otherwise — for larger
+ * M the host side composes this stage from dpgp_potrf_batched / dpgp_trsm_batched and plain GEMMs, ops.py).  Mp = 16 * ceil(M / 16).
  *   g_psi2[D][Mp][Mp]  d f_hat / d Psi2_d   (lower triangle j <= i valid, symmetric)
  *   w_kuu [D][Mp][Mp]  (d f_hat / d K_uu,d) .* (K_uu,d - jitter I)   (lower triangle)
  *   g_v   [D][Mp]      d f_hat / d (Psi1_d^T y_d)
@@ -156,11 +157,15 @@ int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *alpha, const 
                          void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v, double *d_alpha_beta,
                          int *info, void *stream);
 
-/* Backward pass, stage B (first version): second streaming pass over the observations — the derivatives of
+/* Backward pass, stage B: second streaming pass over the observations — the derivatives of
  * <g_psi2, Psi2> + <g_v, Psi1^T y> + <d f_hat / d K_uu, K_uu> (reference forward: src/kernels/rbf_kernel.py:58-199) with
  * respect to mu[N,Q], the diagonal q(X) variances s[N,Q], z[M,Q] and gamma[D,Q], given the stage-A adjoints.  alpha is a
- * constant factor here (its derivative is complete in d_alpha_beta of stage A).  prec = DPGP_PREC_MIXED (fp32
- * arithmetic, fp64 reductions) or DPGP_PREC_F64; M <= 128.  ws: dpgp_elbo_grad_psi_workspace_bytes(D,N,M,Q).                */
+ * constant factor here (its derivative is complete in d_alpha_beta of stage A).
+ *   DPGP_PREC_MIXED: fp32 arithmetic, fp64 sums of the per-workgroup partial results, any M: the Psi2 term on the matrix pipe
+ *     (psi2_grad_kernel: the forward's f16-split exponent tiles, a second MFMA product for the z-weighted column sums), the
+ *     Psi1 term by two reduction-free kernels, the K_uu term without a pass over the observations;
+ *   DPGP_PREC_F64: one plain kernel, M <= 128 (-30 otherwise).
+ * M may exceed N (prediction evaluates few test points).  ws: dpgp_elbo_grad_psi_workspace_bytes(D,N,M,Q).                   */
 size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q);
 int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                        const double *s, const double *gamma, const double *alpha, const double *g_psi2,
@@ -170,9 +175,9 @@ int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, con
  * g_v[d][a] y[n][d]: then y and g_v may be NULL.  Mixed precision only.  (The over-T model, reference dp_gp_lvm.py:513-676,
  * couples every atom with all columns of y.) */
 int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
-                       const double *s, const double *gamma, const double *alpha, const double *g_psi2,
-                       const double *w_kuu, const double *g_v, const double *g_psi1, int prec, void *ws, size_t ws_bytes, double *d_mu,
-                       double *d_s, double *d_z, double *d_gamma, void *stream);
+                          const double *s, const double *gamma, const double *alpha, const double *g_psi2,
+                          const double *w_kuu, const double *g_v, const double *g_psi1, int prec, void *ws,
+                          size_t ws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream);
 
 /* hipEvent helpers for hosts without their own HIP binding */
 void *dpgp_event_create(void);
