@@ -655,6 +655,28 @@ def dp_gp_lvm_t(y_train,
             out = _objective_of(raw_vars)
         return out, last_info[0]
 
+    graph = {}
+
+    def _objective_terms_graph():
+        """The same evaluation replayed from a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm): this composed objective
+        is ~200 small launches, i.e. launch-bound; capturing them once removes the per-launch host cost.  The raw variables
+        are read in place, so updates by an optimiser are seen by the replay."""
+        if 'g' not in graph:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    evaluate()
+            cur.wait_stream(side)
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                with torch.no_grad():
+                    graph['out'] = _objective_of(raw_vars)
+            graph['g'] = g_
+        graph['g'].replay()
+        return graph['out'].clone()
+
     def _gradients():
         """d objective / d raw variable for all raw variables: torch autograd around the library-backed f_hat (above)."""
         leaves = {k: v.detach().clone().requires_grad_(True) for k, v in raw_vars.items()}
@@ -715,6 +737,7 @@ def dp_gp_lvm_t(y_train,
         def cholesky_info(self):
             return evaluate()[1]
 
+        objective_terms_graph = staticmethod(_objective_terms_graph)
         gradients = staticmethod(_gradients)
         optimise = staticmethod(_optimise)
 

@@ -1,0 +1,24 @@
+# scratch: over-T objective, eager launches vs HIP-graph replay
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+from dp_gp_lvm_amd.utils.synthetic import make_problem, CONFIGS
+cfg = 3
+n, d, m, q = CONFIGS[cfg]
+p = make_problem(cfg)
+mdl = dp_gp_lvm_t(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=p['phi'].shape[1],
+                  alpha_prior_params=np.array([p['s1'], p['s2']]), device=torch.device('cuda', 0), precision='mixed',
+                  initial_values=dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']),
+                                      gamma_atoms=p['gamma_atoms'], alpha_atoms=p['alpha_atoms'], beta_atoms=p['beta_atoms'],
+                                      gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'], w_2=p['w2']))
+a = mdl.objective_terms.cpu().numpy()
+b = mdl.objective_terms_graph().cpu().numpy()
+print('eager', a, '\ngraph', b, '\nmax rel diff', np.abs(a - b).max() / np.abs(a).max())
+for name, fn in (('eager', lambda: mdl.objective_terms), ('graph replay', mdl.objective_terms_graph)):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(30): fn()
+    torch.cuda.synchronize(); print('%-13s %.3f ms' % (name, (time.perf_counter() - t0) / 30 * 1e3))
+mdl.raw['x_mean'].add_(0.01)
+print('after an in-place update: eager %.6f graph %.6f' % (float(mdl.objective), float(mdl.objective_terms_graph()[0])))

@@ -64,6 +64,12 @@ def test_accessors_and_shapes(dev):
     assert model.kernel.covariance_matrix(model.inducing_input, None).shape == (4, 10, 10)
     with pytest.raises(AssertionError):
         dp_gp_lvm_t(y, num_latent_dims=9, num_inducing_points=10, truncation_level=4, device=dev)
+    # the same evaluation replayed from a HIP graph; it reads the variables in place
+    g1 = model.objective_terms_graph()
+    np.testing.assert_allclose(g1.cpu().numpy(), terms.cpu().numpy(), rtol=1e-12)
+    model.raw['x_mean'].add_(0.05)
+    np.testing.assert_allclose(model.objective_terms_graph().cpu().numpy(), model.objective_terms.cpu().numpy(), rtol=1e-12)
+    assert abs(float(model.objective_terms_graph()[0]) - float(g1[0])) > 1e-6
 
 
 REF2RAW = dict(x_mean='x_mean', x_var_raw='x_var', x_u='x_u', dp_logits='dp_logits', gamma_1_raw='dp_gamma_1',
