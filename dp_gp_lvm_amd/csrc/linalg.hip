@@ -359,23 +359,28 @@ __global__ __launch_bounds__(256, 2) void potrf_batched_lds_kernel(int M, int Mp
     if (t == 0) info[b] = fail;
 }
 
+// The right-hand sides are independent column by column: workgroup = (batch element, chunk of TRSM_KC columns), so that a
+// few matrices with many right-hand sides (the over-T model: T = 8 matrices, D = 512 columns; stage A of the backward pass
+// for M > 128: the identity) still fill the GPU.  K = leading dimension of rhs, kc0 .. kc0 + kw = this chunk.
+#define TRSM_KC 64
 template <typename T>
-__global__ __launch_bounds__(256) void trsm_batched_kernel(int M, int K, int Mp, int Kp, const T *__restrict__ l,
+__global__ __launch_bounds__(256) void trsm_batched_kernel(int M, int K, int Mp, int Kcp, int nchunk, const T *__restrict__ l,
                                                            T *__restrict__ rhs, T *__restrict__ ws, int plain) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *lds = reinterpret_cast<T *>(smem_raw + LA_LDS_HDR);
-    const int b = blockIdx.x, t = threadIdx.x, nb = Mp / 16;
+    const int b = blockIdx.x / nchunk, ch = blockIdx.x - b * nchunk, t = threadIdx.x, nb = Mp / 16;
+    const int kc0 = ch * TRSM_KC, kw = min(nchunk == 1 ? K : TRSM_KC, K - kc0), Kp = 16 * ((kw + 15) / 16);
     const T *Lg = l + (size_t)b * M * M;
-    T *R = rhs + (size_t)b * M * K;
-    T *Lw = ws + (size_t)b * ((size_t)Mp * Mp + (size_t)Mp * Kp + (size_t)nb * 256), *Rw = Lw + (size_t)Mp * Mp,
-      *dinv = Rw + (size_t)Mp * Kp;
+    T *R = rhs + (size_t)b * M * K + kc0;
+    T *Lw = ws + (size_t)blockIdx.x * ((size_t)Mp * Mp + (size_t)Mp * Kcp + (size_t)nb * 256), *Rw = Lw + (size_t)Mp * Mp,
+      *dinv = Rw + (size_t)Mp * Kcp;
     for (int e = t; e < Mp * Mp; e += 256) {
         const int i = e / Mp, j = e - i * Mp;
         Lw[e] = (i < M && j < M) ? ((j <= i) ? Lg[(size_t)i * M + j] : (T)0) : ((i == j) ? (T)1 : (T)0);
     }
     for (int e = t; e < Mp * Kp; e += 256) {
         const int i = e / Kp, j = e - i * Kp;
-        Rw[e] = (i < M && j < K) ? R[(size_t)i * K + j] : (T)0;
+        Rw[e] = (i < M && j < kw) ? R[(size_t)i * K + j] : (T)0;
     }
     __syncthreads();
     if (plain) {
@@ -389,9 +394,9 @@ __global__ __launch_bounds__(256) void trsm_batched_kernel(int M, int K, int Mp,
         trsm_left_blocked<T>(Lw, Mp, dinv, Rw, Kp, nb, Kp / 16, lds);
     }
     __syncthreads();
-    for (int e = t; e < M * K; e += 256) {
-        const int i = e / K, j = e - i * K;
-        R[e] = Rw[(size_t)i * Kp + j];
+    for (int e = t; e < M * kw; e += 256) {
+        const int i = e / kw, j = e - i * kw;
+        R[(size_t)i * K + j] = Rw[(size_t)i * Kp + j];
     }
 }
 
@@ -404,8 +409,9 @@ extern "C" size_t dpgp_potrf_workspace_bytes(int B, int M, int elem_size) {
 }
 extern "C" size_t dpgp_trsm_workspace_bytes(int B, int M, int K, int elem_size) {
     if (B <= 0 || M <= 0 || K <= 0) return 0;
-    const int Mp = dpgp_round_up(M, 16), Kp = dpgp_round_up(K, 16);
-    return dpgp_align256((size_t)elem_size * B * ((size_t)Mp * Mp + (size_t)Mp * Kp + (size_t)(Mp / 16) * 256));
+    const int Mp = dpgp_round_up(M, 16);
+    const int nchunk = K > TRSM_KC ? dpgp_ceil_div(K, TRSM_KC) : 1, Kcp = nchunk == 1 ? dpgp_round_up(K, 16) : TRSM_KC;
+    return dpgp_align256((size_t)elem_size * B * nchunk * ((size_t)Mp * Mp + (size_t)Mp * Kcp + (size_t)(Mp / 16) * 256));
 }
 
 template <typename T>
@@ -460,8 +466,9 @@ static int trsm_api(int B, int M, int K, const T *l, T *rhs, void *ws, size_t ws
     if (!ws) return -6;
     if (ws_bytes < dpgp_trsm_workspace_bytes(B, M, K, sizeof(T))) return -7;
     if (algo < 0 || algo > DPGP_ALGO_MFMA_F32) return -8;
-    const int Mp = dpgp_round_up(M, 16), Kp = dpgp_round_up(K, 16);
-    size_t tiles = (size_t)(Kp / 16 + 1);
+    const int Mp = dpgp_round_up(M, 16);
+    const int nchunk = K > TRSM_KC ? dpgp_ceil_div(K, TRSM_KC) : 1, Kcp = nchunk == 1 ? dpgp_round_up(K, 16) : TRSM_KC;
+    size_t tiles = (size_t)(Kcp / 16 + 1);
     if (tiles < 4) tiles = 4;   // the diagonal-tile inversion uses one dinv slot per wave
     size_t lds = LA_LDS_HDR + sizeof(T) * (size_t)(16 * LDT) * tiles;
     auto kern = trsm_batched_kernel<T>;
@@ -469,8 +476,8 @@ static int trsm_api(int B, int M, int K, const T *l, T *rhs, void *ws, size_t ws
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
         return DPGP_ERR_LAUNCH;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, M, K, Mp, Kp, l, rhs, (T *)ws,
-                       algo == DPGP_ALGO_PLAIN ? 1 : 0);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * nchunk)), dim3(256), lds, (hipStream_t)stream, M, K, Mp, Kcp,
+                       nchunk, l, rhs, (T *)ws, algo == DPGP_ALGO_PLAIN ? 1 : 0);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }

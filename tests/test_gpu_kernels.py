@@ -130,6 +130,20 @@ def test_potrf_trsm(dev, m, dt, algo):
     close(x, x_ref, tol, 'trsm')
 
 
+@pytest.mark.parametrize('shape', [(2, 40, 65), (3, 100, 150), (1, 130, 512), (2, 16, 64)])
+def test_trsm_many_right_hand_sides(dev, shape):
+    """More than 64 right-hand sides: one workgroup per (matrix, chunk of 64 columns)."""
+    b, m, k = shape
+    rng = np.random.default_rng(m + k)
+    a = rng.standard_normal((b, m, m + 3))
+    a = a @ a.transpose(0, 2, 1) + 0.5 * m * np.eye(m)
+    l_ref = np.linalg.cholesky(a)
+    rhs = rng.standard_normal((b, m, k))
+    x = ops.trsm_batched(T(l_ref, torch.float64, dev), T(rhs, torch.float64, dev))
+    x_ref = np.stack([np.linalg.solve(l_ref[i], rhs[i]) for i in range(b)])
+    close(x, x_ref, dict(rtol=1e-10, atol_rel=1e-12), 'trsm')
+
+
 @pytest.mark.parametrize('m', [200, 256, 300, 512])
 @pytest.mark.parametrize('dt', [torch.float64, torch.float32])
 def test_potrf_large_multi_workgroup(dev, m, dt):
