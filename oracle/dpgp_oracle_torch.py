@@ -247,3 +247,32 @@ def objective_t_and_gradients(y, raw_values, s_1=1.0, s_2=1.0, mask_size=1, jitt
     out = {k: (np.zeros_like(np.asarray(raw_values[k], dtype=np.float64)) if g is None else g.numpy().copy())
            for k, g in zip(NAMES, grads)}
     return float(obj), out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Bayesian GP-LVM (reference gaussian_process.py:132-270): one kernel for all output dims = the over-T f_hat with a single
+# atom and phi = 1; objective = -(f_hat - KL + log-normal hyper-prior of gamma, alpha, beta).  Pinned by
+# oracle/gen_golden_bgplvm.py against the reference's own constructor (objective 1e-11, gradients 1e-7).
+# --------------------------------------------------------------------------------------------------------------------
+BGPLVM_NAMES = ['gamma_raw', 'alpha_raw', 'beta_raw', 'x_mean', 'x_u', 'x_var_raw']
+
+
+def objective_bgplvm(y, raw, jitter=GP_DEFAULT_JITTER):
+    mu, z = raw['x_mean'], raw['x_u']
+    s = _softplus(raw['x_var_raw'])
+    gam, al, be = _softplus(raw['gamma_raw']), _softplus(raw['alpha_raw']), _softplus(raw['beta_raw'])
+    phi = torch.ones((y.shape[1], 1), dtype=y.dtype)
+    f = fhat_t(y, z, mu, s, phi, gam, al[:, 0], be[:, 0], jitter=jitter)
+    kl = 0.5 * (torch.sum(mu * mu) + torch.sum(s - torch.log(s)) - mu.shape[0] * mu.shape[1])
+    hyper = sum(torch.sum(_log_normal_log_pdf(a)) for a in (gam, al, be))
+    return -(f - kl + hyper)
+
+
+def objective_bgplvm_and_gradients(y, raw_values, jitter=GP_DEFAULT_JITTER):
+    yt = torch.as_tensor(np.asarray(y), dtype=torch.float64)
+    raw = {k: torch.tensor(np.asarray(raw_values[k], dtype=np.float64), dtype=torch.float64, requires_grad=True)
+           for k in BGPLVM_NAMES}
+    obj = objective_bgplvm(yt, raw, jitter=jitter)
+    grads = torch.autograd.grad(obj, [raw[k] for k in BGPLVM_NAMES], allow_unused=True)
+    return float(obj), {k: (np.zeros_like(np.asarray(raw_values[k], dtype=np.float64)) if g is None else g.numpy().copy())
+                        for k, g in zip(BGPLVM_NAMES, grads)}

@@ -90,3 +90,18 @@ def test_torch_oracle_reproduces_the_over_t_reference(path):
     o_d2, _ = ot.objective_and_gradients(g['y'], {k: g[k] for k in ot.NAMES}, s_1=float(g['s_1']), s_2=float(g['s_2']))
     np.testing.assert_allclose(o_d2, float(g['objective_over_d']), rtol=1e-10)
     assert abs(o_d2 - obj) > 1e-3
+
+
+# ---- Bayesian GP-LVM: fixtures from the reference's own bayesian_gp_lvm (oracle/gen_golden_bgplvm.py) ----
+FIXTURES_B = sorted(glob.glob(os.path.join(GOLDEN, 'bgplvm_ref_*.npz')))
+
+
+@pytest.mark.parametrize('path', FIXTURES_B, ids=[os.path.basename(p) for p in FIXTURES_B])
+def test_torch_oracle_reproduces_the_bgplvm_reference(path):
+    g = np.load(path)
+    obj, grads = ot.objective_bgplvm_and_gradients(g['y'], {k: g[k] for k in ot.BGPLVM_NAMES})
+    np.testing.assert_allclose(obj, float(g['objective']), rtol=1e-11)
+    for k in ot.BGPLVM_NAMES:
+        ref = g['grad_' + k]
+        np.testing.assert_allclose(grads[k], ref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=k)
+    assert len(FIXTURES_B) >= 2
