@@ -815,7 +815,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
                         vx = (float)(-0.5 * DPGP_LOG2E) * w;
                         a = (float)(-0.25 * DPGP_LOG2E) * w;
                         bb = (float)DPGP_LOG2E * w * mc;
-                        cc = (float)(-DPGP_LOG2E) * (0.5f * w * mc * mc + 0.25f * dpgp_log(den));
+                        cc = (float)(-0.5 * DPGP_LOG2E) * w * mc * mc - 0.25f * __builtin_amdgcn_logf(den);   // (v_log_f32 = log2, den >= 1)
                     }
                     const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
                     const _Float16 bhh = (_Float16)bb, bll = (_Float16)(bb - (float)bhh);
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
                         vx = (float)(-0.5 * DPGP_LOG2E) * w;
                         a = (float)(-0.25 * DPGP_LOG2E) * w;
                         bb = (float)DPGP_LOG2E * w * mc;
-                        cc = (float)(-DPGP_LOG2E) * (0.5f * w * mc * mc + 0.25f * dpgp_log(den));
+                        cc = (float)(-0.5 * DPGP_LOG2E) * w * mc * mc - 0.25f * __builtin_amdgcn_logf(den);   // (v_log_f32 = log2, den >= 1)
                     }
                     const _Float16 ah = (_Float16)a, al_ = (_Float16)(a - (float)ah);
                     const _Float16 bhh = (_Float16)bb, bll = (_Float16)(bb - (float)bhh);
