@@ -10,7 +10,7 @@
 #include "internal.h"
 
 struct ElboLayout {
-    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, off_kl, off_pc, total;
+    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, off_kl, off_pc, off_guard, total;
     int ns1, ns2, Mp;
 };
 
@@ -25,6 +25,7 @@ static ElboLayout elbo_layout(int D, int N, int M, int Q, int prec) {
     L.off_ld = o; o += dpgp_align256(sizeof(double) * D);
     L.off_ik = o; o += dpgp_align256(sizeof(int) * D);
     L.off_kl = o; o += dpgp_align256(sizeof(double) * DPGP_KL_NBLK);
+    L.off_guard = o; o += dpgp_align256(sizeof(double) * D);
     L.off_pc = o; o += dpgp_align256(psi2_consts_bytes(M, Q));
     L.off_v = o;  o += dpgp_align256(sizeof(double) * (size_t)L.ns1 * D * M);
     L.off_p2 = o; o += dpgp_align256(sp * (size_t)L.ns2 * D * L.Mp * L.Mp);
@@ -39,15 +40,16 @@ extern "C" size_t dpgp_elbo_workspace_bytes(int D, int N, int M, int Q, int prec
 }
 
 // Where a finished dpgp_elbo_fhat call left its streaming results inside `ws` (for stage A of the backward pass composed on
-// the host side when M > 128): out[8] = { byte offset of the Psi2 partial slabs [ns2][D][Mp][Mp] (lower patches), ns2, their
+// the host side when M > 128): out[10] = { byte offset of the Psi2 partial slabs [ns2][D][Mp][Mp] (lower patches), ns2, their
 // element size (4 or 8), Mp, byte offset of the Psi1^T y partial slabs [ns1][D][M] (fp64), ns1, byte offset of the y^T y
-// partial slabs [nyy][D] (fp64), nyy }
+// partial slabs [nyy][D] (fp64), nyy, byte offset of the conditioning guard values guard[D] (fp64; see dpgp.h), D }
 extern "C" int dpgp_elbo_workspace_layout(int D, int N, int M, int Q, int prec, size_t *out) {
     if (D <= 0 || N <= 0 || M <= 0 || Q <= 0 || prec < 0 || prec > 2) return -1;
     if (!out) return -6;
     const ElboLayout L = elbo_layout(D, N, M, Q, prec);
     out[0] = L.off_p2; out[1] = (size_t)L.ns2; out[2] = (prec == DPGP_PREC_F64) ? 8 : 4; out[3] = (size_t)L.Mp;
     out[4] = L.off_v;  out[5] = (size_t)L.ns1; out[6] = L.off_yy; out[7] = DPGP_YY_NCH;
+    out[8] = L.off_guard; out[9] = (size_t)D;
     return DPGP_OK;
 }
 
@@ -86,8 +88,8 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
                                               fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst, 1)))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
-    if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info, la, algo,
-                                     st)))
+    if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
+                                     reinterpret_cast<double *>(ws + L.off_guard), la, algo, st)))
         return rc;
     // f_hat and KL; with the model-level pointers of exec also the packed pair / the finished objective, in the same launch
     return launch_sum_terms(D, terms, klp, sums, ex ? (const double *)ex->model_scal : nullptr,

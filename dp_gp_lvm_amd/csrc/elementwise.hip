@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
         pf_y = (lane < 16 && n0 + lane < nend) ? y[(size_t)(n0 + lane) * ldy + b] : (TIN)0;
     };
     prefetch(nbeg + 16 * wv);
+    bool oor = false;
     for (int n0 = nbeg + 16 * wv; n0 < nend; n0 += 64) {
         // ---- n-side image of rows n0 .. n0+15 ----
 #pragma unroll
@@ -383,7 +384,9 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
                 const p1_f4 v = *reinterpret_cast<const p1_f4 *>(cq + lane * QPC + 4 * q4);
                 c += (v[0] + v[1]) + (v[2] + v[3]);
             }
-            c = fmaxf((float)(-0.5 * DPGP_LOG2E) * c, -60000.0f);
+            c = (float)(-0.5 * DPGP_LOG2E) * c;
+            oor |= !(c >= -60000.0f);                       // f16 range guard (as in psi2_patch_f16p): the result becomes NaN
+            c = fmaxf(c, -60000.0f);
             const _Float16 ch = (_Float16)c;
             const p1_h2 cw = {ch, (_Float16)(c - (float)ch)};
             *reinterpret_cast<unsigned *>(am + lane * SL + 6 * Q) = __builtin_bit_cast(unsigned, cw);
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next tile overwrites the image just read
     }
     // ---- sum the 4 row groups of each wave and the 4 waves ----
-    __syncthreads();                                        // cq aliases red
+    const bool any_oor = __syncthreads_or(oor ? 1 : 0) != 0;   // (also the barrier cq -> red needs: cq aliases red)
 #pragma unroll
     for (int J = 0; J < 8; ++J) red[wv * 4 + kk][16 * J + li] = acc[J];
     __syncthreads();
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
         double v = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += (double)red[k][t];
-        part[((size_t)sp * B + b) * M + mc + t] = (double)alpha[b] * v;
+        part[((size_t)sp * B + b) * M + mc + t] = any_oor ? (double)__builtin_nanf("") : (double)alpha[b] * v;
     }
 }
 
@@ -705,4 +708,4 @@ extern "C" int dpgp_kl_qx_f32(int N, int Q, const float *mu, const float *s, dou
 extern "C" int dpgp_kl_qx_f64(int N, int Q, const double *mu, const double *s, double *out, void *stream) {
     return kl_api_launch(N, Q, nullptr, nullptr, mu, s, out, stream);
 }
-extern "C" int dpgp_version(void) { return 100; }
+extern "C" int dpgp_version(void) { return 200; }

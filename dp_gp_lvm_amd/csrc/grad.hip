@@ -833,7 +833,11 @@ size_t psi_grad_ws_bytes(int D, int N, int M, int Q, int *nsplit_out) {
     if (ns > dpgp_ceil_div(N, 32)) ns = dpgp_ceil_div(N, 32);
     if (ns < 1) ns = 1;
     if (nsplit_out) *nsplit_out = ns;
-    return sizeof(double) * ((size_t)2 * D * N * Q + (size_t)D * ns * M * Q + (size_t)ns * D * Q);
+    const size_t rows = (size_t)2 * D * N * Q + (size_t)D * ns * M * Q + (size_t)ns * D * Q;
+    // the K_uu term of the M > 128 path (launch_kuu_grad, elbo.hip) puts D M Q + ceil(M / 64) D Q doubles into the same
+    // region; M > N is legal there (prediction evaluates few test points)
+    const size_t kuu = (size_t)D * M * Q + (size_t)dpgp_ceil_div(M, 64) * D * Q;
+    return sizeof(double) * (rows > kuu ? rows : kuu);
 }
 
 template <typename TC>

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
                                                       const double *__restrict__ yy_part,
                                                       const double *__restrict__ logdet_k,
                                                       const int *__restrict__ info_k, double *__restrict__ terms,
-                                                      int *__restrict__ info, TL *__restrict__ ws, size_t ws_stride,
-                                                      int mode) {
+                                                      int *__restrict__ info, double *__restrict__ guard,
+                                                      TL *__restrict__ ws, size_t ws_stride, int mode) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *scratch = reinterpret_cast<double *>(smem_raw);
     int &fail = *reinterpret_cast<int *>(smem_raw + 64);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
     STAMP(0);
     // ---- assemble B = K + beta Psi2 (lower) with the border row v^T; <K^-1, Psi2>_F on the fly ----
     const TL be = (TL)beta[d];
-    double ip = 0.0;
+    double ip = 0.0, kin2 = 0.0, p2n2 = 0.0;     // <K^-1, Psi2>, |K^-1|_F^2, |Psi2|_F^2 (the last two: conditioning guard)
     const int ii = t >> 4, jj = t & 15;
     const int nlow = nb * (nb + 1) / 2;
     {
@@ -122,7 +122,10 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
                     TL bv;
                     if (je <= i && i < M) {            // inside the real lower triangle
                         bv = k0[e] + be * (TL)p2[e];
-                        ip += (double)ki[e] * p2[e] * (i == je ? 1.0 : 2.0);
+                        const double wt = (i == je ? 1.0 : 2.0);
+                        ip += (double)ki[e] * p2[e] * wt;
+                        kin2 += (double)ki[e] * (double)ki[e] * wt;
+                        p2n2 += p2[e] * p2[e] * wt;
                     } else {
                         bv = (i == je) ? (TL)1 : (TL)0;   // identity padding (and don't-care zeros above the diagonal)
                     }
@@ -154,6 +157,8 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
         }
     }
     ip = block_sum(ip, scratch);
+    kin2 = block_sum(kin2, scratch);
+    p2n2 = block_sum(p2n2, scratch);
     __syncthreads();
     STAMP(1);
     // ---- L_B = chol(B), border -> L_B^-1 v ----
@@ -184,8 +189,20 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
         const double b_ = beta[d], a_ = alpha[d];
         double *o = terms + (size_t)d * 5;
         const int fk = info_k[d];
-        const int f = fk ? fk : (fail ? M + fail : 0);
+        int f = fk ? fk : (fail ? M + fail : 0);
+        // Conditioning guard.  Psi2 computed in fp32 carries a relative rounding error eps = 2^-23 (Frobenius norm); through
+        // B = K + beta Psi2 it moves  -log det L_A + beta/2 <K^-1, Psi2>  by at most  beta |K^-1|_F eps |Psi2|_F  and
+        // beta^2/2 v^T B^-1 v  by at most  beta^3/2 |K^-1| eps |Psi2| v^T B^-1 v   (B >= K, so |B^-1| <= |K^-1|).  The bound is
+        // written to guard[d] in every precision mode; with an fp32 Psi2 (TP = float) an output dim whose bound exceeds
+        // DPGP_GUARD_REL * N is reported as info = DPGP_INFO_ILL_CONDITIONED: its terms are still written, but they can no
+        // longer be trusted to the mixed-precision tolerance — evaluate with DPGP_PREC_F64.  (Entries are uncorrelated
+        // rounding errors, so the typical deviation is ~1/M of the bound.)
+        const double errb = 1.1920928955078125e-07 * b_ * sqrt(kin2 * p2n2) * (1.0 + 0.5 * b_ * b_ * cc);
+        if (guard) guard[d] = errb;
+        if (sizeof(TP) == 4 && !f && !(errb <= DPGP_GUARD_REL * (double)N)) f = DPGP_INFO_ILL_CONDITIONED;
+        const bool flagged_only = (f == DPGP_INFO_ILL_CONDITIONED);
         info[d] = f;
+        if (flagged_only) f = 0;                               // the terms below stay numbers
         const double nan_ = __longlong_as_double(0x7ff8000000000000LL);
         o[0] = 0.5 * N * (log(b_) - DPGP_LOG_2PI);
         o[1] = f ? nan_ : -(ld - logdet_k[d]);                 // -sum log diag L_A
@@ -220,7 +237,7 @@ template int launch_chain_k<double>(int, int, double *, double *, int *, int, hi
 template <typename TP, typename TL>
 int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1,
                    const double *alpha, const double *beta, const double *yy_part, const double *logdet_k,
-                   const int *info_k, double *terms, int *info, TL *ws, int algo, hipStream_t st) {
+                   const int *info_k, double *terms, int *info, double *guard, TL *ws, int algo, hipStream_t st) {
     const int Mp = dpgp_round_up(M, 16);
     int mode = 2;
     size_t lds = la_lds_bytes(Mp, sizeof(TL));
@@ -236,7 +253,7 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
             hipSuccess)
         return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(D), dim3(256), lds, st, D, N, M, Mp, psi2_part, ns2, v_part, ns1, alpha, beta, yy_part,
-                       logdet_k, info_k, terms, info, ws, la_chain_ws_elems(M), mode);
+                       logdet_k, info_k, terms, info, guard, ws, la_chain_ws_elems(M), mode);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -253,7 +270,7 @@ extern "C" int dpgp_debug_chain_b_occupancy(int Mp, int extra) {
 #define INST_CHAIN_B(TP, TL)                                                                                        \
     template int launch_chain_b<TP, TL>(int, int, int, const TP *, int, const double *, int, const double *,      \
                                         const double *, const double *, const double *, const int *, double *, int *, \
-                                        TL *, int, hipStream_t);
+                                        double *, TL *, int, hipStream_t);
 INST_CHAIN_B(float, float)
 INST_CHAIN_B(float, double)
 INST_CHAIN_B(double, double)

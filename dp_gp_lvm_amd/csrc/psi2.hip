@@ -101,7 +101,9 @@ template <typename T, int KS, int PT> struct Psi2Lds {
     static constexpr int OFF_W = 2 * PS * ZLD + 2 * (DPGP_MAX_Q + 2);      // start of the per-wave regions
     static constexpr int FILL = OFF_W + 4 * WSZ;
     static constexpr int RED = 2 * PS * ZLD + 2 * (DPGP_MAX_Q + 2) + 4 * PT * 4 * 64;
-    static constexpr int ELEMS = FILL > RED ? FILL : RED;
+    static constexpr int ELEMS0 = FILL > RED ? FILL : RED;
+    static constexpr int OFF_TAB = (ELEMS0 + 3) & ~3;        // exp2 table of the fp64 kernel (dpgp_exp2_tab), 16-B aligned
+    static constexpr int ELEMS = OFF_TAB + (sizeof(T) == 8 ? DPGP_EXP2_TAB_ELEMS : 0);
 };
 
 // DIAG is a compile-time property of the patch (pi == pj: only tiles J <= I are computed) so that the MFMA / exp
@@ -136,6 +138,8 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
 
     // ---- prologue (workgroup-wide): gamma_b, z column means, centred z rows of both blocks -----------------------
     if (t < Q) gq[t] = (T)gamma[(size_t)b * Q + t];
+    const double *etab = reinterpret_cast<const double *>(zs + G::OFF_TAB);       // fp64 only (the fp32 exp2 is v_exp_f32)
+    if (sizeof(T) == 8) dpgp_exp2_tab_init(reinterpret_cast<double *>(zs + G::OFF_TAB));
     block_column_means(z, M, Q, zc, reinterpret_cast<double *>(zs + G::OFF_W));   // scratch: the (not yet used) wave regions
     for (int e = t; e < 2 * PS * ZLD; e += 256) {
         int r = e / ZLD, k = e - r * ZLD;
@@ -274,7 +278,7 @@ __device__ __forceinline__ void psi2_patch(int N, int M, int Q, int B, const TIN
                 for (int J = 0; J < PT; ++J)
                     if (!(DIAG && J > I)) {
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) acc[I][J][v] += dpgp_exp2(c[J][v]);
+                        for (int v = 0; v < 4; ++v) acc[I][J][v] += dpgp_exp2_hot(c[J][v], etab);
                     }
             }
         }
@@ -777,6 +781,11 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[I][J][v] = 0.0f;
 
+    // f16 range guard: P[n,m] (and the row constant c'_n) are clamped to +-30000 so that their (hi, lo) f16 words exist;
+    // a clamped value of a real row makes the exponent tiles wrong (the large terms of P[n,m] + P[n,m'] + cross term cancel).
+    // The clamp is DETECTED and the whole patch of this workgroup comes out as NaN: never a silently wrong Psi2.  Reached
+    // when |z - c| or |mu - c| is ~90 length scales or more; DPGP_ALGO_MFMA_F32 / fp64 have no such limit.
+    bool oor = false;
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
     constexpr int NPA = (NR * XLD + 63) / 64;
     // q(X) rows of the next chunk stay in flight in registers during this chunk.  Raw input type: a conversion here would
@@ -848,6 +857,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(cq + lane * G::KQ + 4 * q4);
                 c += (v[0] + v[1]) + (v[2] + v[3]);
             }
+            oor |= !(c >= -30000.0f);              // f16 range guard: see the epilogue
             c = fmaxf(c, -30000.0f);
             const _Float16 ch = (_Float16)c;
             const dpgp_h2 cw = {ch, (_Float16)(c - (float)ch)};
@@ -900,6 +910,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
 #pragma unroll
                 for (int v = 0; v < 4; v += 2) {
                     unsigned w0, w1;
+                    oor |= !(fabsf(pc[J][v]) <= 30000.0f) | !(fabsf(pc[J][v + 1]) <= 30000.0f);
                     split_pair_words(fminf(fmaxf(pc[J][v], -30000.0f), 30000.0f),
                                      fminf(fmaxf(pc[J][v + 1], -30000.0f), 30000.0f), w0, w1);
                     pw[(4 * kk + v) * PLD + 16 * J + li] = w0;
@@ -1012,7 +1023,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
 
     // ---- epilogue ----
     float *red = zs + L.off_wave;
-    const float al = (float)alpha[b];
+    const float al = __syncthreads_or(oor ? 1 : 0) ? __builtin_nanf("") : (float)alpha[b];     // range guard: NaN patch
     const float al2 = al * al;
     float *out = part + ((size_t)sp * B + b) * (size_t)Mp * Mp;
     // 32x32 result tile: register v of lane l holds (row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32)
@@ -1395,6 +1406,7 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
         igq[i] = gqr[i] > 0.0f ? 1.0f / gqr[i] : 0.0f;
     }
     const size_t slot = (size_t)b * npatch + patch;
+    bool oor = false;                                           // f16 range guard (see psi2_patch_f16p): poisons d/dgamma
 
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
     constexpr int NPA = (NR * XLD + 63) / 64;
@@ -1461,6 +1473,7 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(cq + lane * KQ + 4 * q4);
                 c += (v[0] + v[1]) + (v[2] + v[3]);
             }
+            oor |= !(c >= -30000.0f);              // f16 range guard: see the epilogue
             c = fmaxf(c, -30000.0f);
             const _Float16 ch = (_Float16)c;
             const dpgp_h2 cw = {ch, (_Float16)(c - (float)ch)};
@@ -1500,6 +1513,7 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
 #pragma unroll
                 for (int v = 0; v < 4; v += 2) {
                     unsigned w0, w1;
+                    oor |= !(fabsf(pc[J][v]) <= 30000.0f) | !(fabsf(pc[J][v + 1]) <= 30000.0f);
                     split_pair_words(fminf(fmaxf(pc[J][v], -30000.0f), 30000.0f),
                                      fminf(fmaxf(pc[J][v + 1], -30000.0f), 30000.0f), w0, w1);
                     pw[(4 * kk + v) * PLD + 16 * J + li] = w0;
@@ -1660,7 +1674,9 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
 #pragma unroll
         for (int i = 0; i < QH; ++i) red[wv * KQ + qb + i] = dgam[i];
     __syncthreads();
-    if (t < Q) dg_part[((size_t)(patch * n_splits + sp) * B + b) * Q + t] = (double)(unscale * (red[t] + red[KQ + t] + red[2 * KQ + t] + red[3 * KQ + t]));
+    const bool any_oor = __syncthreads_or(oor ? 1 : 0) != 0;
+    if (t < Q) dg_part[((size_t)(patch * n_splits + sp) * B + b) * Q + t] =
+        any_oor ? (double)__builtin_nanf("") : (double)(unscale * (red[t] + red[KQ + t] + red[2 * KQ + t] + red[3 * KQ + t]));
 }
 
 bool psi2_grad_supported(int M, int Q) { return Q <= DPGP_MAX_Q && M >= 1; }

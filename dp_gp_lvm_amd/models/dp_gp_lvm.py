@@ -53,7 +53,7 @@ def dp_gp_lvm(y_train,
     :param process_group: torch.distributed group over which the D output dims are sharded (None: single GPU).
     :param backward_precision: precision of the streaming stage (B) of the backward pass; default: `precision`.  'mixed' with
            precision='f64' = fp64 forward and dense adjoints (accurate B^-1, K^-1 however ill-conditioned K_uu is), the
-           streaming stage on the matrix pipe (gradients to ~1e-4): what optimise() falls back to.
+           streaming stage on the matrix pipe (gradients to ~1e-4): the training configuration (see optimise()).
     :param initial_values: dict of post-initialisation parameter VALUES (x_mean, x_var, x_u, phi_logits, gamma_atoms,
            alpha_atoms, beta_atoms, gamma_1, gamma_2, w_1, w_2) that replace the random/PCA initialisation — used by the
            parity tests and the benchmark, which must not depend on PCA sign conventions or NumPy's global RNG.
@@ -68,6 +68,7 @@ def dp_gp_lvm(y_train,
         'less than the number of observations.'
     assert precision in _lib.PREC, 'precision must be one of %s' % sorted(_lib.PREC)
     assert backward_precision in (None, 'mixed', 'f64'), "backward_precision must be None, 'mixed' or 'f64'"
+    assert truncation_level <= 64, 'truncation levels above 64 are not supported by the HIP model kernels (PREP_MAX_T)'
     device = default_device() if device is None else torch.device(device)
     iv = dict(initial_values or {})
 
@@ -159,6 +160,8 @@ def dp_gp_lvm(y_train,
     grad_names = ('x_mean', 'x_var', 'x_u', 'dp_logits', 'dp_gamma_1', 'dp_gamma_2', 'dp_w', 'gamma_atoms', 'alpha_atoms',
                   'beta_atoms')
 
+    grad_state = {}
+
     def _gradients(events=None):
         """d objective / d (raw trainable variables) — what tf.gradients(objective, trainable variables) gives the
         reference's optimiser (test/synthetic_data_hard_test.py:143-155).  First version of the backward pass: one forward
@@ -182,8 +185,8 @@ def dp_gp_lvm(y_train,
         sizes = [num_samples * num_latent_dims, num_samples * num_latent_dims, num_inducing_points * num_latent_dims,
                  rows * truncation_level, max(truncation_level - 1, 1), max(truncation_level - 1, 1), 2,
                  truncation_level * num_latent_dims, truncation_level, truncation_level]
-        flat = torch.zeros(sum(sizes), **f64)
-        parts = list(torch.split(flat, sizes))
+        flat = torch.zeros(sum(sizes) + 1, **f64)          # (+1: this rank's trouble flag, summed over ranks with the rest)
+        parts = list(torch.split(flat, sizes + [1]))[:-1]
         t_ = truncation_level
         _lib.check(lib.dpgp_model_backward(
             d_local, t_, num_latent_dims, num_samples, num_inducing_points, d_lo, mask_size, rows, r['logits'].data_ptr(),
@@ -192,69 +195,49 @@ def dp_gp_lvm(y_train,
             s_1, s_2, 1 if rank == 0 else 0, dmu.data_ptr(), ds.data_ptr(), dz.data_ptr(), dg.data_ptr(), dab.data_ptr(),
             *[p_.data_ptr() for p_ in parts], st), 'dpgp_model_backward')
         mark(3)
+        # trouble flag of the LOCAL output dims (a Cholesky / conditioning flag of the forward evaluation or a non-finite
+        # partial gradient), reduced with the gradients: every rank sees the same decision (optimise() branches on it)
+        flat[-1] = ((workspace.info != 0).any() | ~torch.isfinite(flat[:-1]).all()).to(TORCH_DTYPE)
         if sharded:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)      # one packed exchange (N Q x 2 + M Q + ...)
+        grad_state['flag'] = flat[-1]
         shapes = [x_mean.shape, x_var_raw.shape, x_u.shape, r['logits'].shape, r['gamma_1'].shape, r['gamma_2'].shape,
                   r['w'].shape, gamma_atoms_raw.shape, sig_var_atoms_raw.shape, beta_atoms_raw.shape]
         return {k: p_[:int(np.prod(sh))].reshape(sh) for k, p_, sh in zip(grad_names, parts, shapes)}
 
-    twin = {}
-
-    def _fp64_twin():
-        """A second model on the SAME raw variables (shared storage) that evaluates in fp64: the safety net of optimise()."""
-        if 'model' not in twin:
-            t_model = dp_gp_lvm(y_train, num_latent_dims=num_latent_dims, num_inducing_points=num_inducing_points,
-                                truncation_level=truncation_level, alpha_prior_params=alpha_prior_params, mask_size=mask_size,
-                                device=device, precision='f64', backward_precision='mixed',
-                                initial_values=dict(x_mean=x_mean.detach().cpu().numpy()))
-            mine = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw,
-                        beta_atoms=beta_atoms_raw, **{'dp_' + k: v for k, v in dp_model.raw.items()})
-            for k, v in t_model.raw.items():
-                v.data = mine[k].data                                            # same storage: updates are seen by both
-            twin['model'] = t_model
-        return twin['model']
-
-    def _optimise(num_iterations, learning_rate=0.01, callback=None, fallback_precision='f64', _force_fallback_at=()):
+    def _optimise(num_iterations, learning_rate=0.01, callback=None):
         """Adam on the raw variables with the HIP gradients (the reference: tf.train.AdamOptimizer(...).minimize(objective),
         test/synthetic_data_hard_test.py:143-155).  torch.optim.Adam only applies the update (plumbing).
-        Mixed precision carries Psi2 in fp32: once training drives K_uu towards singularity (long length scales: its small
-        eigenvalues approach the 1e-8 jitter) the fp32 rounding of Psi2 (~1e-7 N alpha^2) exceeds the small eigenvalues of
-        B = K_uu + beta Psi2, the Cholesky factorisation fails or the gradients blow up, where the reference's fp64 graph
-        still works.  Every iteration therefore checks the Cholesky flags and the gradients; a bad step
-        is recomputed by an fp64 twin of the model on the same variables (`fallback_precision='f64'`, single GPU, M <= 128),
-        and after 3 such steps the rest of the run stays in fp64.  Returns {'fallback_steps': count, 'precision': final}."""
+
+        Every iteration checks the flags of the evaluation — failed factorisation, the conditioning guard of the fp32 Psi2
+        (DPGP_INFO_ILL_CONDITIONED, include/dpgp.h), non-finite gradients — as ONE value that travels with the packed gradient
+        all-reduce, so all ranks of a sharded run take the same branch, and raises FloatingPointError (the reference's
+        tf.cholesky raises InvalidArgumentError there) instead of updating parameters with meaningless gradients.
+        precision='mixed' carries Psi2 in fp32: once training drives K_uu towards singularity (long length scales: its small
+        eigenvalues approach the 1e-8 jitter) that is no longer the reference's objective and the guard fires (DESIGN.md
+        section 5).  The training configuration that follows the reference's fp64 arithmetic all the way is
+        precision='f64', backward_precision='mixed': fp64 forward and dense adjoints, the streaming stage of the backward pass
+        on the matrix pipe.  Returns {'iterations', 'precision', 'backward_precision'}."""
         params = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, dp_logits=dp_model.raw['logits'],
                       dp_gamma_1=dp_model.raw['gamma_1'], dp_gamma_2=dp_model.raw['gamma_2'], dp_w=dp_model.raw['w'],
                       gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw, beta_atoms=beta_atoms_raw)
         opt = torch.optim.Adam(list(params.values()), lr=learning_rate)
-        can_fall_back = (precision == 'mixed' and fallback_precision == 'f64' and not sharded and world == 1 and
-                         16 * ((num_inducing_points + 15) // 16) <= 128)
-        stats = {'fallback_steps': 0, 'precision': precision}
-        use_twin = False
         for it in range(num_iterations):
-            src = _fp64_twin() if use_twin else None
-            g = src.gradients() if use_twin else _gradients()
-            info_now = (src.per_dimension_terms[1] if use_twin else workspace.info)
-            bad = (info_now != 0).any() | ~torch.stack([torch.isfinite(v).all() for v in g.values()]).all()
-            if bool(bad) or (it in _force_fallback_at and not use_twin):      # (_force_fallback_at: test hook)
-                if use_twin or not can_fall_back:
-                    raise FloatingPointError('Cholesky factorisation failed or non-finite gradient at iteration %d '
-                                             '(precision %s)' % (it, 'f64' if use_twin else precision))
-                src = _fp64_twin()
-                g = src.gradients()
-                if bool((src.per_dimension_terms[1] != 0).any()) or not all(bool(torch.isfinite(v).all()) for v in g.values()):
-                    raise FloatingPointError('Cholesky factorisation failed or non-finite gradient at iteration %d in fp64 '
-                                             'as well' % it)
-                stats['fallback_steps'] += 1
-                if stats['fallback_steps'] >= 3:
-                    use_twin, stats['precision'] = True, 'f64'
-                    twin['active'] = True                                        # .objective follows (see the accessors)
+            g = _gradients()
+            if float(grad_state['flag']) != 0.0:                                 # identical on every rank
+                raise FloatingPointError(
+                    'iteration %d: failed Cholesky factorisation, ill-conditioning flag or non-finite gradient in '
+                    'precision=%r (info codes of this rank: %s).  The fp32 psi-statistics of precision="mixed" stop being a '
+                    'substitute for the reference\'s fp64 once K_uu is nearly singular: build the model with '
+                    'precision="f64", backward_precision="mixed".'
+                    % (it, precision, sorted(set(workspace.info.unique().tolist()) - {0})))
             for k, p_ in params.items():
                 p_.grad = g[k].reshape(p_.shape).clone()
             opt.step()
             if callback is not None:
                 callback(it)
-        return stats
+        return {'iterations': num_iterations, 'precision': precision,
+                'backward_precision': backward_precision or precision}
 
     def _mixed():
         phi = dp_model.assignments                                               # [D x T], all output dims
@@ -335,19 +318,25 @@ def dp_gp_lvm(y_train,
 
         @property
         def objective(self):
-            """dp.objective - (f_hat - KL) - hyper-prior (dp_gp_lvm.py:154): 0-d fp64 device tensor.  (After optimise() has
-            moved a mixed-precision run to its fp64 twin, the twin evaluates.)"""
-            return _fp64_twin().objective if twin.get('active') else evaluate()[0].clone()
+            """dp.objective - (f_hat - KL) - hyper-prior (dp_gp_lvm.py:154): 0-d fp64 device tensor."""
+            return evaluate()[0].clone()
 
         @property
         def objective_terms(self):
             """(objective, f_hat, KL, DP objective, hyper-prior log-likelihood) of one evaluation, as a device tensor."""
-            return _fp64_twin().objective_terms if twin.get('active') else evaluate().clone()
+            return evaluate().clone()
 
         @property
         def per_dimension_terms(self):
-            """[D_local x 5] f_hat terms and the Cholesky info flags of the last evaluation."""
+            """[D_local x 5] f_hat terms and the info flags of the last evaluation (0 fine, > 0 failed factorisation,
+            DPGP_INFO_ILL_CONDITIONED = -2: fp32 Psi2 no longer trustworthy for this output dim)."""
             return workspace.terms, workspace.info
+
+        @property
+        def conditioning_guard(self):
+            """[D_local] bound on what the rounding of an fp32 Psi2 can move each output dim's f_hat terms by (last
+            evaluation; computed in every precision mode; flagged in info when > DPGP_GUARD_REL * N in mixed / f32)."""
+            return workspace.guard
 
         evaluate_ = staticmethod(evaluate)
 
@@ -360,7 +349,6 @@ def dp_gp_lvm(y_train,
 
         gradients = staticmethod(_gradients)
         optimise = staticmethod(_optimise)
-        fp64_twin = staticmethod(_fp64_twin)     # the model on the same variables evaluated in fp64 (see optimise)
 
         @property
         def prediction_terms(self):
@@ -689,6 +677,12 @@ def dp_gp_lvm_t(y_train,
         opt = torch.optim.Adam(list(raw_vars.values()), lr=learning_rate)
         for it in range(num_iterations):
             g = _gradients()
+            # potrf replaces a failing pivot by 1 and goes on: a failed factorisation would give finite, meaningless
+            # gradients.  The reference's tf.cholesky raises; so does this.
+            bad = ~torch.stack([torch.isfinite(v).all() for v in g.values()]).all() | (last_info[0] != 0)
+            if bool(bad):
+                raise FloatingPointError('iteration %d: failed Cholesky factorisation or non-finite gradient (precision=%r); '
+                                         'use precision="f64"' % (it, precision))
             for k, p_ in raw_vars.items():
                 p_.grad = g[k].reshape(p_.shape)
             opt.step()

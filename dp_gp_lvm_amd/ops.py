@@ -199,6 +199,14 @@ class ElboWorkspace:
         self.sums = torch.empty(2, dtype=torch.float64, device=device)
         self.info = torch.empty(d, dtype=torch.int32, device=device)
         self.exec = _lib.ExecResources()
+        import ctypes
+        lay = (ctypes.c_size_t * 10)()
+        _lib.check(l.dpgp_elbo_workspace_layout(d, n, m, q, _lib.PREC[prec], ctypes.cast(lay, ctypes.c_void_p)),
+                   'dpgp_elbo_workspace_layout')
+        self.layout = tuple(int(v) for v in lay)
+        # guard[d]: bound on what the rounding of an fp32 Psi2 can do to output dim d's terms (include/dpgp.h,
+        # DPGP_INFO_ILL_CONDITIONED); a view into the workspace, valid after an evaluation
+        self.guard = self.ws[self.layout[8]:self.layout[8] + 8 * d].view(torch.float64)
 
 
 def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None, events=None,
@@ -274,10 +282,7 @@ def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma):
     f64 = torch.float64
     d, n, m, q = workspace.shape
     dev = workspace.ws.device
-    lay = (ctypes.c_size_t * 8)()
-    _lib.check(_lib.lib().dpgp_elbo_workspace_layout(d, n, m, q, _lib.PREC[workspace.prec], ctypes.cast(lay, ctypes.c_void_p)),
-               'dpgp_elbo_workspace_layout')
-    off_p2, ns2, esz, mp, off_v, ns1, off_yy, nyy = (int(v) for v in lay)
+    off_p2, ns2, esz, mp, off_v, ns1, off_yy, nyy = workspace.layout[:8]
     raw = workspace.ws
     pdt = torch.float32 if esz == 4 else f64
     p2 = raw[off_p2:off_p2 + esz * ns2 * d * mp * mp].view(pdt).view(ns2, d, mp, mp).sum(dim=0, dtype=f64)[:, :m, :m]

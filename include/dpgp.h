@@ -45,6 +45,17 @@ extern "C" {
 #define DPGP_PREC_MIXED 1 /* psi-statistics fp32 (MFMA), Cholesky chain + reductions fp64      */
 #define DPGP_PREC_F64 2   /* everything fp64                                                   */
 
+/* info[] codes besides the LAPACK-style positive ones (fused ELBO only; 0 = fine):
+ *   DPGP_INFO_ILL_CONDITIONED: with an fp32 Psi2 (DPGP_PREC_MIXED / DPGP_PREC_F32) the rounding of Psi2, amplified by
+ *   K_uu^-1, may move this output dim's terms by more than DPGP_GUARD_REL * N (bound written to the workspace's guard[d],
+ *   see dpgp_elbo_workspace_layout): the terms are written but are not covered by the mixed-precision tolerance any more.
+ *   Evaluate with DPGP_PREC_F64 (the reference's arithmetic, src/utils/types.py:13-14).
+ * Operands outside the f16 range of the default fp32 psi kernels (|z - mean z| or |mu - mean z| beyond ~90 length scales)
+ * are detected in the kernels: the affected Psi2 patch / Psi1^T y slab comes out as NaN, which the fused ELBO reports as a
+ * failed factorisation (info > 0, NaN terms).  DPGP_ALGO_MFMA_F32 and fp64 have no such limit.                              */
+#define DPGP_INFO_ILL_CONDITIONED (-2)
+#define DPGP_GUARD_REL 2.0e-3
+
 int dpgp_version(void);
 /* text of the HIP error behind the last DPGP_ERR_LAUNCH returned to the calling thread (diagnostics) */
 const char *dpgp_last_hip_error(void);
@@ -117,9 +128,10 @@ int dpgp_kl_qx_f64(int N, int Q, const double *mu, const double *s, double *out,
  *                   info[D]    (see top of file)
  *   ws: dpgp_elbo_workspace_bytes(D,N,M,Q,prec).  algo: DPGP_ALGO_*.                                               */
 size_t dpgp_elbo_workspace_bytes(int D, int N, int M, int Q, int prec);
-/* where a finished dpgp_elbo_fhat call left its streaming results inside ws: out[8] = { byte offset of the Psi2 partial slabs
+/* where a finished dpgp_elbo_fhat call left its streaming results inside ws: out[10] = { byte offset of the Psi2 partial slabs
  * [ns2][D][Mp][Mp] (lower 64x64 patches; their sum over the slabs is Psi2), ns2, element size of the slabs (4 or 8), Mp,
- * byte offset of the Psi1^T y partial slabs [ns1][D][M] (fp64), ns1, byte offset of the y^T y partial slabs [nyy][D] (fp64), nyy }.
+ * byte offset of the Psi1^T y partial slabs [ns1][D][M] (fp64), ns1, byte offset of the y^T y partial slabs [nyy][D] (fp64), nyy,
+ * byte offset of guard[D] (fp64: bound on the effect of an fp32 Psi2's rounding on each output dim's terms), D }.
  * Used by the host-side composition of the backward pass's stage A for M > 128 (ops.elbo_grad_chain). */
 int dpgp_elbo_workspace_layout(int D, int N, int M, int Q, int prec, size_t *out);
 int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,

@@ -373,5 +373,5 @@ if __name__ == '__main__':
         synthetic_fixture(3, 'spot_C3', dsel=[0, 170, 341, 511])
         synthetic_fixture(5, 'spot_C5', dsel=[0, 186, 373, 559])
     if 'spot4' in only:
-        synthetic_fixture(4, 'spot_C4', dsel=[0, 255])
+        synthetic_fixture(4, 'spot_C4', dsel=[0, 85, 170, 255])
     print('done; reference unit tests passed under the stand-in: %d' % n_tests)

@@ -279,25 +279,35 @@ def test_stage_b_beyond_128_inducing_points(dev, shape):
         ops.elbo_grad_psi(t(y), t(z), t(mu), t(s), t(gamma), t(alpha), gp, wk, gv, prec='f64')
 
 
-def test_optimise_falls_back_to_fp64_on_a_bad_step(dev):
-    """optimise() checks the Cholesky flags and the gradients every iteration; a bad mixed-precision step is recomputed by an
-    fp64 twin on the same variables, after 3 such steps the run stays in fp64 (hook: _force_fallback_at)."""
+def _ill_conditioned(g, scale):
+    """The fixture's problem with the ARD weights scaled down: long length scales make the inducing points redundant and
+    K_uu nearly singular (what Adam does to the BASELINE configs after ~200 iterations)."""
+    g2 = {k: g[k] for k in g.files} if hasattr(g, 'files') else dict(g)
+    g2['gamma_atoms_raw'] = np.log(np.expm1(softplus(np.asarray(g['gamma_atoms_raw'])) * scale))
+    return g2
+
+
+def test_optimise_checks_flags_every_iteration(dev):
+    """optimise() reads ONE flag per iteration (Cholesky / conditioning guard / non-finite gradient; it travels with the packed
+    gradient all-reduce) and raises instead of stepping on meaningless gradients; precision='f64' with the streaming stage
+    of the backward pass on the matrix pipe is the configuration that keeps going where the fp32 Psi2 is flagged."""
     g = golden('grad_ref_60_10_15_4_T5')
     model = build_model(g, dev, 'mixed')
     before = float(model.objective)
     stats = model.optimise(12, learning_rate=0.01)
-    assert stats == {'fallback_steps': 0, 'precision': 'mixed'}
-    stats = model.optimise(12, learning_rate=0.01, _force_fallback_at=(2, 5))
-    assert stats == {'fallback_steps': 2, 'precision': 'mixed'}
-    stats = model.optimise(12, learning_rate=0.01, _force_fallback_at=(0, 1, 2))
-    assert stats == {'fallback_steps': 3, 'precision': 'f64'}
-    twin = model.fp64_twin()
-    np.testing.assert_allclose(float(twin.objective), float(model.evaluate_()[0]), rtol=1e-5)   # same variables, two precisions
-    assert float(model.objective) == float(twin.objective)                                  # the accessor follows the twin now
+    assert stats == {'iterations': 12, 'precision': 'mixed', 'backward_precision': 'mixed'}
     assert float(model.objective) < before
-    model64 = build_model(g, dev, 'f64')
+    assert int((model.per_dimension_terms[1] != 0).sum()) == 0
+    bad = _ill_conditioned(g, 1e-5)
+    mixed = build_model(bad, dev, 'mixed')
     with pytest.raises(FloatingPointError):
-        model64.optimise(3, _force_fallback_at=(1,))                                       # nothing to fall back to
+        mixed.optimise(3)
+    assert set(mixed.per_dimension_terms[1].unique().tolist()) - {0} != set()       # flagged, not silently wrong
+    robust = build_model(bad, dev, 'f64', backward_precision='mixed')
+    before = float(robust.objective)
+    assert robust.optimise(5, learning_rate=0.01)['backward_precision'] == 'mixed'
+    assert int((robust.per_dimension_terms[1] != 0).sum()) == 0
+    assert float(robust.objective) < before
 
 
 @pytest.mark.parametrize('fixture', ['grad_ref_40_6_12_3_T4', 'grad_ref_60_10_15_4_T5'])

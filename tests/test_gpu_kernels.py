@@ -111,6 +111,40 @@ def test_psi2_far_from_origin_is_translation_invariant(dev, dt):
     close(got, ref, tol, 'shifted psi2')
 
 
+def test_psi_statistics_outside_the_f16_range_are_poisoned_not_wrong(dev):
+    """The default fp32 psi kernels split their operands into f16 pairs: the per-(n, m) log-terms must stay below ~3e4, i.e.
+    |z - mean z| and |mu - mean z| within ~90 length scales.  Beyond that the clamp is DETECTED and the result is NaN (the fused
+    ELBO then reports a failed factorisation) — never a silently wrong number; the exact-fp32 kernel (algo='mfma_f32') and
+    fp64 have no such limit and still match the oracle.  Inducing points at +-150 length scales around observations at 0."""
+    rng = np.random.default_rng(9)
+    b, n, m, q = 2, 300, 40, 3
+    z = rng.standard_normal((m, q))
+    z[: m // 2] += 150.0
+    z[m // 2:] -= 150.0                                              # column means ~0, |z - c| ~ 150
+    mu = rng.standard_normal((n, q)) * 0.5
+    mu[:50] += 150.0                                                 # some observations sit at the far cluster
+    s = np.exp(0.3 * rng.standard_normal((n, q)))
+    gam, al = np.ones((b, q)), np.ones((b, 1))
+    ref = orc.psi2(z, mu, s, gam, al)
+    f32, f64 = torch.float32, torch.float64
+    got = ops.psi2(T(z, f32, dev), T(mu, f32, dev), T(s, f32, dev), T(gam, f32, dev), T(al, f32, dev))
+    assert bool(torch.isnan(got).any()), 'out-of-range operands must poison the f16-split result'
+    exact = ops.psi2(T(z, f32, dev), T(mu, f32, dev), T(s, f32, dev), T(gam, f32, dev), T(al, f32, dev), algo='mfma_f32')
+    close(exact, ref, dict(rtol=2e-3, atol_rel=1e-6), 'exact-fp32 psi2 far outside the f16 range')
+    dbl = ops.psi2(T(z, f64, dev), T(mu, f64, dev), T(s, f64, dev), T(gam, f64, dev), T(al, f64, dev))
+    close(dbl, ref, TOL_PSI2[f64], 'fp64 psi2 far outside the f16 range')
+    # the fused ELBO in mixed precision reports it (NaN terms + info != 0); fp64 evaluates
+    y = rng.standard_normal((n, b))
+    be = np.ones((b, 1))
+    args = [T(a, f64, dev) for a in (y, z, mu, s, gam, al, be)]
+    terms, sums, info = ops.elbo_fhat(*args, prec='mixed')
+    assert int((info != 0).sum()) == b and bool(torch.isnan(terms).any())
+    terms64, _, info64 = ops.elbo_fhat(*args, prec='f64')
+    assert int(info64.abs().max()) == 0
+    want = orc.fhat_terms(y, z, mu, s, gam, al, be)
+    np.testing.assert_allclose(terms64.cpu().numpy(), want, rtol=1e-8, atol=1e-8 * np.abs(want).max())
+
+
 @pytest.mark.parametrize('m', [1, 7, 16, 20, 25, 64, 100, 128, 130])
 @pytest.mark.parametrize('dt', [torch.float64, torch.float32])
 @pytest.mark.parametrize('algo', ['auto', 'plain'])

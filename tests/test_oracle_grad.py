@@ -105,3 +105,30 @@ def test_torch_oracle_reproduces_the_bgplvm_reference(path):
         ref = g['grad_' + k]
         np.testing.assert_allclose(grads[k], ref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=k)
     assert len(FIXTURES_B) >= 2
+
+
+ILLCOND = sorted(glob.glob(os.path.join(GOLDEN, 'illcond_ref_*.npz')))
+
+
+@pytest.mark.parametrize('path', ILLCOND, ids=[os.path.basename(p) for p in ILLCOND])
+def test_oracles_at_the_ill_conditioned_point(path):
+    """tests/golden/illcond_ref_*.npz (oracle/gen_golden_illcond.py): the reference's own objective and tf.gradients after
+    Adam has driven K_uu towards singularity.  Both oracles must reproduce them (they are the checkers of the GPU tests at
+    this point), and the fixture must really be in the regime where the fp32 path's guard fires."""
+    g = np.load(path)
+    assert len(ILLCOND) >= 1 and g['kuu_condition'].max() > 1e5
+    n = g['y'].shape[0]
+    assert g['guard'].max() > 10 * 2.0e-3 * n                       # 10 x DPGP_GUARD_REL N (include/dpgp.h)
+    obj, grads = ot.objective_and_gradients(g['y'], {k: g[k] for k in ot.NAMES}, s_1=float(g['s_1']), s_2=float(g['s_2']),
+                                            mask_size=int(g['mask_size']))
+    np.testing.assert_allclose(obj, float(g['objective']), rtol=1e-9)
+    for k in ot.NAMES:
+        ref = g['grad_' + k]
+        np.testing.assert_allclose(grads[k], ref, rtol=0, atol=1e-6 * max(1e-300, np.abs(ref).max()), err_msg=k)
+    e = np.exp(g['dp_logits'] - g['dp_logits'].max(axis=1, keepdims=True))
+    phi = e / e.sum(axis=1, keepdims=True)
+    obj_np = orc.objective(g['y'], g['x_u'], g['x_mean'], softplus(g['x_var_raw']), phi, softplus(g['gamma_atoms_raw']),
+                           softplus(g['alpha_atoms_raw']), softplus(g['beta_atoms_raw']), softplus(g['gamma_1_raw']),
+                           softplus(g['gamma_2_raw']), float(softplus(g['w_1_raw'])), float(softplus(g['w_2_raw'])),
+                           float(g['s_1']), float(g['s_2']))
+    np.testing.assert_allclose(obj_np, float(g['objective']), rtol=1e-9)
