@@ -32,3 +32,35 @@ def create_positive_variable(initial_value, shape=None, device=None):
 def create_random_positive_variable(shape, device=None):
     """Raw variable ~ N(0,1) (types.py:60-72)."""
     return torch.as_tensor(np.random.standard_normal(size=shape), dtype=TORCH_DTYPE, device=device)
+
+
+# ---- variable collections: the reference's tf.GraphKeys.TRAINABLE_VARIABLES / GLOBAL_VARIABLES (types.py:21-37) ----
+# A model constructor registers its raw variables as trainable; the prediction methods register q(X*) (mean and raw
+# variance) as non-trainable — exactly the split the reference's experiment scripts rely on
+# (test/frey_faces_prediction.py:164-171: one Adam over get_training_variables(), a second over get_prediction_variables()).
+_COLLECTIONS = {'trainable': [], 'global': []}
+
+
+def register_variable(tensor, trainable=True):
+    """Add a raw variable (torch tensor, updated in place by optimisers) to the collections; returns it."""
+    _COLLECTIONS['global'].append(tensor)
+    if trainable:
+        _COLLECTIONS['trainable'].append(tensor)
+    return tensor
+
+
+def reset_variable_collections():
+    """tf.reset_default_graph() for the two collections."""
+    _COLLECTIONS['trainable'].clear()
+    _COLLECTIONS['global'].clear()
+
+
+def get_training_variables():
+    """List of the trainable raw variables of every model built since the last reset (types.py:21-26)."""
+    return list(_COLLECTIONS['trainable'])
+
+
+def get_prediction_variables():
+    """The non-trainable variables: q(X*) of the prediction methods, optimised at test time (types.py:29-37)."""
+    train = {id(v) for v in _COLLECTIONS['trainable']}
+    return [v for v in _COLLECTIONS['global'] if id(v) not in train]

@@ -22,7 +22,9 @@ def main():
     for k, v in dict(n=200, d=24, m=30, q=5, t=8, iters=500, seed=1).items():
         ap.add_argument('--' + k, type=int, default=v)
     ap.add_argument('--lr', type=float, default=0.01)
-    ap.add_argument('--precision', default='mixed', choices=['mixed', 'f64'])
+    ap.add_argument('--precision', default='f64', choices=['mixed', 'f64'],
+                    help="f64 (default): fp64 forward + streaming backward stage on the matrix pipe, the configuration that follows "
+                         "the reference's arithmetic through training; mixed: fp32 psi-statistics, raises when its guard fires")
     ap.add_argument('--out', default='')
     ap.add_argument('--over-t', action='store_true', help='train the over-T formulation dp_gp_lvm_t instead of dp_gp_lvm')
     ap.add_argument('--predict', type=int, default=0, help='hold out this many rows and report their test log-likelihood')
@@ -46,7 +48,8 @@ def main():
         y, y_held_out = y_all[:-a.predict], y_all[-a.predict:]
     factory = dp_gp_lvm_t if a.over_t else dp_gp_lvm
     model = factory(y_train=y, num_inducing_points=a.m, num_latent_dims=a.q, truncation_level=a.t,
-                    device=torch.device('cuda', 0), precision=a.precision)
+                    device=torch.device('cuda', 0), precision=a.precision,
+                    **({} if a.over_t else {'backward_precision': 'mixed'}))
     print('Training DP-GP-LVM: N=%d D=%d M=%d Q=%d T=%d, %d Adam iterations, lr %g' % (a.n, a.d, a.m, a.q, a.t, a.iters, a.lr))
     t0 = time.time()
 
@@ -57,20 +60,18 @@ def main():
     train_opt_time = time.time() - t0
     print('Final iter {:5}:\n  GP-DP: {}\nTime to optimise: {} s'.format(a.iters - 1, float(model.objective), train_opt_time))
     if a.predict and not a.over_t:
-        lower_bound, x_test_mean, _, test_ll = model.predict_new_latent_variables(y_held_out)
+        lower_bound, x_test_mean, x_test_covar, test_ll = model.predict_new_latent_variables(y_held_out)
         print('held-out rows: prediction lower bound {}, test log-likelihood {} (at the nearest-neighbour q(X*))'.format(
             float(lower_bound), float(test_ll)))
-    x_mean, x_covar = model.q_x
-    gat, aat, bat = model.dp_atoms
     phi = model.assignments.cpu().numpy()
     print('group assignment of the output dims (argmax of q(Z)):', phi.argmax(axis=1))
     if a.out:
-        mixed = (model.assignments @ gat, model.assignments @ bat, model.assignments @ aat) if a.over_t else \
-            (model.ard_weights, model.noise_precision, model.signal_variance)
-        np.savez(a.out, y_train=y, ard_weights=mixed[0].cpu().numpy(), noise_precision=mixed[1].cpu().numpy(),
-                 signal_variance=mixed[2].cpu().numpy(), x_u=model.inducing_input.cpu().numpy(),
-                 x_mean=x_mean.cpu().numpy(), x_covar=x_covar.cpu().numpy(), assignments=phi, gamma_atoms=gat.cpu().numpy(),
-                 alpha_atoms=aat.cpu().numpy(), beta_atoms=bat.cpu().numpy(), train_opt_time=train_opt_time)
+        # the reference's result schema (src/utils/constants.py:38-72): every ResultKeys array, under its key string
+        from dp_gp_lvm_amd.utils.results import save_results
+        test = {}
+        if a.predict and not a.over_t:
+            test = dict(y_test=y_held_out, x_test_mean=x_test_mean, x_test_covar=x_test_covar)
+        save_results(a.out, model, y, extra=dict(train_opt_time=train_opt_time), **test)
         print('saved', a.out)
 
 

@@ -136,3 +136,21 @@ def test_dirichlet_process_standalone(dev):
     w1, w2 = dp.q_alpha
     ref = orc.dp_objective(dp.q_z.cpu().numpy(), g1.cpu().numpy(), g2.cpu().numpy(), float(w1), float(w2), 1.1, 0.9)
     np.testing.assert_allclose(float(dp.objective), ref, rtol=1e-10)
+
+
+def test_objective_replayed_from_a_hip_graph_follows_the_parameters(dev):
+    """evaluate_graph(): the captured evaluation gives the eager numbers bit for bit, and sees in-place parameter updates."""
+    import torch
+    g = golden('dpgplvm_50_10_25_3_T8')
+    model = build(g, dev, 'mixed')
+    eager = model.objective_terms.cpu().numpy()
+    replay = model.evaluate_graph().clone().cpu().numpy()
+    np.testing.assert_array_equal(replay, eager)
+    with torch.no_grad():
+        model.raw['x_mean'].mul_(1.01)
+        model.raw['gamma_atoms'].add_(0.05)
+    eager2 = model.objective_terms.cpu().numpy()
+    out = torch.zeros(5, dtype=torch.float64, device=dev)
+    model.evaluate_graph(out=out)
+    np.testing.assert_array_equal(out.cpu().numpy(), eager2)
+    assert eager2[0] != eager[0]

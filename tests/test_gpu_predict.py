@@ -107,3 +107,72 @@ def test_test_latent_gradients_and_optimisation(dev):
     do = int(g['n_observed'])
     gm2, gs2 = model.test_latent_gradients(y_test[:, :do], xm, xv)
     assert gm2.shape == xm.shape and bool(torch.isfinite(gm2).all()) and bool(torch.isfinite(gs2).all())
+
+
+@pytest.mark.parametrize('fixture', FIXTURES)
+def test_reference_compat_returns_the_references_own_bounds(dev, fixture):
+    """reference_compat=True: the bounds exactly as the reference's graph computes them (with the [D x D] broadcast of
+    dp_gp_lvm.py:292 / :409), against the numbers its own methods produced (tests/golden/predict_ref_*.npz)."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    g = golden(fixture)
+    model = build(dp_gp_lvm, g, dev, 'f64')
+    lb, _, _, ll = model.predict_new_latent_variables(g['y_test'], x_test_mean=g['new_x_test_mean'], reference_compat=True)
+    np.testing.assert_allclose(float(lb), float(g['new_lower_bound']), rtol=1e-9)
+    np.testing.assert_allclose(float(ll), float(g['new_test_log_likelihood']), rtol=1e-9)
+    do = int(g['n_observed'])
+    lb2 = model.predict_missing_data(g['y_test'][:, :do], x_test_mean=g['missing_x_test_mean'], reference_compat=True)[0]
+    np.testing.assert_allclose(float(lb2), float(g['missing_lower_bound']), rtol=1e-9)
+
+
+def test_variable_split_and_mvn_scoring(dev):
+    """get_training_variables() / get_prediction_variables() (reference src/utils/types.py:21-37) and mvn_log_pdf
+    (src/distributions/normal.py:14-36) as test/frey_faces_prediction.py:164-171,232-238 uses them."""
+    from scipy.stats import multivariate_normal
+    from dp_gp_lvm_amd.distributions.normal import mvn_log_pdf
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    from dp_gp_lvm_amd.utils import types as ty
+    ty.reset_variable_collections()
+    g = golden(FIXTURES[1])
+    model = build(dp_gp_lvm, g, dev, 'f64')
+    train = ty.get_training_variables()
+    assert len(train) == 10 and ty.get_prediction_variables() == []      # (the reference's w_1, w_2 are one 2-vector here)
+    assert {id(v) for v in train} == {id(v) for v in model.raw.values()}
+    do, n_test = int(g['n_observed']), g['y_test'].shape[0]
+    _, xm, _, mean, covar = model.predict_missing_data(g['y_test'][:, :do], x_test_mean=g['missing_x_test_mean'])
+    pred = ty.get_prediction_variables()
+    assert len(pred) == 2 and pred[0].shape == xm.shape and pred[1].shape == xm.shape
+    assert len(ty.get_training_variables()) == 10
+    # ground-truth log-likelihood of the unobserved dims under the predictive posterior, one dim at a time
+    y_u = g['y_test'][:, do:]
+    total = 0.0
+    for du in range(y_u.shape[1]):
+        got = mvn_log_pdf(torch.as_tensor(y_u[:, du][None, :], device=dev), mean[:, du][None, :], covar[du])
+        want = multivariate_normal.logpdf(y_u[:, du], mean=mean[:, du].cpu().numpy(), cov=covar[du].cpu().numpy())
+        np.testing.assert_allclose(got.cpu().numpy(), [want], rtol=1e-10)
+        total += float(got[0])
+    assert np.isfinite(total)
+    bad = -torch.eye(n_test, dtype=torch.float64, device=dev)
+    assert bool(torch.isnan(mvn_log_pdf(torch.zeros((1, n_test), dtype=torch.float64, device=dev),
+                                        torch.zeros((1, n_test), dtype=torch.float64, device=dev), bad)).all())
+    ty.reset_variable_collections()
+
+
+def test_training_example_writes_the_reference_result_schema(dev, tmp_path):
+    """examples/train_synthetic.py end to end (train, predict held-out rows, save) and the file read back by ResultKeys."""
+    import subprocess
+    import sys
+    import os
+    from dp_gp_lvm_amd.utils.constants import ResultKeys
+    from dp_gp_lvm_amd.utils.results import load_results
+    out = str(tmp_path / 'dp_gp_lvm_synthetic_test.npz')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(repo, 'examples', 'train_synthetic.py'), '--n', '80', '--d', '9', '--m', '12',
+                    '--q', '3', '--t', '4', '--iters', '30', '--predict', '6', '--out', out], check=True, timeout=600,
+                   stdout=subprocess.DEVNULL)
+    res = load_results(out)
+    expect = set(ResultKeys) - {ResultKeys.ORIGINAL_DATA, ResultKeys.RANDOMISED_DATA, ResultKeys.NORMALISED_DATA}
+    assert expect <= set(res)
+    assert res[ResultKeys.TRAINING_DATA].shape == (74, 9) and res[ResultKeys.TEST_DATA].shape == (6, 9)
+    assert res[ResultKeys.TEST_INPUT_MEAN].shape == (6, 3) and res[ResultKeys.TEST_INPUT_COVAR].shape == (6, 3, 3)
+    assert res[ResultKeys.DP_ASSIGNMENTS].shape == (9, 4) and res[ResultKeys.Q_V_A].shape == (3,)
+    assert res[ResultKeys.ARD_WEIGHTS].shape == (9, 3) and np.all(res[ResultKeys.NOISE_PRECISION] > 0)
