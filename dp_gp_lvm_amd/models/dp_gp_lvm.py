@@ -164,7 +164,7 @@ def dp_gp_lvm(y_train,
 
     graph_state = {}
 
-    def evaluate_graph(out=None):
+    def _evaluate_graph(out=None):
         """evaluate() replayed from a HIP graph (captured on first use): one hipGraphLaunch instead of eight kernel launches
         and their argument marshalling on the host — at small per-GPU shares (D / 8 output dims) the host side of the eager
         path is as long as the kernels.  The graph reads the raw variables in place, so optimiser updates are seen; with a
@@ -369,7 +369,7 @@ def dp_gp_lvm(y_train,
             return workspace.guard
 
         evaluate_ = staticmethod(evaluate)
-        evaluate_graph = staticmethod(evaluate_graph)
+        evaluate_graph = staticmethod(_evaluate_graph)
 
         @staticmethod
         def partial_pack():
