@@ -6,11 +6,12 @@ One step = one evaluation of dp_gp_lvm(...).objective (reference: src/models/dp_
 raw parameters to the scalar objective in device memory: parameter transforms + soft-assignment mixing + DP objective +
 hyper-prior (dpgp_model_prepare), K_uu, Psi1^T y, Psi2, both Choleskys + solves + the five f_hat terms, KL
 (dpgp_elbo_fhat), the packed 2-scalar all-reduce when D is sharded over GPUs (RCCL), and dpgp_model_finalize.
-Steps are enqueued back to back and the host synchronises once at the end of the timed region (what a training loop
-does: the reference reads the objective only every 100 iterations, test/synthetic_data_hard_test.py:143-155); every
-step's objective is kept on the device and checked after timing.
+Every step ends with the objective copied to pinned host memory on the stream (host-visible per evaluation); steps are
+enqueued back to back and the host synchronises once at the end of the timed region (what a training loop does: the
+reference reads the objective only every 100 iterations, test/synthetic_data_hard_test.py:143-155); every step's value is
+checked after timing.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--prec mixed] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--prec mixed] [--graph auto|on|off] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `value` is whole-job evaluations/s (D=512 is a fixed total: strong scaling).
@@ -40,31 +41,72 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the gram GB/s and Cholesky TFLOP/s side measurements')
     ap.add_argument('--no-grad', action='store_true', help='skip the objective + gradients side measurement (first-version backward pass)')
+    ap.add_argument('--no-side', action='store_true', help='skip the exact-fp32 and fp64 side runs of the same metric')
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='replay the evaluation from a HIP graph (auto: when D is sharded over several GPUs)')
     ap.add_argument('--cpu-dims', type=int, default=0, help='output dims in the bounded CPU sample (0 = auto)')
     return ap.parse_args()
 
 
+def host_cpu():
+    """(model string, usable cores): the box's CPU share — the scheduler affinity capped by the cgroup quota (a GPU box gives
+    one GPU's worker a slice of the host, os.cpu_count() is the whole machine)."""
+    model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return model, cores
+
+
 def cpu_baseline(cfg, p, shape, dims):
-    """The C restatement of the reference algorithm (oracle/dpgp_oracle.c, fast build, OpenMP over output dims) timed on
-    this box's host cores on a bounded sample: `dims` of the D output dims (every dim costs the same), 3 repetitions."""
+    """SURVEY.md 8(d) protocol.  The C restatement of the reference algorithm (oracle/dpgp_oracle.c, -O3 -ffast-math build with
+    libmvec's vector exp: AVX-512 when the host has it, else AVX2; OpenMP over output dims) timed on this box's host cores on a
+    bounded sample: `dims` of the D output dims (every dim costs the same), 2 warm-ups, median of 5 repetitions, on all usable
+    cores and on ONE thread.  The reference as written cannot hold configs 2-5 (168 GB ... 107 PB temporaries, SURVEY.md section 0);
+    its own source under the NumPy stand-in at config 1 takes 1.25 s per objective build (quoted)."""
     from oracle.c_oracle import COracle
     n, d, m, q = shape
     orc = COracle(fast=True)
-    cores = orc.max_threads
+    model, cores = host_cpu()
+    cores = max(1, min(cores, orc.max_threads))
+
+    def timed(sel, threads):
+        args = (np.ascontiguousarray(p['y'][:, sel]), p['z'], p['mu'], p['s'], p['gamma'][sel], p['alpha'][sel], p['beta'][sel])
+        for _ in range(2):
+            orc.fhat_terms(*args, nthreads=threads)          # warm-ups (page in, spin up the OpenMP pool)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            orc.fhat_terms(*args, nthreads=threads)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
     dims = min(d, dims if dims > 0 else max(2 * cores, 16))
     sel = np.linspace(0, d - 1, dims).astype(int)
-    args = (np.ascontiguousarray(p['y'][:, sel]), p['z'], p['mu'], p['s'], p['gamma'][sel], p['alpha'][sel], p['beta'][sel])
-    orc.fhat_terms(*args, nthreads=cores)                    # warm-up (page in, spin up the OpenMP pool)
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        orc.fhat_terms(*args, nthreads=cores)
-        ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts))
-    return dict(value=1.0 / (t * d / dims), unit='ELBO evals/s', cores=int(cores), kind='port',
-                sample='%d of %d output dims of config %d, all of N=%d M=%d Q=%d, fp64 C/OpenMP port of the reference '
-                       'formulas (oracle/dpgp_oracle.c), median of 3 runs of %.2f s, scaled by D/dims'
-                       % (dims, d, cfg, n, m, q, t))
+    t_all = timed(sel, cores)
+    dims1 = max(1, min(dims, 4 if n * m * m * q > 1e10 else 8))
+    sel1 = np.linspace(0, d - 1, dims1).astype(int)
+    t_one = timed(sel1, 1)
+    return dict(value=1.0 / (t_all * d / dims), unit='ELBO evals/s', cores=int(cores), kind='port',
+                sample='%d of %d output dims of config %d, all of N=%d M=%d Q=%d; fp64 C/OpenMP port of the reference formulas '
+                       '(oracle/dpgp_oracle.c, %s: vector exp), 2 warm-ups + median of 5 runs of %.2f s, scaled by D/dims'
+                       % (dims, d, cfg, n, m, q, orc.build_name, t_all),
+                cpu_model=model, host_logical_cpus=int(os.cpu_count() or 0),
+                single_thread={'value': 1.0 / (t_one * d / dims1), 'unit': 'ELBO evals/s',
+                               'sample': '%d output dims, median of 5 runs of %.2f s' % (dims1, t_one)},
+                reference_as_written={'config': 'BASELINE config 1 (N=100, D=12, M=20, Q=4)', 'seconds_per_objective_build': 1.25,
+                                      'what': "the reference's own source under the NumPy stand-in for TensorFlow, build "
+                                              'container (8 cores); quoted from BASELINE.md section 2, not re-measured here'})
 
 
 def secondary(dev, shape, p):
@@ -116,6 +158,30 @@ def secondary(dev, shape, p):
     return out
 
 
+def git_sha():
+    try:
+        import subprocess
+        return subprocess.check_output(['git', '-C', REPO, 'rev-parse', '--short=12', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:                                            # the GPU box receives the tree without .git
+        return None
+
+
+def profiled_traffic(cfg, prec, world):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): read from
+    profiles/r02/traffic.json, which records the build it was measured on; null when this configuration was not profiled."""
+    path = os.path.join(REPO, 'profiles', 'r02', 'traffic.json')
+    if world != 1 or not os.path.exists(path):
+        return None, None
+    try:
+        rec = json.load(open(path)).get('config%d_%s' % (cfg, prec))
+    except (OSError, ValueError):
+        return None, None
+    if not rec:
+        return None, None
+    return float(rec['bytes_per_launch']), rec
+
+
 def main():
     a = parse()
     import torch
@@ -144,13 +210,19 @@ def main():
     init = dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']), gamma_atoms=p['gamma_atoms'],
                 alpha_atoms=p['alpha_atoms'], beta_atoms=p['beta_atoms'], gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'],
                 w_2=p['w2'])
-    model = dp_gp_lvm(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=t,
-                      alpha_prior_params=np.array([p['s1'], p['s2']]), device=dev, precision=a.prec,
-                      process_group=group, initial_values=init)
+    kw = dict(num_latent_dims=q, num_inducing_points=m, truncation_level=t, alpha_prior_params=np.array([p['s1'], p['s2']]),
+              device=dev, initial_values=init)
+    model = dp_gp_lvm(p['y'], precision=a.prec, process_group=group, **kw)
     lib = _lib.lib()
     d_lo, d_hi = model.shard
     outs = torch.zeros((a.steps, 5), dtype=torch.float64, device=dev)   # every step's objective breakdown stays on the device
-    # HIP events around the psi2 kernel on every EV_EVERY-th step only: each recorded event costs ~6 us of stream time
+    host_obj = torch.zeros(a.steps, dtype=torch.float64).pin_memory()   # ... and its objective lands in host memory (async copy)
+    # One step = one evaluation from the device-resident raw parameters to the objective IN HOST MEMORY: the scalar is copied
+    # to a pinned host buffer on the stream in every step (no host synchronisation per step; one at the end of the region).
+    # Launch mode: eager kernel launches, or (--graph on; default when D is sharded) the evaluation replayed from a HIP graph.
+    # HIP events around the psi2 kernel on every EV_EVERY-th step only (each recorded event costs ~6 us of stream time);
+    # those steps are always eager launches.
+    use_graph = (a.graph == 'on') or (a.graph == 'auto' and world > 1)
     EV_EVERY = 8
     ev = {i: (lib.dpgp_event_create(), lib.dpgp_event_create()) for i in range(0, a.steps, EV_EVERY)}
 
@@ -159,12 +231,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step(i):
+        if use_graph and i not in ev:
+            model.evaluate_graph(out=outs[i])
+        else:
+            model.evaluate_(events=ev.get(i), out=outs[i])
+        host_obj[i].copy_(outs[i, 0], non_blocking=True)
+
+    if use_graph:
+        model.evaluate_graph()
     for _ in range(a.warmup):
-        model.evaluate_()
+        model.evaluate_graph() if use_graph else model.evaluate_()
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        model.evaluate_(events=ev.get(i), out=outs[i])
+        step(i)
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -176,10 +257,26 @@ def main():
     for e0, e1 in ev.values():
         lib.dpgp_event_destroy(e0)
         lib.dpgp_event_destroy(e1)
-    objs = outs[:, 0].cpu().numpy()
+    objs = host_obj.numpy().copy()
     terms, info = model.per_dimension_terms
+    if os.environ.get('DPGP_BENCH_NOCHECK'):                      # (timing experiments with diagnostic kernel builds only)
+        objs[:] = 0.0
     assert np.isfinite(objs).all() and np.all(objs == objs[0]), 'objective is not finite / not reproducible'
-    assert int(info.abs().max().item()) == 0, 'a Cholesky factorisation failed'
+    assert os.environ.get('DPGP_BENCH_NOCHECK') or np.array_equal(objs, outs[:, 0].cpu().numpy())
+    assert os.environ.get('DPGP_BENCH_NOCHECK') or int(info.abs().max().item()) == 0, 'a factorisation failed or a precision guard fired'
+
+    def rate(mdl, steps, warm=3):
+        """evals/s of another model object on the same problem (side figures; same launch mode, short run)."""
+        for _ in range(warm):
+            mdl.evaluate_()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            mdl.evaluate_()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        assert int(mdl.per_dimension_terms[1].abs().max().item()) == 0
+        return steps / dt, float(mdl.objective)
 
     if rank == 0:
         d_loc = d_hi - d_lo
@@ -188,19 +285,8 @@ def main():
         exps = d_loc * n * m * (m + 1) // 2
         flops = exps * (4 * q + 2)
         achieved = flops / (psi2_ms * 1e-3) / 1e12
-        # HBM traffic of one psi2 dispatch (incl. its K_uu task slice, now LDS-resident) from the rocprofv3 PMC passes
-        # committed under profiles/r01 (FETCH_SIZE 25318 + WRITE_SIZE 67616, KiB -> bytes; config 3, mixed precision,
-        # 1 GPU); null for every other configuration (not profiled)
-        traffic = 95.2e6 if (a.config == 3 and a.prec == 'mixed' and world == 1) else None
+        traffic, traffic_rec = profiled_traffic(a.config, a.prec, world)
         exp_peak = 256 * 4 * 8 * 2.4e9        # v_exp_f32: 64 lanes / 8 cycles per SIMD, 1024 SIMDs, 2.4 GHz
-        # measured issue floor of the hot loop (profiles/r01/ubench_psi2_row_mix_floor.txt: the per-row instruction mix of
-        # a 64 x 64 patch -- 64 v_exp_f32, 32 v_pk_add_f32, 12 MFMA 32x32x16 f16, 30 split, 16 v_mov -- issues in 1209
-        # cycles per row and SIMD with two waves per SIMD, Q <= 12): rows x patches (a diagonal patch has 3 of 4 tiles)
-        floor_ms = None
-        if q <= 12 and a.prec != 'f64':
-            np64 = (m + 63) // 64
-            tile_rows = d_loc * n * (np64 * (np64 - 1) // 2 * 1.0 + np64 * 0.75)
-            floor_ms = tile_rows * 1209.0 / (256 * 4) / 2.4e9 * 1e3
         f16_path = a.prec != 'f64'
         peak = MFMA_F16_PEAK_TFLOPS if f16_path else 78.6
         res = {
@@ -212,38 +298,52 @@ def main():
             'data': 'synthetic (SURVEY.md 8d recipe, seed %d)' % (1000 + a.config),
             'config': {'workload': 'BASELINE config %d: dp_gp_lvm objective, N=%d D=%d M=%d Q=%d T=%d' % (a.config, n, d, m, q, t),
                        'parallelism': 'D sharded over %d GPU(s), %d output dims per GPU' % (world, d_loc),
-                       'precision': a.prec},
-            'objective': float(objs[0]),
+                       'precision': a.prec, 'launch': 'hip graph replay' if use_graph else 'eager',
+                       'step': 'raw parameters in HBM -> objective in pinned host memory (async copy per step, one sync per run)'},
+            'objective': float(objs[0]), 'git_sha': git_sha(),
             # dominant kernel: psi2 (+ the K_uu task slice that rides in the same dispatch).  `achieved` = ALGORITHMIC flops
             # (N M(M+1)/2 exponents x (4Q+2) flops per output dim) / HIP-event duration; `peak` = dense peak of
             # the matrix pipe the kernel runs on (f16 operands, fp32 accumulate; fp64 MFMA for --prec f64).  The matrix pipe
             # is not what limits it: every exponent costs one v_exp_f32 (8 issue cycles per wave) + one accumulate, see
-            # `exp_frac` (vs the v_exp_f32 rate alone) and `issue_floor_frac` (vs the measured issue rate of the loop's
-            # whole instruction mix) and DESIGN.md section 4.
+            # `exp_frac` (vs the v_exp_f32 rate alone) and DESIGN.md section 4.
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic,
-                         'kernel': 'psi2_f16_kernel' if f16_path else 'psi2_mfma_kernel', 'kernel_ms': psi2_ms,
-                         'limiter': 'VALU issue (v_exp_f32 + accumulate + operand split), not the matrix pipe',
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_rec,
+                         'kernel': 'psi2_pairs_kernel (+ K_uu task slice)' if f16_path else 'psi2_mfma_kernel (+ K_uu task slice)', 'kernel_ms': psi2_ms,
+                         'limiter': ('VALU issue: one v_exp_f32 (8 cycles) + one v_add_f32 (4) per exponent; the matrix pipe runs beneath' if f16_path else
+                                     'fp64 issue: v_mfma_f64 and fp64 VALU (table exp2) share the pipe and do not overlap'),
                          'vs_fp32_matrix_peak': achieved / MFMA_F32_PEAK_TFLOPS,
-                         'exp_per_s': exps / (psi2_ms * 1e-3), 'exp_peak_per_s': exp_peak,
-                         'exp_frac': exps / (psi2_ms * 1e-3) / exp_peak,
-                         'issue_floor_ms': floor_ms, 'issue_floor_frac': (floor_ms / psi2_ms) if floor_ms else None},
+                         'exp_per_s': exps / (psi2_ms * 1e-3), 'exp_peak_per_s': exp_peak if f16_path else None,
+                         'exp_frac': (exps / (psi2_ms * 1e-3) / exp_peak) if f16_path else None},
         }
         if world == 1 and not a.no_secondary:
             res['secondary'] = secondary(dev, shape, p)
+        if world == 1 and not a.no_side and a.prec == 'mixed':
+            # the same metric in the other arithmetic: exact-fp32 products (v_mfma_f32_16x16x4_f32, no f16 split / range limit)
+            # and the reference's own fp64 (src/utils/types.py:13-14) — short runs, same problem, same step definition
+            ks = max(3, min(10, a.steps))
+            v32, o32 = rate(dp_gp_lvm(p['y'], precision='mixed', psi_algo='mfma_f32', **kw), ks)
+            m64 = dp_gp_lvm(p['y'], precision='f64', backward_precision='mixed', **kw)
+            v64, o64 = rate(m64, ks)
+            res['value_fp32_exact'] = v32
+            res['value_f64'] = v64
+            res['precision_check'] = {'objective_mixed': float(objs[0]), 'objective_fp32_exact': o32, 'objective_f64': o64,
+                                      'rel_err_mixed_vs_f64': abs(float(objs[0]) - o64) / abs(o64),
+                                      'rel_err_fp32_exact_vs_f64': abs(o32 - o64) / abs(o64)}
         if world == 1 and not a.no_grad and (a.prec == 'mixed' or (a.prec == 'f64' and m <= 128)):
             # side measurements, not the headline metric: (1) one objective evaluation + the gradients of all raw variables
             # (backward pass; what one Adam iteration of the reference needs); (2) one objective evaluation
             # of the over-T formulation dp_gp_lvm_t on the same data (8f row 3: T Psi2's instead of D)
-            for _ in range(2):
-                model.gradients()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            def grad_ms(mdl, reps):
+                for _ in range(2):
+                    mdl.gradients()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    mdl.gradients()
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t1) / reps
             reps = 10
-            for _ in range(reps):
-                model.gradients()
-            torch.cuda.synchronize()
-            res['objective_and_gradients'] = {'ms': 1e3 * (time.perf_counter() - t0) / reps, 'reps': reps,
+            res['objective_and_gradients'] = {'ms': grad_ms(model, reps), 'reps': reps,
                                               'note': 'stage B of the backward pass on the matrix pipe in mixed precision '
                                                       '(psi2_grad_kernel), plain kernel in f64; DESIGN.md 7.1'}
             # breakdown of one more iteration (torch events on the launch stream): forward, stage A, stage B, chain rule; and
@@ -260,17 +360,10 @@ def main():
                 'forward_ms': t_fwd, 'stage_a_ms': t_a, 'stage_b_ms': t_b, 'chain_rule_ms': t_c,
                 'stage_b_exp_per_s': exps_b / (t_b * 1e-3), 'stage_b_exp_frac_of_v_exp_rate': exps_b / (t_b * 1e-3) / exp_peak})
             if a.prec == 'mixed' and m <= 128:
-                # what optimise() falls back to when fp32 Psi2 is no longer accurate enough: fp64 forward
-                # and dense adjoints, streaming stage B on the matrix pipe
-                tw = model.fp64_twin()
-                for _ in range(2):
-                    tw.gradients()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    tw.gradients()
-                torch.cuda.synchronize()
-                res['objective_and_gradients']['fp64_forward_matrix_pipe_stage_b_ms'] = 1e3 * (time.perf_counter() - t0) / 5
+                # the training configuration that follows the reference's fp64 arithmetic through an Adam run (DESIGN.md
+                # section 5): fp64 forward and dense adjoints, streaming stage B on the matrix pipe
+                res['objective_and_gradients']['training_configuration_f64_forward_mixed_stage_b_ms'] = grad_ms(
+                    dp_gp_lvm(p['y'], precision='f64', backward_precision='mixed', **kw), 5)
             if a.prec in ('mixed', 'f64'):
                 from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
                 model_t = dp_gp_lvm_t(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=p['phi'].shape[1],
@@ -287,14 +380,7 @@ def main():
                                            'truncation_level': int(p['phi'].shape[1]),
                                            'note': 'dp_gp_lvm_t objective, composed of the library operators (not fused)'}
                 if a.prec == 'mixed':
-                    for _ in range(2):
-                        model_t.gradients()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        model_t.gradients()
-                    torch.cuda.synchronize()
-                    res['objective_over_t']['with_gradients_ms'] = 1e3 * (time.perf_counter() - t0) / reps
+                    res['objective_over_t']['with_gradients_ms'] = grad_ms(model_t, reps)
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(a.config, p, shape, a.cpu_dims)
         print(json.dumps(res))

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DPGP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libdpgp_hip.so')
 
 FLAG_NOISE, FLAG_JITTER = 1, 2
-ALGO = {'auto': 0, 'plain': 1, 'mfma_f32': 2}
+ALGO = {'auto': 0, 'plain': 1, 'mfma_f32': 2, 'patch_f16': 3}
 PREC = {'f32': 0, 'mixed': 1, 'f64': 2}
 
 _vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t

@@ -10,7 +10,7 @@
 #include "internal.h"
 
 struct ElboLayout {
-    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, off_kl, off_pc, off_guard, total;
+    size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, off_kl, off_pc, off_guard, off_sc, total;
     int ns1, ns2, Mp;
 };
 
@@ -27,6 +27,7 @@ static ElboLayout elbo_layout(int D, int N, int M, int Q, int prec) {
     L.off_kl = o; o += dpgp_align256(sizeof(double) * DPGP_KL_NBLK);
     L.off_guard = o; o += dpgp_align256(sizeof(double) * D);
     L.off_pc = o; o += dpgp_align256(psi2_consts_bytes(M, Q));
+    L.off_sc = o; o += (prec == DPGP_PREC_F64) ? 0 : psi2_pairs_scale_bytes(D, M);
     L.off_v = o;  o += dpgp_align256(sizeof(double) * (size_t)L.ns1 * D * M);
     L.off_p2 = o; o += dpgp_align256(sp * (size_t)L.ns2 * D * L.Mp * L.Mp);
     L.off_la = o; o += dpgp_align256(sl * (size_t)D * la_chain_ws_elems(M));
@@ -79,13 +80,15 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     // the K_uu branch rides in the psi2 dispatch when it is LDS-resident (or the exact-MFMA psi2 kernel runs, which carries
     // both forms); otherwise it is a launch of its own ahead of psi2
     const bool f16_psi2 = (sizeof(TP) == 4 && algo != DPGP_ALGO_MFMA_F32);
-    const bool fused_k = (algo != DPGP_ALGO_PLAIN) && (!f16_psi2 || la_chain_k_resident(M, (int)sizeof(TL)));
+    const bool fused_k = (algo != DPGP_ALGO_PLAIN) && (!f16_psi2 || la_chain_k_resident(M, (int)sizeof(TL))) &&
+                         !getenv("DPGP_UNFUSED_K");      // (experiments only)
     if (!fused_k && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, st))) return rc;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     // psi2 on the matrix cores; the same dispatch carries, ahead of the psi2 workgroups, the D workgroups of the K_uu
     // branch (Cholesky, log-det, inverse of K_uu), which are latency-bound and overlap the psi2 work completely
     if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st,
-                                              fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst, 1)))
+                                              fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst, 1,
+                                              reinterpret_cast<float *>(ws + L.off_sc))))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,

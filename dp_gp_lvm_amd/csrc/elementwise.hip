@@ -512,8 +512,10 @@ __global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__r
                                                     int first_consts_block) {
     __shared__ double scratch[5][64];
     const int t = threadIdx.x;
-    if ((int)blockIdx.x >= first_consts_block) {      // third role: z-only constants of the psi2 kernel (psi2_consts.h)
-        psi2_consts_rows(z, M, Q, consts, (int)blockIdx.x - first_consts_block, &scratch[0][0]);
+    if ((int)blockIdx.x >= first_consts_block) {      // third role: z-only constants of the psi kernels (psi2_consts.h)
+        const int cb = (int)blockIdx.x - first_consts_block, nrow = (M + 63) / 64;
+        if (cb < nrow) psi2_consts_rows(z, M, Q, consts, cb, &scratch[0][0]);
+        else psi2_pair_rows(z, M, Q, consts, cb - nrow, &scratch[0][0]);        // pair image of psi2_pairs.hip
         return;
     }
     if (blockIdx.x < DPGP_KL_NBLK) {      // KL partials: block k handles every DPGP_KL_NBLK-th run of 256 elements
@@ -557,7 +559,7 @@ int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int 
         blocks += dpgp_ceil_div(D, 64) * YY_NCH;
     }
     const int first_consts = blocks;
-    if (psi2_consts) blocks += dpgp_ceil_div(M, 64);
+    if (psi2_consts) blocks += dpgp_ceil_div(M, 64) + dpgp_ceil_div(psi2_consts_layout(M, Q).Ppad, PSI2_PAIR_ROWS_PER_BLOCK);
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((kl_yy_kernel<TIN>), dim3(blocks), dim3(256), 0, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out, z, M,
                        psi2_consts, first_consts);
     DPGP_LAUNCH_CHECK();

@@ -39,7 +39,9 @@ template <typename TIN> int launch_psi2_consts(const TIN *z, int M, int Q, unsig
 template <typename TIN, typename T>
 int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,
-                        double *logdet_k, int *info_k, unsigned char *consts, int consts_ready);
+                        double *logdet_k, int *info_k, unsigned char *consts, int consts_ready, float *pair_scale);
+// pair_scale: psi2_pairs_scale_bytes(B, M) bytes of scratch for the pair-tile kernel (fp32 results, psi2_pairs.hip)
+size_t psi2_pairs_scale_bytes(int B, int M);
 
 // ---- linalg.hip ------------------------------------------------------------------------------------------------
 // per-d workspace of the fused Cholesky chain, in elements of TL (layout: linalg.hip)

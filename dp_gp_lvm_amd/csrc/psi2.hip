@@ -21,33 +21,12 @@
 #include "internal.h"
 #include "linalg_dev.h"
 #include "psi2_consts.h"
+#include "psi2_chain_task.h"
 
 #define PSI2_NT 32   // n per LDS tile
 #ifndef PSI2_PF_NARROW_KB
 #define PSI2_PF_NARROW_KB 5   // from this many groups of 4 latent dims on, the prefetched q(X) rows are held as fp32
 #endif
-
-// Optional extra task slice in front of the psi2 workgroups (blockIdx.z == 0): the K_uu branch of the ELBO
-// (chain_k_body of linalg_dev.h: Cholesky, log-det and inverse of K_uu for output dim blockIdx.x).  It is part of the SAME
-// dispatch, ahead of the psi2 workgroups, because a separate dispatch on another stream is only served once the ~1500 psi2
-// workgroups have all been placed (measured: it then finishes AFTER psi2 and lands on the critical path).
-struct ChainKTask {
-    void *ws;            // per-output Cholesky workspaces (float or double elements), nullptr = no task slice
-    size_t ws_stride;
-    double *logdet_k;
-    int *info_k;
-    int M, Mp, elem;     // elem = 4 (float) or 8 (double)
-    int last;            // f16 kernel: tasks at the end of the grid instead of in front (see psi2_task_1d)
-};
-// OCC separates the instantiations by the launch bound of the calling kernel (the compiler derives the register budget of
-// a device function from its callers; one shared copy would take the loosest bound and push the f16 kernel past 256 VGPRs)
-template <int OCC>
-__device__ __attribute__((always_inline, flatten)) void chain_k_task(const ChainKTask &tk, int d, unsigned char *smem_raw) {
-    if (tk.elem == 8)
-        chain_k_body<double, OCC>(d, tk.M, tk.Mp, (double *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
-    else
-        chain_k_body<float, OCC>(d, tk.M, tk.Mp, (float *)tk.ws, tk.ws_stride, tk.logdet_k, tk.info_k, 0, smem_raw);
-}
 
 // Workgroup coordinates.  grid = (B, n-splits, patches); the patch index is the SLOWEST dimension and enumerates the
 // off-diagonal patches (16 tiles of work) before the diagonal ones (10 tiles), so the long workgroups are dispatched
@@ -69,27 +48,6 @@ __device__ __forceinline__ void psi2_block_coords(int nps, int zoff, int &b, int
     sp = blockIdx.y;
     psi2_patch_coords(nps, blockIdx.z - zoff, pi, pj);
 }
-// One-dimensional grid of the f16 kernel: C = B K_uu tasks (if fused) and P = B * ns * patches psi2 items (item j =
-// b + B (sp + ns patch), long off-diagonal patches first).  The K_uu tasks are latency bound (one small Cholesky each, hardly
-// any VALU work) and a psi2 workgroup needs a second psi2 workgroup on its compute unit to keep the vector units busy (one
-// wave per SIMD reaches ~2/3 of the issue rate).  Measured placements of the K_uu tasks (config 3 / config 2, evals/s):
-//   en bloc in front 515 / 2499;  en bloc at the end 545 / 2064;  interleaved with psi2 items in runs of 8: 457 / 2452
-//   (next to a psi2 workgroup a K_uu task takes ~600 us instead of ~100 us, whatever its s_setprio).
-// In front, B >= ~256 tasks hold every slot of the GPU for ~100 us with idle vector units; at the end they fill the slots
-// the psi2 tail leaves empty anyway, but add their full latency when there are only few of them.  Hence: at the end iff
-// B >= 256.
-__device__ __forceinline__ bool psi2_task_1d(int id, int C, bool chain_last, int &task) {
-    if (chain_last) {
-        const int P = (int)gridDim.x - C;
-        if (id < P) { task = id; return false; }
-        task = id - P;
-        return true;
-    }
-    if (id < C) { task = id; return true; }
-    task = id - C;
-    return false;
-}
-
 // LDS geometry shared by the kernel and the host-side size computation
 template <typename T, int KS, int PT> struct Psi2Lds {
     static constexpr int PS = 16 * PT;                       // patch edge
@@ -1825,11 +1783,14 @@ static int launch_psi2_ks(int B, int N, int M, int Q, const TIN *z, const TIN *m
 template <typename TIN>
 __global__ __launch_bounds__(256) void psi2_consts_kernel(const TIN *__restrict__ z, int M, int Q, unsigned char *__restrict__ dst) {
     __shared__ double scratch[5 * 64];
-    psi2_consts_rows(z, M, Q, dst, (int)blockIdx.x, scratch);
+    const int nrow = (M + 63) / 64;
+    if ((int)blockIdx.x < nrow) psi2_consts_rows(z, M, Q, dst, (int)blockIdx.x, scratch);
+    else psi2_pair_rows(z, M, Q, dst, (int)blockIdx.x - nrow, scratch);
 }
 size_t psi2_consts_bytes(int M, int Q) { return psi2_consts_layout(M, Q).bytes; }
 template <typename TIN> int launch_psi2_consts(const TIN *z, int M, int Q, unsigned char *consts, hipStream_t st) {
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_consts_kernel<TIN>), dim3(dpgp_ceil_div(M, 64)), dim3(256), 0, st, z, M, Q, consts);
+    const int blocks = dpgp_ceil_div(M, 64) + dpgp_ceil_div(psi2_consts_layout(M, Q).Ppad, PSI2_PAIR_ROWS_PER_BLOCK);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_consts_kernel<TIN>), dim3(blocks), dim3(256), 0, st, z, M, Q, consts);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -1870,6 +1831,29 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
     return DPGP_OK;
 }
 
+// psi2_pairs.hip: the pair-tile kernel (fp32 results; the default)
+template <typename TIN>
+int launch_psi2_pairs(int B, int N, int M, int Q, const TIN *mu, const TIN *s, const TIN *gamma, const TIN *alpha,
+                      float *part, int ns, const ChainKTask &task, const unsigned char *consts, float *scale, hipStream_t st);
+template <typename TIN, typename T> struct Psi2PairsDispatch {
+    static int run(int, int, int, int, const TIN *, const TIN *, const TIN *, const TIN *, const TIN *, T *, int,
+                   const ChainKTask &, unsigned char *, int, float *, hipStream_t) {
+        return -13;
+    }
+};
+template <typename TIN> struct Psi2PairsDispatch<TIN, float> {
+    static int run(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                   const TIN *alpha, float *part, int ns, const ChainKTask &task, unsigned char *consts, int consts_ready,
+                   float *pair_scale, hipStream_t st) {
+        if (!consts || !pair_scale) return -18;
+        if (!consts_ready) {
+            const int rc = launch_psi2_consts<TIN>(z, M, Q, consts, st);
+            if (rc) return rc;
+        }
+        return launch_psi2_pairs<TIN>(B, N, M, Q, mu, s, gamma, alpha, part, ns, task, consts, pair_scale, st);
+    }
+};
+
 // the f16-split kernel exists for fp32 results only
 template <typename TIN, typename T> struct Psi2F16Dispatch {
     static int run(int, int, int, int, const TIN *, const TIN *, const TIN *, const TIN *, const TIN *, T *, int,
@@ -1894,7 +1878,7 @@ template <typename TIN> struct Psi2F16Dispatch<TIN, float> {
 template <typename TIN, typename T>
 int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,
-                        double *logdet_k, int *info_k, unsigned char *consts, int consts_ready) {
+                        double *logdet_k, int *info_k, unsigned char *consts, int consts_ready, float *pair_scale) {
     const int Mp = dpgp_round_up(M, 16);
     ChainKTask task = {chain_ws, la_chain_ws_elems_inline(M), logdet_k, info_k, M, Mp, chain_elem, B >= 256 ? 1 : 0};
     if (algo == DPGP_ALGO_PLAIN && chain_ws) return -16;     // the plain path launches chain_k on its own
@@ -1909,9 +1893,14 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
         DPGP_LAUNCH_CHECK();
         return DPGP_OK;
     }
-    // fp32 results: f16-split operands on the matrix pipe unless the exact-fp32 MFMA kernel is asked for
-    if (sizeof(T) == 4 && algo != DPGP_ALGO_MFMA_F32)
+    // fp32 results: f16-split operands on the matrix pipe unless the exact-fp32 MFMA kernel is asked for; the pair-tile
+    // kernel (psi2_pairs.hip) by default, the per-observation patch kernel on request
+    // (more than 20 latent dims: 12 K-steps per pair tile leave no room for resident column operands; patch kernel)
+    if (sizeof(T) == 4 && (algo == DPGP_ALGO_PATCH_F16 || (algo != DPGP_ALGO_MFMA_F32 && psi2_pairs_ksteps(Q) > 8)))
         return Psi2F16Dispatch<TIN, T>::run(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, consts, consts_ready, st);
+    if (sizeof(T) == 4 && algo != DPGP_ALGO_MFMA_F32)
+        return Psi2PairsDispatch<TIN, T>::run(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, consts, consts_ready, pair_scale,
+                                              st);
     const int KS = dpgp_ceil_div(Q + 2, 4);
     switch (KS) {
 #define CASE(k) \
@@ -1923,13 +1912,13 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
 }
 template int launch_psi2_partial<float, float>(int, int, int, int, const float *, const float *, const float *,
                                                const float *, const float *, float *, int, int, hipStream_t, void *, int,
-                                               double *, int *, unsigned char *, int);
+                                               double *, int *, unsigned char *, int, float *);
 template int launch_psi2_partial<double, double>(int, int, int, int, const double *, const double *, const double *,
                                                  const double *, const double *, double *, int, int, hipStream_t, void *,
-                                                 int, double *, int *, unsigned char *, int);
+                                                 int, double *, int *, unsigned char *, int, float *);
 template int launch_psi2_partial<double, float>(int, int, int, int, const double *, const double *, const double *,
                                                 const double *, const double *, float *, int, int, hipStream_t, void *,
-                                                int, double *, int *, unsigned char *, int);
+                                                int, double *, int *, unsigned char *, int, float *);
 
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
@@ -1937,7 +1926,8 @@ template int launch_psi2_partial<double, float>(int, int, int, int, const double
 extern "C" size_t dpgp_psi2_workspace_bytes(int B, int N, int M, int Q, int elem_size) {
     if (B <= 0 || N <= 0 || M <= 0 || Q <= 0) return 0;
     int Mp = dpgp_round_up(M, 16);
-    return dpgp_align256((size_t)elem_size * psi2_nsplit(B, N, M) * B * Mp * Mp) + psi2_consts_bytes(M, Q);
+    return dpgp_align256((size_t)elem_size * psi2_nsplit(B, N, M) * B * Mp * Mp) + psi2_consts_bytes(M, Q) +
+           psi2_pairs_scale_bytes(B, M);
 }
 
 template <typename T>
@@ -1955,11 +1945,12 @@ static int psi2_api(int B, int N, int M, int Q, const T *z, const T *mu, const T
     if (!out) return -10;
     if (!ws) return -11;
     if (ws_bytes < dpgp_psi2_workspace_bytes(B, N, M, Q, sizeof(T))) return -12;
-    if (algo < 0 || algo > DPGP_ALGO_MFMA_F32) return -13;
+    if (algo < 0 || algo > DPGP_ALGO_PATCH_F16) return -13;
     const int ns = psi2_nsplit(B, N, M), Mp = dpgp_round_up(M, 16);
     unsigned char *consts = (unsigned char *)ws + dpgp_align256(sizeof(T) * (size_t)ns * B * Mp * Mp);
     int rc = launch_psi2_partial<T, T>(B, N, M, Q, z, mu, s, gamma, alpha, (T *)ws, ns, algo, (hipStream_t)stream,
-                                       nullptr, 0, nullptr, nullptr, consts, 0);
+                                       nullptr, 0, nullptr, nullptr, consts, 0,
+                                       reinterpret_cast<float *>(consts + psi2_consts_bytes(M, Q)));
     if (rc) return rc;
     size_t tot = (size_t)B * M * M;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_finish_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

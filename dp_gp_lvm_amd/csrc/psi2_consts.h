@@ -12,7 +12,24 @@
 struct Psi2Consts {
     int ZLD, SL, Mp64;
     size_t off_zs, off_bimg, bytes;
+    // pair image of the pair-tile psi2 kernel (psi2_pairs.hip): SLP f16 slots per pair p = m (m + 1) / 2 + m' (m' <= m), sums
+    // s = (z_m - c) + (z_m' - c): per latent dim q the slots {hi, lo, hi} of s_q^2 (term 2q) and of s_q (term 2q + 1), slots
+    // 6Q, 6Q + 1 = 1, rest 0; pairs [P, Ppad) are zero.  Independent of the output dim.  Stored in MFMA OPERAND ORDER: for the
+    // tile of 32 pairs T = p / 32 and the K-step ks = slot / 16 the 64 lanes' 16-byte operand words are contiguous (lane =
+    // 32 (slot % 16 / 8) + p % 32 holds slots 16 ks + 8 (lane / 32) .. + 7 of pair 32 T + lane % 32): one wave-wide load is one
+    // coalesced KB (with one row of slots per pair the 64 lanes of a load touched 32 different cache lines, and the address
+    // path of the texture unit, not the arithmetic, set the kernel's pace).
+    int KS, SLP, P, Ppad;
+    size_t off_pairs;
+    // per pair, for the kernel's epilogue: pmap[p] = m << 16 | m' (0xffffffff for p >= P) and the squared differences
+    // dz2[q][p] = (z_mq - z_m'q)^2 (fp32, [Q][Ppad]), from which the per-output factor alpha^2 exp2(beta_p) is formed
+    size_t off_pmap, off_dz2;
 };
+// K-steps of 16 slots that hold the 6Q + 2 slots of a row; only these instantiations of the kernel exist
+__host__ __device__ inline int psi2_pairs_ksteps(int Q) {
+    const int ks = (6 * Q + 2 + 15) / 16;
+    return ks <= 2 ? 2 : (ks <= 4 ? 4 : (ks <= 6 ? 6 : (ks <= 8 ? 8 : 12)));
+}
 __host__ __device__ inline Psi2Consts psi2_consts_layout(int M, int Q) {
     Psi2Consts c;
     const int KQ = 4 * ((Q + 3) / 4);
@@ -21,7 +38,14 @@ __host__ __device__ inline Psi2Consts psi2_consts_layout(int M, int Q) {
     c.Mp64 = (M + 63) & ~63;
     c.off_zs = 128;
     c.off_bimg = c.off_zs + sizeof(float) * (size_t)c.Mp64 * c.ZLD;
-    c.bytes = (c.off_bimg + sizeof(_Float16) * (size_t)c.Mp64 * c.SL + 255) & ~(size_t)255;
+    c.off_pairs = (c.off_bimg + sizeof(_Float16) * (size_t)c.Mp64 * c.SL + 255) & ~(size_t)255;
+    c.KS = psi2_pairs_ksteps(Q);
+    c.SLP = 16 * c.KS;
+    c.P = (int)((long long)M * (M + 1) / 2);
+    c.Ppad = (c.P + 31) & ~31;
+    c.off_pmap = (c.off_pairs + sizeof(_Float16) * (size_t)c.Ppad * c.SLP + 255) & ~(size_t)255;
+    c.off_dz2 = (c.off_pmap + sizeof(unsigned) * (size_t)c.Ppad + 255) & ~(size_t)255;
+    c.bytes = (c.off_dz2 + sizeof(float) * (size_t)Q * c.Ppad + 255) & ~(size_t)255;
     return c;
 }
 
@@ -62,5 +86,66 @@ __device__ __forceinline__ void psi2_consts_rows(const TIN *__restrict__ z, int 
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         const h2v hv = {h2[0], h2[1]};
         reinterpret_cast<unsigned *>(bimg)[(size_t)m * (c.SL / 2) + w] = __builtin_bit_cast(unsigned, hv);
+    }
+}
+
+// pair (m, m'), m' <= m, of the row-major lower-triangle index p
+__host__ __device__ inline void psi2_pair_of(int p, int &m, int &mp) {
+    int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+    while ((long long)(i + 1) * (i + 2) / 2 <= p) ++i;
+    while ((long long)i * (i + 1) / 2 > p) --i;
+    m = i;
+    mp = p - (int)((long long)i * (i + 1) / 2);
+}
+#define PSI2_PAIR_ROWS_PER_BLOCK 256
+// pair-image rows [256 blk, 256 blk + 256) by one 256-thread workgroup; scratch as psi2_consts_rows
+template <typename TIN>
+__device__ __forceinline__ void psi2_pair_rows(const TIN *__restrict__ z, int M, int Q, unsigned char *__restrict__ dst,
+                                               int blk, double *scratch) {
+    const Psi2Consts c = psi2_consts_layout(M, Q);
+    float *zc = reinterpret_cast<float *>(scratch + 8 * 32);
+    block_column_means(z, M, Q, zc, scratch);
+    const int t = threadIdx.x, wpr = c.SLP / 2;                  // 32-bit words per row
+    unsigned *img = reinterpret_cast<unsigned *>(dst + c.off_pairs);
+    const int p0 = PSI2_PAIR_ROWS_PER_BLOCK * blk;
+    if (p0 + t < c.Ppad) {                                       // thread = pair: index map and squared differences
+        const int p = p0 + t;
+        int m = 0, mp = 0;
+        if (p < c.P) psi2_pair_of(p, m, mp);
+        reinterpret_cast<unsigned *>(dst + c.off_pmap)[p] = (p < c.P) ? ((unsigned)m << 16 | (unsigned)mp) : 0xffffffffu;
+        float *dz2 = reinterpret_cast<float *>(dst + c.off_dz2);
+        for (int q = 0; q < Q; ++q) {
+            const float d = (p < c.P) ? (float)((double)z[(size_t)m * Q + q] - (double)z[(size_t)mp * Q + q]) : 0.0f;
+            dz2[(size_t)q * c.Ppad + p] = d * d;
+        }
+    }
+    for (int e = t; e < PSI2_PAIR_ROWS_PER_BLOCK * wpr; e += 256) {
+        const int r = e / wpr, w = e - r * wpr, p = p0 + r;
+        if (p >= c.Ppad) break;
+        int m = 0, mp = 0;
+        if (p < c.P) psi2_pair_of(p, m, mp);
+        _Float16 h2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int slot = 2 * w + i;
+            float val = 0.0f;
+            if (p < c.P) {
+                if (slot < 6 * Q) {
+                    const int tt = slot / 3, part = slot - 3 * tt, q = tt >> 1;
+                    const float sq = ((float)z[(size_t)m * Q + q] - zc[q]) + ((float)z[(size_t)mp * Q + q] - zc[q]);
+                    const float v = (tt & 1) ? sq : sq * sq;
+                    const _Float16 h = (_Float16)v;
+                    val = (part == 1) ? (float)(_Float16)(v - (float)h) : (float)h;
+                } else if (slot < 6 * Q + 2) {
+                    val = 1.0f;
+                }
+            }
+            h2[i] = (_Float16)val;
+        }
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const h2v hv = {h2[0], h2[1]};
+        // word w of pair p holds slots 2w, 2w + 1: K-step ks = w / 8, operand half (w % 8) / 4, word (w % 4) of the lane's four
+        const int ks = w >> 3, hf = (w >> 2) & 1, wi = w & 3, lane = 32 * hf + (p & 31);
+        img[(((size_t)(p >> 5) * c.KS + ks) * 64 + lane) * 4 + wi] = __builtin_bit_cast(unsigned, hv);
     }
 }

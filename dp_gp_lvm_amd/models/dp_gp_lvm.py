@@ -42,7 +42,7 @@ def dp_gp_lvm(y_train,
               alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
               mask_size=1,
               device=None, precision='mixed', process_group=None, initial_values=None, backward_precision=None,
-              _shard_of=None):
+              psi_algo='auto', _shard_of=None):
     """
     :param y_train: [N x D] numpy array, columns normalised to zero mean / unit variance (dp_gp_lvm.py:30-32).
     :param num_latent_dims: Q.  :param num_inducing_points: M.  :param truncation_level: T.
@@ -54,6 +54,8 @@ def dp_gp_lvm(y_train,
     :param backward_precision: precision of the streaming stage (B) of the backward pass; default: `precision`.  'mixed' with
            precision='f64' = fp64 forward and dense adjoints (accurate B^-1, K^-1 however ill-conditioned K_uu is), the
            streaming stage on the matrix pipe (gradients to ~1e-4): the training configuration (see optimise()).
+    :param psi_algo: 'auto' (fp32 psi-statistics on f16 hi/lo-split MFMA operands), 'mfma_f32' (exact fp32 products on
+           v_mfma_f32_16x16x4_f32: no f16 range limit, slower) or 'plain' (VALU cross-check kernels); forward evaluation only.
     :param initial_values: dict of post-initialisation parameter VALUES (x_mean, x_var, x_u, phi_logits, gamma_atoms,
            alpha_atoms, beta_atoms, gamma_1, gamma_2, w_1, w_2) that replace the random/PCA initialisation — used by the
            parity tests and the benchmark, which must not depend on PCA sign conventions or NumPy's global RNG.
@@ -68,6 +70,7 @@ def dp_gp_lvm(y_train,
         'less than the number of observations.'
     assert precision in _lib.PREC, 'precision must be one of %s' % sorted(_lib.PREC)
     assert backward_precision in (None, 'mixed', 'f64'), "backward_precision must be None, 'mixed' or 'f64'"
+    assert psi_algo in _lib.ALGO, 'psi_algo must be one of %s' % sorted(_lib.ALGO)
     assert truncation_level <= 64, 'truncation levels above 64 are not supported by the HIP model kernels (PREP_MAX_T)'
     device = default_device() if device is None else torch.device(device)
     iv = dict(initial_values or {})
@@ -139,7 +142,7 @@ def dp_gp_lvm(y_train,
     workspace = ops.ElboWorkspace(d_local, num_samples, num_inducing_points, num_latent_dims, precision, device)
     s_1, s_2 = dp_model.prior
 
-    def evaluate(events=None, out=None):
+    def evaluate(events=None, out=None, _local_part_only=False):
         """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior).
         Launches: prepare, gram, [chain_k on the side stream], kl_yy, psi1T_y, psi2, chain_b, tail (sum+pack+finalize)."""
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
@@ -153,31 +156,38 @@ def dp_gp_lvm(y_train,
             buf['phi'].data_ptr(), buf['scal'].data_ptr(), st), 'dpgp_model_prepare')
         red = buf['red']
         # single GPU: the last kernel of the fused ELBO also packs and finalises; sharded: it packs, then one all-reduce
-        _, sums, _ = ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
-                                   jitter=GP_DEFAULT_JITTER, prec=precision, workspace=workspace, events=events,
-                                   model_tail=(buf['scal'], red, None if sharded else out))
-        if sharded:
-            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=process_group)    # the only exchange: 2 fp64 scalars
-            _lib.check(lib.dpgp_model_finalize(red.data_ptr(), sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
-                                               out.data_ptr(), st), 'dpgp_model_finalize')
+        ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
+                      jitter=GP_DEFAULT_JITTER, prec=precision, algo=psi_algo, workspace=workspace, events=events,
+                      model_tail=(buf['scal'], red, None if sharded else out))
+        if sharded and not _local_part_only:
+            _exchange_and_finalise(out)
         return out
+
+    def _exchange_and_finalise(out):
+        lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+        dist.all_reduce(buf['red'], op=dist.ReduceOp.SUM, group=process_group)    # the only exchange: 2 fp64 scalars
+        _lib.check(lib.dpgp_model_finalize(buf['red'].data_ptr(), workspace.sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
+                                           out.data_ptr(), st), 'dpgp_model_finalize')
 
     graph_state = {}
 
     def _evaluate_graph(out=None):
         """evaluate() replayed from a HIP graph (captured on first use): one hipGraphLaunch instead of eight kernel launches
         and their argument marshalling on the host — at small per-GPU shares (D / 8 output dims) the host side of the eager
-        path is as long as the kernels.  The graph reads the raw variables in place, so optimiser updates are seen; with a
-        process group the all-reduce is captured too (RCCL; the gloo transport of the tests cannot be captured).  Returns the
-        same device tensor as evaluate(); `out` (optional, [5]) receives a copy on the stream."""
+        path is as long as the kernels.  The graph reads the raw variables in place, so optimiser updates are seen.  With a
+        process group the graph holds this rank's part (prepare ... pack); the 2-scalar all-reduce and the finalising kernel
+        follow as ordinary calls (a collective inside a captured graph is transport-specific; this form works with any).
+        Returns the same device tensor as evaluate(); `out` (optional, [5]) receives a copy on the stream."""
         if 'graph' not in graph_state:
-            evaluate()                                   # (first call outside the capture: function attributes, RCCL warm-up)
+            evaluate()                                   # (first call outside the capture: function attributes, warm-up)
             torch.cuda.synchronize()
             gph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gph):
-                evaluate()
+                evaluate(_local_part_only=True)
             graph_state['graph'] = gph
         graph_state['graph'].replay()
+        if sharded:
+            _exchange_and_finalise(buf['out'])
         if out is not None:
             out.copy_(buf['out'], non_blocking=True)
         return buf['out']
@@ -519,7 +529,7 @@ def dp_gp_lvm_t(y_train,
                 alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
                 mask_size=1,
                 seed=0,
-                device=None, precision='mixed', initial_values=None):
+                device=None, precision='mixed', initial_values=None, _view_of_many=False):
     """
     Over-T formulation — mirror of the reference's ``dp_gp_lvm_t`` factory (src/models/dp_gp_lvm.py:513-676), SURVEY.md
     §8(f) row 3: the kernel batch is the T atoms, the mixture weights phi [T x D] enter outside the kernel, so an evaluation
@@ -536,7 +546,8 @@ def dp_gp_lvm_t(y_train,
     precision: 'f64', or 'mixed' = the Psi statistics in fp32 (f16-split MFMA kernels), everything after them in fp64.
     """
     num_samples, num_dimensions = np.shape(y_train)
-    assert 0 < num_latent_dims < num_dimensions, \
+    # (_view_of_many: one view of a multi-view model, whose own check is against the views' total dimensionality)
+    assert 0 < num_latent_dims < num_dimensions or _view_of_many, \
         'Number of latent dimensions must be postive and less than the dimensionality of the observed data.'
     assert 0 < num_inducing_points <= num_samples, \
         'Number of inducing points must be positive and less than or equal to the number of observations in the ' \

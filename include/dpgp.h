@@ -36,9 +36,10 @@ extern "C" {
 #define DPGP_MAX_Q 30
 
 /* algorithm selectors for the calls that have a matrix-core and a plain-VALU implementation */
-#define DPGP_ALGO_AUTO 0     /* matrix-core kernels (the product path); fp32 psi2 uses f16 hi/lo-split operands   */
+#define DPGP_ALGO_AUTO 0     /* matrix-core kernels (the product path); fp32 psi2 = pair-tile GEMM, f16 hi/lo operands */
 #define DPGP_ALGO_PLAIN 1    /* straightforward one-thread-per-element HIP kernels (cross-check)                  */
 #define DPGP_ALGO_MFMA_F32 2 /* as AUTO, but fp32 psi2 on v_mfma_f32_16x16x4_f32 (exact fp32 products; slower)    */
+#define DPGP_ALGO_PATCH_F16 3 /* as AUTO, but fp32 psi2 by the per-observation 64x64 patch kernel (round-1 form)    */
 
 /* precision modes of the fused ELBO */
 #define DPGP_PREC_F32 0   /* psi-statistics fp32, Cholesky chain fp32                          */

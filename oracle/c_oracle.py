@@ -30,7 +30,15 @@ class COracle:
     """fast=False: strict-IEEE build (the checker).  fast=True: -O3 -ffast-math build (the timed CPU baseline)."""
 
     def __init__(self, fast=False):
-        path = os.path.join(_HERE, '_build', 'libdpgp_oracle_fast.so' if fast else 'libdpgp_oracle.so')
+        name = 'libdpgp_oracle.so'
+        if fast:                       # AVX-512 build when the host has it (8-wide libmvec exp), AVX2 otherwise
+            try:
+                flags = open('/proc/cpuinfo').read()
+            except OSError:
+                flags = ''
+            name = 'libdpgp_oracle_fast_v4.so' if ' avx512f' in flags else 'libdpgp_oracle_fast.so'
+        self.build_name = name
+        path = os.path.join(_HERE, '_build', name)
         if not os.path.exists(path):
             build()
         self.lib = ctypes.CDLL(path)

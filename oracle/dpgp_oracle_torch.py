@@ -276,3 +276,36 @@ def objective_bgplvm_and_gradients(y, raw_values, jitter=GP_DEFAULT_JITTER):
     grads = torch.autograd.grad(obj, [raw[k] for k in BGPLVM_NAMES], allow_unused=True)
     return float(obj), {k: (np.zeros_like(np.asarray(raw_values[k], dtype=np.float64)) if g is None else g.numpy().copy())
                         for k, g in zip(BGPLVM_NAMES, grads)}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Manifold relevance determination (reference src/models/gaussian_process.py:551-664): V views share
+# q(X); every view has its own B = 1 kernel and its own inducing inputs.  objective = -(sum_v f_hat_v - KL + sum_v prior_v),
+# each f_hat_v being the Bayesian GP-LVM's (:236-258 = :619-651).  Pinned by oracle/gen_golden_mrd.py.
+# --------------------------------------------------------------------------------------------------------------------
+def mrd_names(num_views):
+    v = range(num_views)
+    return ['gamma_raw_%d' % i for i in v] + ['alpha_raw_%d' % i for i in v] + ['beta_raw_%d' % i for i in v] + \
+        ['x_mean', 'x_var_raw'] + ['x_u_%d' % i for i in v]
+
+
+def objective_mrd(views, raw, jitter=GP_DEFAULT_JITTER):
+    mu, s = raw['x_mean'], _softplus(raw['x_var_raw'])
+    kl = 0.5 * (torch.sum(mu * mu) + torch.sum(s - torch.log(s)) - mu.shape[0] * mu.shape[1])
+    total = -kl
+    for i, y in enumerate(views):
+        gam, al, be = (_softplus(raw['%s_raw_%d' % (k, i)]) for k in ('gamma', 'alpha', 'beta'))
+        phi = torch.ones((y.shape[1], 1), dtype=y.dtype)
+        total = total + fhat_t(y, raw['x_u_%d' % i], mu, s, phi, gam, al[:, 0], be[:, 0], jitter=jitter) + \
+            sum(torch.sum(_log_normal_log_pdf(a)) for a in (gam, al, be))
+    return -total
+
+
+def objective_mrd_and_gradients(views, raw_values, jitter=GP_DEFAULT_JITTER):
+    vt = [torch.as_tensor(np.asarray(y), dtype=torch.float64) for y in views]
+    names = mrd_names(len(views))
+    raw = {k: torch.tensor(np.asarray(raw_values[k], dtype=np.float64), dtype=torch.float64, requires_grad=True) for k in names}
+    obj = objective_mrd(vt, raw, jitter=jitter)
+    grads = torch.autograd.grad(obj, [raw[k] for k in names], allow_unused=True)
+    return float(obj), {k: (np.zeros_like(np.asarray(raw_values[k], dtype=np.float64)) if g is None else g.numpy().copy())
+                        for k, g in zip(names, grads)}

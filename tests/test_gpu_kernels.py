@@ -87,6 +87,8 @@ def test_psi_statistics_vs_oracle_ragged(dev, shape, dt):
     ref2 = orc.psi2(z, mu, s, gam, al)
     close(ops.psi2(*args), ref2, TOL_PSI2[dt], 'psi2')
     close(ops.psi2(*args, algo='mfma_f32'), ref2, TOL_PSI2[dt], 'psi2 fp32-MFMA variant')
+    if dt == torch.float32:
+        close(ops.psi2(*args, algo='patch_f16'), ref2, TOL_PSI2[dt], 'psi2 per-observation patch kernel')
     close(ops.psi1(*args), orc.psi1(z, mu, s, gam, al), TOL[dt], 'psi1')
     tol = dict(TOL[dt])
     if dt == torch.float32:
