@@ -135,6 +135,14 @@ __device__ __forceinline__ double dpgp_exp2_hot(double x, const double *tab) { r
 __device__ __forceinline__ float dpgp_log(float x) { return logf(x); }
 __device__ __forceinline__ double dpgp_log(double x) { return log(x); }
 
+// Fixes a value in its fp32 register before it is split into an f16 (hi, lo) pair.  Without it the compiler (with
+// -ffp-contract=fast) forms  hi = f16(fl32(x y))  with v_cvt but the residual  x y - hi'  with hi' = v_fma_mixlo_f16(x, y, 0),
+// the f16 rounding of the EXACT product: near a rounding tie hi' != hi and the pair is off by one f16 ulp of hi
+// (found on the GPU: 2e-3 relative on single terms of Psi2; ISA: v_cvt_pk_f16_f32 next to v_fma_mixlo_f16 of the same product).
+__device__ __forceinline__ float dpgp_pin(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 // Wavefront (64 lanes) sum.
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -361,6 +361,8 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
                         bb = (float)DPGP_LOG2E * w1 * mcq;
                         cc = w1 * mcq * mcq + dpgp_log(den);
                     }
+                    a = dpgp_pin(a);                          // (pinned before the (hi, lo) split: see dpgp_pin)
+                    bb = dpgp_pin(bb);
                     const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
                     const _Float16 bh = (_Float16)bb, bl = (_Float16)(bb - (float)bh);
                     unsigned *dst = reinterpret_cast<unsigned *>(am + r * SL + 6 * q);      // slots {ah, ah, al, bh, bh, bl}
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
             c = (float)(-0.5 * DPGP_LOG2E) * c;
             oor |= !(c >= -60000.0f);                       // f16 range guard (as in psi2_patch_f16p): the result becomes NaN
             c = fmaxf(c, -60000.0f);
+            c = dpgp_pin(c);
             const _Float16 ch = (_Float16)c;
             const p1_h2 cw = {ch, (_Float16)(c - (float)ch)};
             *reinterpret_cast<unsigned *>(am + lane * SL + 6 * Q) = __builtin_bit_cast(unsigned, cw);

@@ -784,6 +784,8 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
                         bb = (float)DPGP_LOG2E * w * mc;
                         cc = (float)(-0.5 * DPGP_LOG2E) * w * mc * mc - 0.25f * __builtin_amdgcn_logf(den);   // (v_log_f32 = log2, den >= 1)
                     }
+                    a = dpgp_pin(a);                          // (pinned before the (hi, lo) split: see dpgp_pin)
+                    bb = dpgp_pin(bb);
                     const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
                     const _Float16 bhh = (_Float16)bb, bll = (_Float16)(bb - (float)bhh);
                     unsigned *dst = reinterpret_cast<unsigned *>(aimg + r * SL + 6 * k);     // slots {ah, ah, al, bh, bh, bl}
@@ -817,6 +819,7 @@ __device__ __forceinline__ void psi2_patch_f16p(int N, int M, int Q, int B, cons
             }
             oor |= !(c >= -30000.0f);              // f16 range guard: see the epilogue
             c = fmaxf(c, -30000.0f);
+            c = dpgp_pin(c);
             const _Float16 ch = (_Float16)c;
             const dpgp_h2 cw = {ch, (_Float16)(c - (float)ch)};
             *reinterpret_cast<unsigned *>(aimg + lane * SL + 6 * Q) = __builtin_bit_cast(unsigned, cw);
@@ -1398,6 +1401,8 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
                         bb = (float)DPGP_LOG2E * w * mc;
                         cc = (float)(-0.5 * DPGP_LOG2E) * w * mc * mc - 0.25f * __builtin_amdgcn_logf(den);   // (v_log_f32 = log2, den >= 1)
                     }
+                    a = dpgp_pin(a);                          // (pinned before the (hi, lo) split: see dpgp_pin)
+                    bb = dpgp_pin(bb);
                     const _Float16 ah = (_Float16)a, al_ = (_Float16)(a - (float)ah);
                     const _Float16 bhh = (_Float16)bb, bll = (_Float16)(bb - (float)bhh);
                     unsigned *dst = reinterpret_cast<unsigned *>(aimg + r * SL + 6 * k);
@@ -1433,6 +1438,7 @@ __global__ __launch_bounds__(256, (KB <= 3 ? 2 : 1)) void psi2_grad_kernel(int N
             }
             oor |= !(c >= -30000.0f);              // f16 range guard: see the epilogue
             c = fmaxf(c, -30000.0f);
+            c = dpgp_pin(c);
             const _Float16 ch = (_Float16)c;
             const dpgp_h2 cw = {ch, (_Float16)(c - (float)ch)};
             *reinterpret_cast<unsigned *>(aimg + lane * SL + 6 * Q) = __builtin_bit_cast(unsigned, cw);

@@ -75,7 +75,7 @@ __device__ __forceinline__ void psi2_consts_rows(const TIN *__restrict__ z, int 
             if (slot < 6 * Q) {
                 const int tt = slot / 3, part = slot - 3 * tt, q = tt >> 1;
                 const float zz = (m < M) ? (float)z[(size_t)m * Q + q] - zc[q] : 0.0f;
-                const float v = (tt & 1) ? zz : zz * zz;
+                const float v = dpgp_pin((tt & 1) ? zz : zz * zz);     // (pinned before the (hi, lo) split: see dpgp_pin)
                 const _Float16 h = (_Float16)v;
                 val = (part == 1) ? (float)(_Float16)(v - (float)h) : (float)h;
             } else if (slot < 6 * Q + 2) {
@@ -98,6 +98,7 @@ __host__ __device__ inline void psi2_pair_of(int p, int &m, int &mp) {
     mp = p - (int)((long long)i * (i + 1) / 2);
 }
 #define PSI2_PAIR_ROWS_PER_BLOCK 256
+#define PSI2_PAIR_S2_SCALE 0.015625f     // 1 / 64 (see psi2_pair_rows); the kernel's a-coefficients carry the 64
 // pair-image rows [256 blk, 256 blk + 256) by one 256-thread workgroup; scratch as psi2_consts_rows
 template <typename TIN>
 __device__ __forceinline__ void psi2_pair_rows(const TIN *__restrict__ z, int M, int Q, unsigned char *__restrict__ dst,
@@ -133,11 +134,13 @@ __device__ __forceinline__ void psi2_pair_rows(const TIN *__restrict__ z, int M,
                 if (slot < 6 * Q) {
                     const int tt = slot / 3, part = slot - 3 * tt, q = tt >> 1;
                     const float sq = ((float)z[(size_t)m * Q + q] - zc[q]) + ((float)z[(size_t)mp * Q + q] - zc[q]);
-                    const float v = (tt & 1) ? sq : sq * sq;
+                    // s^2 / 64 against 64 a on the other side: a = -1/4 w log2e is ~0.1, its f16 lo piece would be an f16
+                    // subnormal (resolution 2^-24: only ~11 + 7 bits of a); balanced, both lo pieces are normal numbers
+                    const float v = dpgp_pin((tt & 1) ? sq : sq * sq * PSI2_PAIR_S2_SCALE);   // (see dpgp_pin)
                     const _Float16 h = (_Float16)v;
                     val = (part == 1) ? (float)(_Float16)(v - (float)h) : (float)h;
-                } else if (slot < 6 * Q + 2) {
-                    val = 1.0f;
+                } else if (slot < 6 * Q + 2 || (slot == 6 * Q + 2 && slot < c.SLP)) {
+                    val = 1.0f;                                  // (third slot: the third f16 piece of the row constant c'')
                 }
             }
             h2[i] = (_Float16)val;

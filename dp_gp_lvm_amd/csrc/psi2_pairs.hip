@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256, PP_WAVES) void psi2_pairs_kernel(int N, int M,
                 for (int q = 0; q < Q; ++q) {
                     const float g = gq[q], sv = (float)s[(size_t)n * Q + q], mc = (float)mu[(size_t)n * Q + q] - zc[q];
                     const float den = 2.0f * g * sv + 1.0f, w = g / den;
-                    const float a = (float)(-0.25 * DPGP_LOG2E) * w, bb = (float)DPGP_LOG2E * w * mc;
+                    // (a carries the 64 that the s^2 features were divided by: psi2_consts.h, PSI2_PAIR_S2_SCALE)
+                    const float a = dpgp_pin((float)(-0.25 * DPGP_LOG2E / PSI2_PAIR_S2_SCALE) * w);
+                    const float bb = dpgp_pin((float)DPGP_LOG2E * w * mc);              // (pinned: see dpgp_pin)
                     cc -= bb * mc + 0.5f * __builtin_amdgcn_logf(den);          // (v_log_f32 = log2, den >= 1)
                     const _Float16 ah = (_Float16)a, alo = (_Float16)(a - (float)ah);
                     const _Float16 bh = (_Float16)bb, blo = (_Float16)(bb - (float)bh);
@@ -234,17 +236,26 @@ __global__ __launch_bounds__(256, PP_WAVES) void psi2_pairs_kernel(int N, int M,
                     dst[3 * q + 1] = __builtin_bit_cast(unsigned, w1);
                     dst[3 * q + 2] = __builtin_bit_cast(unsigned, w2);
                 }
-                // f16 range guard: c'' must exist as an f16 pair (|mu - c| within ~250 length scales); a clamp of a real row
-                // is detected and poisons this workgroup's results (NaN), never a silently wrong Psi2
-                oor |= !(cc >= -60000.0f);
+                // Range guard.  The terms of the exponent cancel (E = c'' + sum a s^2 + b s is a sum of squares in disguise) and
+                // are as large as |c''| ~ (|mu - c| / length scale)^2: with 22-bit operands and fp32 accumulation the exponent
+                // of a row is good to ~|c''| 2^-21, i.e. the row's terms to 0.4 % at |c''| = 8192 (|mu - c| ~ 50 length scales
+                // in every latent dim).  Beyond that the row is DETECTED and this workgroup's results become NaN — never a
+                // silently wrong Psi2 (DPGP_ALGO_MFMA_F32 and fp64 have no such limit).
+                oor |= !(cc >= -8192.0f);
                 cc = fmaxf(cc, -60000.0f);
             } else {
                 for (int q = 0; q < 3 * Q; ++q) dst[q] = 0u;
             }
+            // c'' is the largest number in the exponent and common to a whole row: three f16 pieces (33 bits) where a K slot
+            // is free (always, except Q = 5), so that its rounding does not show in every term of the observation
+            cc = dpgp_pin(cc);
             const _Float16 ch = (_Float16)cc;
-            const pp_h2 cw = {ch, (_Float16)(cc - (float)ch)};
+            const float r1 = dpgp_pin(cc - (float)ch);
+            const _Float16 cm = (_Float16)r1;
+            const pp_h2 cw = {ch, cm}, cw2 = {(_Float16)(r1 - (float)cm), (_Float16)0.0f};
             dst[3 * Q] = __builtin_bit_cast(unsigned, cw);
             for (int k = 3 * Q + 1; k < SLP / 2; ++k) dst[k] = 0u;
+            if (6 * Q + 2 < SLP) dst[3 * Q + 1] = __builtin_bit_cast(unsigned, cw2);
         }
         if (__syncthreads_or(oor ? 1 : 0)) poison = __builtin_nanf("");
 

@@ -70,7 +70,9 @@ def test_fhat_spot_baseline_shapes(dev, cfg, name, prec):
     np.testing.assert_allclose(np.sqrt((p2 * p2).sum(axis=(1, 2))), g['psi_2_fro'], rtol=rt)
     np.testing.assert_allclose(p2[:, g['sample_i'], g['sample_j']], g['psi_2_samples'], rtol=rt,
                                atol=rt * np.abs(g['psi_2_samples']).max())
-    np.testing.assert_allclose(p2.sum(axis=2), g['psi_2_rowsum'], rtol=rt)
+    # (fp32: the exponent of the pair-tile kernel is a K = 2Q + 1 product of f16-split operands accumulated in fp32, whose
+    #  terms are ~10 x the exponent at Q = 20: entries to ~5e-5, relative to the largest row sum here)
+    np.testing.assert_allclose(p2.sum(axis=2), g['psi_2_rowsum'], rtol=rt, atol=0 if prec == 'f64' else rt * np.abs(g['psi_2_rowsum']).max())
 
 
 @pytest.mark.parametrize('cfg', [2, 3])
