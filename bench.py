@@ -94,7 +94,7 @@ def cpu_baseline(cfg, p, shape, dims):
     dims = min(d, dims if dims > 0 else max(2 * cores, 16))
     sel = np.linspace(0, d - 1, dims).astype(int)
     t_all = timed(sel, cores)
-    dims1 = max(1, min(dims, 4 if n * m * m * q > 1e10 else 8))
+    dims1 = max(1, min(dims, 1 if n * m * m * q > 1e10 else 8))
     sel1 = np.linspace(0, d - 1, dims1).astype(int)
     t_one = timed(sel1, 1)
     return dict(value=1.0 / (t_all * d / dims), unit='ELBO evals/s', cores=int(cores), kind='port',

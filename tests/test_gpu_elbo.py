@@ -52,10 +52,15 @@ def test_fhat_terms_golden(dev, fixture, prec, algo):
     np.testing.assert_allclose(sums[1], float(g['kl']), rtol=1e-12)
 
 
-@pytest.mark.parametrize('cfg,name', [(2, 'spot_C2'), (3, 'spot_C3'), (5, 'spot_C5')])
+@pytest.mark.parametrize('cfg,name', [(2, 'spot_C2'), (3, 'spot_C3'), (4, 'spot_C4'), (5, 'spot_C5')])
 @pytest.mark.parametrize('prec', ['f64', 'mixed', 'f32'])
 def test_fhat_spot_baseline_shapes(dev, cfg, name, prec):
-    """Full N, M, Q of BASELINE configs 2/3/5 on the 4 output dims the reference was evaluated on."""
+    """Full N, M, Q of BASELINE configs 2/3/4/5 on the 4 output dims the reference was evaluated on (config 4: the reference
+    kernel with B = 1 on N-chunks)."""
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip(name + '.npz is not generated yet (oracle/gen_golden.py spot4)')
     g = golden(name)
     p = make_problem(cfg, d_slice=g['dsel'])
     terms, sums, info = run(p, dev, prec)
@@ -75,7 +80,7 @@ def test_fhat_spot_baseline_shapes(dev, cfg, name, prec):
     np.testing.assert_allclose(p2.sum(axis=2), g['psi_2_rowsum'], rtol=rt, atol=0 if prec == 'f64' else rt * np.abs(g['psi_2_rowsum']).max())
 
 
-@pytest.mark.parametrize('cfg', [2, 3])
+@pytest.mark.parametrize('cfg', [2, 3, 4, 5])
 def test_full_size_properties(dev, cfg):
     """Size-independent properties at the full BASELINE shape (the oracle would take minutes here):
     (1) sharding D commutes: terms of a D-slice equal the slice of the terms (to fp32 summation order); (2) f_hat is the sum of the terms;
@@ -122,12 +127,12 @@ def test_not_positive_definite_is_reported_not_fatal(dev):
 def test_config4_shape_against_c_oracle(dev):
     """BASELINE config 4 shape (N=10000, M=512, Q=20) on 2 of its 256 output dims: exercises the 8x8-patch psi2 grid,
     three K-steps of f16 MFMA, and the global-memory (non-LDS) blocked Cholesky.  No reference-generated golden exists at
-    this size (the reference's temporary would be 107 PB), so the checker is the C oracle, itself pinned to
-    the reference at every other shape."""
+    The reference-generated golden at this shape is spot_C4 (test_fhat_spot_baseline_shapes: the reference kernel with B = 1 on
+    N-chunks); this test adds two more output dims against the strict build of the C oracle, itself pinned to the reference."""
     from oracle.c_oracle import COracle
     sel = np.array([3, 200])
     p = make_problem(4, d_slice=sel)
-    c = COracle(fast=True)
+    c = COracle(fast=False)                                  # the strict-IEEE build: the checker (c_oracle.py)
     ref, info_ref = c.fhat_terms(p['y'], p['z'], p['mu'], p['s'], p['gamma'], p['alpha'], p['beta'],
                                  nthreads=min(16, c.max_threads))
     assert not info_ref.any()
