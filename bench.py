@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--no-grad', action='store_true', help='skip the objective + gradients side measurement (first-version backward pass)')
     ap.add_argument('--no-side', action='store_true', help='skip the exact-fp32 and fp64 side runs of the same metric')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='replay the evaluation from a HIP graph (auto: when D is sharded over several GPUs)')
+                    help='replay the evaluation from a HIP graph (auto = off: measured no faster)')
     ap.add_argument('--cpu-dims', type=int, default=0, help='output dims in the bounded CPU sample (0 = auto)')
     return ap.parse_args()
 
@@ -222,7 +222,7 @@ def main():
     # Launch mode: eager kernel launches, or (--graph on; default when D is sharded) the evaluation replayed from a HIP graph.
     # HIP events around the psi2 kernel on every EV_EVERY-th step only (each recorded event costs ~6 us of stream time);
     # those steps are always eager launches.
-    use_graph = (a.graph == 'on') or (a.graph == 'auto' and world > 1)
+    use_graph = (a.graph == 'on')          # ('auto' = eager: measured, the graph replay is no faster at D = 64 per GPU and slower at D = 512)
     EV_EVERY = 8
     ev = {i: (lib.dpgp_event_create(), lib.dpgp_event_create()) for i in range(0, a.steps, EV_EVERY)}
 

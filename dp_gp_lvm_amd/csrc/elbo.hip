@@ -8,6 +8,7 @@
 //   5. B = K + beta Psi2, bordered Cholesky, f_hat terms      (chain_b_kernel)
 //   6. f_hat = sum of terms, KL = sum of partials [+ model-level tail]  (sum_terms_kernel)
 #include "internal.h"
+#include "psi2_consts.h"
 
 struct ElboLayout {
     size_t off_yy, off_v, off_p2, off_la, off_ld, off_ik, off_kl, off_pc, off_guard, off_sc, total;
@@ -69,13 +70,14 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     unsigned char *pconst = ws + L.off_pc;
     hipEvent_t ev0 = ex ? (hipEvent_t)ex->ev_psi2_begin : nullptr, ev1 = ex ? (hipEvent_t)ex->ev_psi2_end : nullptr;
     int rc;
-    if ((rc = launch_gram<double, TL>(D, M, M, Q, z, nullptr, gamma, alpha, beta, DPGP_FLAG_JITTER, jitter, la, L.Mp,
-                                      la_chain_ws_elems(M), st)))
+    // one front launch: KL, y'y, the z-only constants of the psi kernels (incl. the pair image), K_uu + jitter I and — for
+    // the pair-tile psi2 kernel — its per-(output dim, pair) scale table
+    const bool pairs_psi2 = (sizeof(TP) == 4 && algo == DPGP_ALGO_AUTO && psi2_pairs_ksteps(Q) <= 8);
+    float *pscale = reinterpret_cast<float *>(ws + L.off_sc);
+    if ((rc = launch_elbo_front<TL>(N, Q, mu, s, klp, D, y, ldy, yy, z, M, pconst, gamma, alpha, beta, jitter, la, L.Mp,
+                                    la_chain_ws_elems(M), pairs_psi2 ? pscale : nullptr, st)))
         return rc;
-    // (the same launch builds the z-only constants of the f16 psi2 kernel)
-    if ((rc = launch_kl_yy<double>(N, Q, mu, s, klp, D, y, ldy, yy, z, M, pconst, st))) return rc;
-    if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1,
-                                                 st)))
+    if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1, st)))
         return rc;
     // the K_uu branch rides in the psi2 dispatch when it is LDS-resident (or the exact-MFMA psi2 kernel runs, which carries
     // both forms); otherwise it is a launch of its own ahead of psi2
@@ -87,8 +89,8 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     // psi2 on the matrix cores; the same dispatch carries, ahead of the psi2 workgroups, the D workgroups of the K_uu
     // branch (Cholesky, log-det, inverse of K_uu), which are latency-bound and overlap the psi2 work completely
     if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st,
-                                              fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst, 1,
-                                              reinterpret_cast<float *>(ws + L.off_sc))))
+                                              fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst,
+                                              pairs_psi2 ? 2 : 1, pscale)))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,

@@ -11,15 +11,13 @@
 // ---------------------------------------------------------------------------------------------------------------
 #define GRAM_T 64
 template <typename TIN, typename T>
-__global__ __launch_bounds__(256) void gram_kernel(int N0, int N1, int Q, const TIN *__restrict__ x0,
-                                                   const TIN *__restrict__ x1, const TIN *__restrict__ gamma,
-                                                   const TIN *__restrict__ alpha, const TIN *__restrict__ beta,
-                                                   int flags, T jitter, T *__restrict__ out, int ld_out,
-                                                   size_t batch_stride, int symmetric) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
+__device__ __forceinline__ void gram_tile(int b, int i0, int j0, int N0, int N1, int Q, const TIN *__restrict__ x0,
+                                          const TIN *__restrict__ x1, const TIN *__restrict__ gamma,
+                                          const TIN *__restrict__ alpha, const TIN *__restrict__ beta, int flags, T jitter,
+                                          T *__restrict__ out, int ld_out, size_t batch_stride, int symmetric,
+                                          unsigned char *smem_raw) {
     T *xs = reinterpret_cast<T *>(smem_raw);          // [64][Q+1]
     T *zs = xs + GRAM_T * (Q + 1);                     // [64][Q+1]
-    const int b = blockIdx.z, i0 = blockIdx.y * GRAM_T, j0 = blockIdx.x * GRAM_T;
     const int t = threadIdx.x;
     const TIN *g = gamma + (size_t)b * Q;
     for (int e = t; e < GRAM_T * Q; e += 256) {
@@ -80,6 +78,16 @@ __global__ __launch_bounds__(256) void gram_kernel(int N0, int N1, int Q, const 
                 if (j + c < N1) p[c] = v[c];
         }
     }
+}
+template <typename TIN, typename T>
+__global__ __launch_bounds__(256) void gram_kernel(int N0, int N1, int Q, const TIN *__restrict__ x0,
+                                                   const TIN *__restrict__ x1, const TIN *__restrict__ gamma,
+                                                   const TIN *__restrict__ alpha, const TIN *__restrict__ beta,
+                                                   int flags, T jitter, T *__restrict__ out, int ld_out,
+                                                   size_t batch_stride, int symmetric) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    gram_tile<TIN, T>(blockIdx.z, blockIdx.y * GRAM_T, blockIdx.x * GRAM_T, N0, N1, Q, x0, x1, gamma, alpha, beta, flags, jitter,
+                      out, ld_out, batch_stride, symmetric, smem_raw);
 }
 
 template <typename TIN, typename T>
@@ -508,32 +516,31 @@ __global__ void sum_slabs_kernel(size_t n, int ns, const double *__restrict__ pa
 // ---------------------------------------------------------------------------------------------------------------
 #define YY_NCH DPGP_YY_NCH
 template <typename TIN>
-__global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__restrict__ mu,
-                                                    const TIN *__restrict__ s, double *__restrict__ kl_out, int D,
-                                                    const TIN *__restrict__ y, int ldy, double *__restrict__ yy_out,
-                                                    const TIN *__restrict__ z, int M, unsigned char *__restrict__ consts,
-                                                    int first_consts_block) {
-    __shared__ double scratch[5][64];
+__device__ __forceinline__ void kl_yy_block(int blk, int N, int Q, const TIN *__restrict__ mu, const TIN *__restrict__ s,
+                                            double *__restrict__ kl_out, int D, const TIN *__restrict__ y, int ldy,
+                                            double *__restrict__ yy_out, const TIN *__restrict__ z, int M,
+                                            unsigned char *__restrict__ consts, int first_consts_block,
+                                            double (*scratch)[64]) {
     const int t = threadIdx.x;
-    if ((int)blockIdx.x >= first_consts_block) {      // third role: z-only constants of the psi kernels (psi2_consts.h)
-        const int cb = (int)blockIdx.x - first_consts_block, nrow = (M + 63) / 64;
+    if (blk >= first_consts_block) {      // third role: z-only constants of the psi kernels (psi2_consts.h)
+        const int cb = blk - first_consts_block, nrow = (M + 63) / 64;
         if (cb < nrow) psi2_consts_rows(z, M, Q, consts, cb, &scratch[0][0]);
         else psi2_pair_rows(z, M, Q, consts, cb - nrow, &scratch[0][0]);        // pair image of psi2_pairs.hip
         return;
     }
-    if (blockIdx.x < DPGP_KL_NBLK) {      // KL partials: block k handles every DPGP_KL_NBLK-th run of 256 elements
+    if (blk < DPGP_KL_NBLK) {      // KL partials: block k handles every DPGP_KL_NBLK-th run of 256 elements
         if (kl_out == nullptr) return;
         double a0 = 0.0;
         const size_t tot = (size_t)N * Q;
-        for (size_t i = (size_t)blockIdx.x * 256 + t; i < tot; i += (size_t)DPGP_KL_NBLK * 256) {
+        for (size_t i = (size_t)blk * 256 + t; i < tot; i += (size_t)DPGP_KL_NBLK * 256) {
             const double m0 = (double)mu[i], v0 = (double)s[i];
             a0 += m0 * m0 + v0 - log(v0) - 1.0;
         }
         const double a = block_sum(a0, &scratch[0][0]);
-        if (t == 0) kl_out[blockIdx.x] = 0.5 * a;     // sum over blocks = 1/2 (sum mu^2 + sum (s - log s) - N Q)
+        if (t == 0) kl_out[blk] = 0.5 * a;     // sum over blocks = 1/2 (sum mu^2 + sum (s - log s) - N Q)
         return;
     }
-    const int bid = blockIdx.x - DPGP_KL_NBLK, dblk = bid / YY_NCH, ch = bid - dblk * YY_NCH;
+    const int bid = blk - DPGP_KL_NBLK, dblk = bid / YY_NCH, ch = bid - dblk * YY_NCH;
     const int d = dblk * 64 + (t & 63), wv = t >> 6;
     const int nper = (N + YY_NCH - 1) / YY_NCH, n0 = ch * nper, n1 = min(N, n0 + nper);
     double a0 = 0.0, a1 = 0.0;
@@ -553,6 +560,69 @@ __global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__r
     __syncthreads();
     if (t < 64 && d < D) yy_out[(size_t)ch * D + d] = scratch[0][t] + scratch[1][t] + scratch[2][t] + scratch[3][t];
 }
+template <typename TIN>
+__global__ __launch_bounds__(256) void kl_yy_kernel(int N, int Q, const TIN *__restrict__ mu,
+                                                    const TIN *__restrict__ s, double *__restrict__ kl_out, int D,
+                                                    const TIN *__restrict__ y, int ldy, double *__restrict__ yy_out,
+                                                    const TIN *__restrict__ z, int M, unsigned char *__restrict__ consts,
+                                                    int first_consts_block) {
+    __shared__ double scratch[5][64];
+    kl_yy_block<TIN>((int)blockIdx.x, N, Q, mu, s, kl_out, D, y, ldy, yy_out, z, M, consts, first_consts_block, scratch);
+}
+// The front launch of the fused ELBO: the roles of kl_yy_kernel and, behind them, the 64 x 64 tiles of K_uu + jitter I of all
+// D output dims (gram_tile) -- none of them depends on another, so one launch replaces two (the evaluation at D / 8 output
+// dims per GPU is a chain of latency-bound launches).
+template <typename TL>
+__global__ __launch_bounds__(256) void elbo_front_kernel(int N, int Q, const double *__restrict__ mu,
+                                                         const double *__restrict__ s, double *__restrict__ kl_out, int D,
+                                                         const double *__restrict__ y, int ldy, double *__restrict__ yy_out,
+                                                         const double *__restrict__ z, int M, unsigned char *__restrict__ consts,
+                                                         int first_consts_block, int first_gram_block,
+                                                         const double *__restrict__ gamma, const double *__restrict__ alpha,
+                                                         const double *__restrict__ beta, TL jitter, TL *__restrict__ kuu,
+                                                         int ld_kuu, size_t kuu_stride, int first_scale_block,
+                                                         float *__restrict__ pair_scale) {
+    __shared__ double scratch[5][64];
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int blk = (int)blockIdx.x;
+    if (blk < first_gram_block) {
+        kl_yy_block<double>(blk, N, Q, mu, s, kl_out, D, y, ldy, yy_out, z, M, consts, first_consts_block, scratch);
+        return;
+    }
+    if (blk >= first_scale_block) {                       // the pair-scale table of the pair-tile psi2 kernel (psi2_consts.h)
+        const int nb = (psi2_consts_layout(M, Q).Ppad + 255) / 256, sb = blk - first_scale_block;
+        psi2_pair_scale_block<double, double>(sb / nb, sb % nb, M, Q, z, gamma, alpha, pair_scale);
+        return;
+    }
+    const int tm = (M + GRAM_T - 1) / GRAM_T, g = blk - first_gram_block, b = g / (tm * tm), r = g - b * tm * tm;
+    gram_tile<double, TL>(b, (r / tm) * GRAM_T, (r % tm) * GRAM_T, M, M, Q, z, z, gamma, alpha, beta, DPGP_FLAG_JITTER, jitter,
+                          kuu, ld_kuu, kuu_stride, 1, smem_raw);
+}
+template <typename TL>
+int launch_elbo_front(int N, int Q, const double *mu, const double *s, double *kl_out, int D, const double *y, int ldy,
+                      double *yy_out, const double *z, int M, unsigned char *psi2_consts, const double *gamma,
+                      const double *alpha, const double *beta, double jitter, TL *kuu, int ld_kuu, size_t kuu_stride,
+                      float *pair_scale, hipStream_t st) {
+    int blocks = DPGP_KL_NBLK + dpgp_ceil_div(D, 64) * YY_NCH;
+    const int first_consts = blocks;
+    blocks += dpgp_ceil_div(M, 64) + dpgp_ceil_div(psi2_consts_layout(M, Q).Ppad, PSI2_PAIR_ROWS_PER_BLOCK);
+    const int first_gram = blocks, tm = dpgp_ceil_div(M, GRAM_T);
+    blocks += D * tm * tm;
+    const int first_scale = blocks;                     // pair_scale != nullptr: D x ceil(Ppad / 256) more blocks
+    if (pair_scale) blocks += D * dpgp_ceil_div(psi2_consts_layout(M, Q).Ppad, 256);
+    const size_t lds = sizeof(TL) * 2 * GRAM_T * (Q + 1);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((elbo_front_kernel<TL>), dim3(blocks), dim3(256), lds, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out,
+                       z, M, psi2_consts, first_consts, first_gram, gamma, alpha, beta, (TL)jitter, kuu, ld_kuu, kuu_stride,
+                       first_scale, pair_scale);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+template int launch_elbo_front<float>(int, int, const double *, const double *, double *, int, const double *, int, double *,
+                                      const double *, int, unsigned char *, const double *, const double *, const double *,
+                                      double, float *, int, size_t, float *, hipStream_t);
+template int launch_elbo_front<double>(int, int, const double *, const double *, double *, int, const double *, int, double *,
+                                       const double *, int, unsigned char *, const double *, const double *, const double *,
+                                       double, double *, int, size_t, float *, hipStream_t);
 
 template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,

@@ -22,6 +22,12 @@ int launch_psi1T_y_partial(int B, int N, int M, int Q, const TIN *z, const TIN *
 template <typename TIN>
 int launch_kl_yy(int N, int Q, const TIN *mu, const TIN *s, double *kl_out, int D, const TIN *y, int ldy,
                  double *yy_out, const TIN *z, int M, unsigned char *psi2_consts, hipStream_t st);
+// the same roles plus the K_uu + jitter I tiles of all D output dims in ONE launch (the front launch of the fused ELBO)
+template <typename TL>
+int launch_elbo_front(int N, int Q, const double *mu, const double *s, double *kl_out, int D, const double *y, int ldy,
+                      double *yy_out, const double *z, int M, unsigned char *psi2_consts, const double *gamma,
+                      const double *alpha, const double *beta, double jitter, TL *kuu, int ld_kuu, size_t kuu_stride,
+                      float *pair_scale, hipStream_t st);   // pair_scale != nullptr: also the pair-scale table (psi2_consts.h)
 // psi2_consts != nullptr: the same launch also builds the z-only constants of the f16 psi2 kernel (psi2_consts.h) from
 // z[M,Q] into psi2_consts (psi2_consts_bytes(M, Q) bytes)
 

@@ -1839,8 +1839,9 @@ static int launch_psi2_f16_kb(int B, int N, int M, int Q, const TIN *z, const TI
 
 // psi2_pairs.hip: the pair-tile kernel (fp32 results; the default)
 template <typename TIN>
-int launch_psi2_pairs(int B, int N, int M, int Q, const TIN *mu, const TIN *s, const TIN *gamma, const TIN *alpha,
-                      float *part, int ns, const ChainKTask &task, const unsigned char *consts, float *scale, hipStream_t st);
+int launch_psi2_pairs(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                      const TIN *alpha, float *part, int ns, const ChainKTask &task, const unsigned char *consts, float *scale,
+                      int scale_ready, hipStream_t st);
 template <typename TIN, typename T> struct Psi2PairsDispatch {
     static int run(int, int, int, int, const TIN *, const TIN *, const TIN *, const TIN *, const TIN *, T *, int,
                    const ChainKTask &, unsigned char *, int, float *, hipStream_t) {
@@ -1856,7 +1857,8 @@ template <typename TIN> struct Psi2PairsDispatch<TIN, float> {
             const int rc = launch_psi2_consts<TIN>(z, M, Q, consts, st);
             if (rc) return rc;
         }
-        return launch_psi2_pairs<TIN>(B, N, M, Q, mu, s, gamma, alpha, part, ns, task, consts, pair_scale, st);
+        // consts_ready > 1: the caller's front launch has also filled the pair-scale table
+        return launch_psi2_pairs<TIN>(B, N, M, Q, z, mu, s, gamma, alpha, part, ns, task, consts, pair_scale, consts_ready > 1, st);
     }
 };
 

@@ -21,9 +21,8 @@ struct Psi2Consts {
     // path of the texture unit, not the arithmetic, set the kernel's pace).
     int KS, SLP, P, Ppad;
     size_t off_pairs;
-    // per pair, for the kernel's epilogue: pmap[p] = m << 16 | m' (0xffffffff for p >= P) and the squared differences
-    // dz2[q][p] = (z_mq - z_m'q)^2 (fp32, [Q][Ppad]), from which the per-output factor alpha^2 exp2(beta_p) is formed
-    size_t off_pmap, off_dz2;
+    // per pair, for the kernel's epilogue: pmap[p] = m << 16 | m' (0xffffffff for p >= P)
+    size_t off_pmap;
 };
 // K-steps of 16 slots that hold the 6Q + 2 slots of a row; only these instantiations of the kernel exist
 __host__ __device__ inline int psi2_pairs_ksteps(int Q) {
@@ -44,8 +43,7 @@ __host__ __device__ inline Psi2Consts psi2_consts_layout(int M, int Q) {
     c.P = (int)((long long)M * (M + 1) / 2);
     c.Ppad = (c.P + 31) & ~31;
     c.off_pmap = (c.off_pairs + sizeof(_Float16) * (size_t)c.Ppad * c.SLP + 255) & ~(size_t)255;
-    c.off_dz2 = (c.off_pmap + sizeof(unsigned) * (size_t)c.Ppad + 255) & ~(size_t)255;
-    c.bytes = (c.off_dz2 + sizeof(float) * (size_t)Q * c.Ppad + 255) & ~(size_t)255;
+    c.bytes = (c.off_pmap + sizeof(unsigned) * (size_t)c.Ppad + 255) & ~(size_t)255;
     return c;
 }
 
@@ -109,46 +107,69 @@ __device__ __forceinline__ void psi2_pair_rows(const TIN *__restrict__ z, int M,
     const int t = threadIdx.x, wpr = c.SLP / 2;                  // 32-bit words per row
     unsigned *img = reinterpret_cast<unsigned *>(dst + c.off_pairs);
     const int p0 = PSI2_PAIR_ROWS_PER_BLOCK * blk;
-    if (p0 + t < c.Ppad) {                                       // thread = pair: index map and squared differences
+    if (p0 + t < c.Ppad) {                                       // thread = pair: index map
         const int p = p0 + t;
         int m = 0, mp = 0;
         if (p < c.P) psi2_pair_of(p, m, mp);
         reinterpret_cast<unsigned *>(dst + c.off_pmap)[p] = (p < c.P) ? ((unsigned)m << 16 | (unsigned)mp) : 0xffffffffu;
-        float *dz2 = reinterpret_cast<float *>(dst + c.off_dz2);
-        for (int q = 0; q < Q; ++q) {
-            const float d = (p < c.P) ? (float)((double)z[(size_t)m * Q + q] - (double)z[(size_t)mp * Q + q]) : 0.0f;
-            dz2[(size_t)q * c.Ppad + p] = d * d;
-        }
     }
-    for (int e = t; e < PSI2_PAIR_ROWS_PER_BLOCK * wpr; e += 256) {
-        const int r = e / wpr, w = e - r * wpr, p = p0 + r;
-        if (p >= c.Ppad) break;
-        int m = 0, mp = 0;
-        if (p < c.P) psi2_pair_of(p, m, mp);
-        _Float16 h2[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int slot = 2 * w + i;
-            float val = 0.0f;
-            if (p < c.P) {
-                if (slot < 6 * Q) {
-                    const int tt = slot / 3, part = slot - 3 * tt, q = tt >> 1;
-                    const float sq = ((float)z[(size_t)m * Q + q] - zc[q]) + ((float)z[(size_t)mp * Q + q] - zc[q]);
-                    // s^2 / 64 against 64 a on the other side: a = -1/4 w log2e is ~0.1, its f16 lo piece would be an f16
-                    // subnormal (resolution 2^-24: only ~11 + 7 bits of a); balanced, both lo pieces are normal numbers
-                    const float v = dpgp_pin((tt & 1) ? sq : sq * sq * PSI2_PAIR_S2_SCALE);   // (see dpgp_pin)
-                    const _Float16 h = (_Float16)v;
-                    val = (part == 1) ? (float)(_Float16)(v - (float)h) : (float)h;
-                } else if (slot < 6 * Q + 2 || (slot == 6 * Q + 2 && slot < c.SLP)) {
-                    val = 1.0f;                                  // (third slot: the third f16 piece of the row constant c'')
-                }
-            }
-            h2[i] = (_Float16)val;
-        }
-        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-        const h2v hv = {h2[0], h2[1]};
-        // word w of pair p holds slots 2w, 2w + 1: K-step ks = w / 8, operand half (w % 8) / 4, word (w % 4) of the lane's four
+    // item = (pair r of the block, latent dim q; q == Q: the tail words): the six slots {h, l, h | h, l, h} of (s_q^2 / 64, s_q)
+    // are the three words 3q .. 3q + 2 of the pair, written in operand order (layout: struct Psi2Consts)
+    auto put = [&](int p, int w, unsigned word) {
         const int ks = w >> 3, hf = (w >> 2) & 1, wi = w & 3, lane = 32 * hf + (p & 31);
-        img[(((size_t)(p >> 5) * c.KS + ks) * 64 + lane) * 4 + wi] = __builtin_bit_cast(unsigned, hv);
+        img[(((size_t)(p >> 5) * c.KS + ks) * 64 + lane) * 4 + wi] = word;
+    };
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    for (int e = t; e < PSI2_PAIR_ROWS_PER_BLOCK * (Q + 1); e += 256) {
+        const int r = e % PSI2_PAIR_ROWS_PER_BLOCK, q = e / PSI2_PAIR_ROWS_PER_BLOCK, p = p0 + r;
+        if (p >= c.Ppad) continue;
+        const bool real = p < c.P;
+        if (q == Q) {                                           // slots 6Q, 6Q + 1 (and 6Q + 2 where it exists) = 1, rest 0
+            const h2v one2 = {(_Float16)1.0f, (_Float16)1.0f}, one1 = {(_Float16)1.0f, (_Float16)0.0f};
+            for (int w = 3 * Q; w < wpr; ++w) {
+                unsigned word = 0u;
+                if (real && w == 3 * Q) word = __builtin_bit_cast(unsigned, one2);
+                if (real && w == 3 * Q + 1 && 6 * Q + 2 < c.SLP) word = __builtin_bit_cast(unsigned, one1);
+                put(p, w, word);
+            }
+            continue;
+        }
+        unsigned w0 = 0u, w1 = 0u, w2 = 0u;
+        if (real) {
+            int m, mp;
+            psi2_pair_of(p, m, mp);
+            const float sq = ((float)z[(size_t)m * Q + q] - zc[q]) + ((float)z[(size_t)mp * Q + q] - zc[q]);
+            // s^2 / 64 against 64 a on the other side keeps both f16 lo pieces well inside the normal range
+            const float f1 = dpgp_pin(sq * sq * PSI2_PAIR_S2_SCALE), f2 = dpgp_pin(sq);     // (pinned: see dpgp_pin)
+            const _Float16 f1h = (_Float16)f1, f1l = (_Float16)(f1 - (float)f1h);
+            const _Float16 f2h = (_Float16)f2, f2l = (_Float16)(f2 - (float)f2h);
+            const h2v a = {f1h, f1l}, b = {f1h, f2h}, d = {f2l, f2h};
+            w0 = __builtin_bit_cast(unsigned, a); w1 = __builtin_bit_cast(unsigned, b); w2 = __builtin_bit_cast(unsigned, d);
+        }
+        put(p, 3 * q, w0); put(p, 3 * q + 1, w1); put(p, 3 * q + 2, w2);
     }
+}
+
+// scale[b][p] = alpha_b^2 exp2(beta_bp),  beta_bp = -1/4 log2e sum_q gamma_bq (z_mq - z_m'q)^2: the per-output factor of every
+// pair of the pair-tile psi2 kernel (applied once per column sum instead of once per exponent); 256 pairs per block, thread =
+// pair, straight from z (no dependency on the other constants).  Runs as extra blocks of the front launch of the fused ELBO,
+// or as a launch of its own (psi2_pairs.hip).
+template <typename TIN, typename TG>
+__device__ __forceinline__ void psi2_pair_scale_block(int b, int pblk, int M, int Q, const TIN *__restrict__ z,
+                                                      const TG *__restrict__ gamma, const TG *__restrict__ alpha,
+                                                      float *__restrict__ scale) {
+    const int P = (int)((long long)M * (M + 1) / 2), Ppad = (P + 31) & ~31;
+    const int p = pblk * 256 + (int)threadIdx.x;
+    if (p >= Ppad) return;
+    float bsum = 0.0f;
+    if (p < P) {
+        int m, mp;
+        psi2_pair_of(p, m, mp);
+        for (int q = 0; q < Q; ++q) {
+            const float d = (float)((double)z[(size_t)m * Q + q] - (double)z[(size_t)mp * Q + q]);
+            bsum += (float)gamma[(size_t)b * Q + q] * d * d;
+        }
+    }
+    const float al = (float)alpha[b];
+    scale[(size_t)b * Ppad + p] = al * al * __builtin_amdgcn_exp2f((float)(-0.25 * DPGP_LOG2E) * bsum);
 }

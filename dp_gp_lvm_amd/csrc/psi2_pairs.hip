@@ -161,18 +161,11 @@ __device__ __forceinline__ void pairs_group(int tb, const _Float16 *__restrict__
     }
 }
 
-// scale[b][p] = alpha_b^2 exp2(beta_bp),  beta_bp = -1/4 log2e sum_q gamma_bq (z_mq - z_m'q)^2: the per-output factor of
-// every pair (applied once per column sum instead of once per exponent); thread = pair, block row = output dim
 template <typename TIN>
-__global__ __launch_bounds__(256) void psi2_pair_scale_kernel(int B, int Q, int Ppad, const float *__restrict__ dz2,
+__global__ __launch_bounds__(256) void psi2_pair_scale_kernel(int M, int Q, const TIN *__restrict__ z,
                                                               const TIN *__restrict__ gamma, const TIN *__restrict__ alpha,
                                                               float *__restrict__ scale) {
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= Ppad) return;
-    float bsum = 0.0f;
-    for (int q = 0; q < Q; ++q) bsum += (float)gamma[(size_t)b * Q + q] * dz2[(size_t)q * Ppad + p];
-    const float al = (float)alpha[b];
-    scale[(size_t)b * Ppad + p] = al * al * __builtin_amdgcn_exp2f((float)(-0.25 * DPGP_LOG2E) * bsum);
+    psi2_pair_scale_block<TIN, TIN>((int)blockIdx.y, (int)blockIdx.x, M, Q, z, gamma, alpha, scale);
 }
 
 template <typename TIN, int KS>
@@ -334,14 +327,14 @@ size_t psi2_pairs_scale_bytes(int B, int M) {
     return dpgp_align256(sizeof(float) * (size_t)B * ppad);
 }
 template <typename TIN>
-int launch_psi2_pairs(int B, int N, int M, int Q, const TIN *mu, const TIN *s, const TIN *gamma, const TIN *alpha,
-                      float *part, int ns, const ChainKTask &task, const unsigned char *consts, float *scale,
-                      hipStream_t st) {
+int launch_psi2_pairs(int B, int N, int M, int Q, const TIN *z, const TIN *mu, const TIN *s, const TIN *gamma,
+                      const TIN *alpha, float *part, int ns, const ChainKTask &task, const unsigned char *consts, float *scale,
+                      int scale_ready, hipStream_t st) {
     if (!consts || !scale) return -18;
-    {
+    if (!scale_ready) {        // (the fused ELBO builds the table in its front launch)
         const Psi2Consts C = psi2_consts_layout(M, Q);
-        DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_pair_scale_kernel<TIN>), dim3(dpgp_ceil_div(C.Ppad, 256), B), dim3(256), 0, st, B, Q,
-                           C.Ppad, reinterpret_cast<const float *>(consts + C.off_dz2), gamma, alpha, scale);
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi2_pair_scale_kernel<TIN>), dim3(dpgp_ceil_div(C.Ppad, 256), B), dim3(256), 0, st, M, Q, z,
+                           gamma, alpha, scale);
         DPGP_LAUNCH_CHECK();
     }
     size_t chain_lds = 0;
@@ -357,7 +350,9 @@ int launch_psi2_pairs(int B, int N, int M, int Q, const TIN *mu, const TIN *s, c
     }
     return -4;
 }
-template int launch_psi2_pairs<float>(int, int, int, int, const float *, const float *, const float *, const float *, float *,
-                                      int, const ChainKTask &, const unsigned char *, float *, hipStream_t);
+template int launch_psi2_pairs<float>(int, int, int, int, const float *, const float *, const float *, const float *,
+                                      const float *, float *, int, const ChainKTask &, const unsigned char *, float *, int,
+                                      hipStream_t);
 template int launch_psi2_pairs<double>(int, int, int, int, const double *, const double *, const double *, const double *,
-                                       float *, int, const ChainKTask &, const unsigned char *, float *, hipStream_t);
+                                       const double *, float *, int, const ChainKTask &, const unsigned char *, float *, int,
+                                       hipStream_t);

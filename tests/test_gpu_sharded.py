@@ -60,8 +60,11 @@ def test_two_ranks_equal_one(dev, tmp_path, prec):
         for k, want in grads1.items():
             np.testing.assert_allclose(r['grad_' + k], want, rtol=0, atol=1e3 * tol * max(np.abs(want).max(), 1e-300), err_msg=k)
         assert int(r['descended']) == 1
-        np.testing.assert_allclose(float(r['after']), after1, rtol=1e-7)
-        np.testing.assert_allclose(r['x_u_after'], xu1, rtol=0, atol=1e-7 * np.abs(xu1).max())
+        # (five Adam steps amplify the last-bit differences of the gradients; in mixed precision the number of n-splits — the
+        #  association of the fp32 partial sums — depends on how many output dims a rank holds)
+        loose = 1e-7 if prec == 'f64' else 2e-6
+        np.testing.assert_allclose(float(r['after']), after1, rtol=loose)
+        np.testing.assert_allclose(r['x_u_after'], xu1, rtol=0, atol=loose * np.abs(xu1).max())
     np.testing.assert_array_equal(ranks[0]['x_u_after'], ranks[1]['x_u_after'])      # replicas stay bit-identical
 
 
