@@ -50,30 +50,43 @@ template <int KS> struct PairsCfg { static constexpr int G = PP_G(KS); };
 #define PP_SCALAR_ADD 1            // 1: the 16 accumulations per tile as v_add_f32 (inline asm keeps the compiler from packing
 #endif                             //    them into v_pk_add_f32, which costs more issue time beside MFMAs: MI355X guide)
 
-// GG pair tiles tb, tb + 4, ... of one wave against the ntile row tiles of the A image in LDS.  The GG column operands stay in
-// registers; the exponent tiles alternate between two result registers sets (c0, c1): the MFMA chain of the next tile is
-// issued before the exponentials of the current one are evaluated.  GG is even or 1.
+// the column operands of GG pair tiles tb, tb + 4, ...: operand order (psi2_consts.h), 64 lanes x 16 bytes contiguous per
+// (tile, K-step)
 template <int KS, int GG>
-__device__ __forceinline__ void pairs_group(int tb, const _Float16 *__restrict__ aimg, const _Float16 *__restrict__ img,
-                                            const unsigned *__restrict__ pmap, const float *__restrict__ scale, int ntile,
-                                            int l5, int half, float poison, float *__restrict__ out, int Mp, int chunk) {
-    constexpr int SLP = 16 * KS, LDA = SLP + PP_APAD;
-    static_assert(GG == 1 || (GG & 1) == 0, "ping-pong needs an even number of resident tiles");
-    pp_h8 bop[GG][KS];
+__device__ __forceinline__ void pairs_load(pp_h8 (&bop)[GG][KS], int tb, const _Float16 *__restrict__ img, int l5, int half) {
 #pragma unroll
     for (int g = 0; g < GG; ++g) {
-        // operand order (psi2_consts.h): 64 lanes x 16 bytes contiguous per (tile, K-step)
         const pp_h8 *row = reinterpret_cast<const pp_h8 *>(img) + (size_t)(tb + 4 * g) * KS * 64 + 32 * half + l5;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bop[g][ks] = row[ks * 64];
     }
-    // the epilogue's per-pair data (index map, alpha^2 exp2(beta_p) of this output dim): fetched now, used after the row loop
+}
+
+// GG pair tiles tb, tb + 4, ... of one wave against the ntile row tiles of the A image in LDS.  The GG column operands stay in
+// registers; the exponent tiles alternate between two result registers sets (c0, c1): the MFMA chain of the next tile is
+// issued before the exponentials of the current one are evaluated.  GG is even or 1.
+// bop: the operands of this group (pairs_load); tb_next >= 0: the operands of the group at tb_next are fetched into bop as soon
+// as the last MFMA of this group has been issued, i.e. beneath this group's epilogue.
+template <int KS, int GG>
+__device__ __forceinline__ void pairs_group(int tb, pp_h8 (&bop)[GG][KS], int tb_next, const _Float16 *__restrict__ aimg,
+                                            const _Float16 *__restrict__ img,
+                                            const unsigned *__restrict__ pmap, const float *__restrict__ scale, int ntile,
+                                            int l5, int half, float poison, float *__restrict__ out, int Mp, int chunk) {
+    constexpr int SLP = 16 * KS, LDA = SLP + PP_APAD;
+    static_assert(GG == 1 || (GG & 1) == 0, "ping-pong needs an even number of resident tiles");
+    // the epilogue's per-pair data (index map, alpha^2 exp2(beta_p) of this output dim, the sum of the earlier chunks): fetched
+    // now, used after the row loop
     unsigned pm[GG];
-    float sc[GG];
+    float sc[GG], old[GG];
 #pragma unroll
     for (int g = 0; g < GG; ++g) {
         pm[g] = pmap[32 * (tb + 4 * g) + l5];
         sc[g] = scale[32 * (tb + 4 * g) + l5];
+    }
+#pragma unroll
+    for (int g = 0; g < GG; ++g) {
+        old[g] = 0.0f;
+        if (chunk && pm[g] != 0xffffffffu && half == 0) old[g] = out[(size_t)(pm[g] >> 16) * Mp + (pm[g] & 0xffffu)];
     }
     float acc[GG][4];
 #pragma unroll
@@ -148,16 +161,14 @@ __device__ __forceinline__ void pairs_group(int tb, const _Float16 *__restrict__
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
     }
+    if (tb_next >= 0) pairs_load<KS, GG>(bop, tb_next, img, l5, half);
     // ---- column sums: add the lane halves, scale by alpha^2 exp2(beta_p), store (first chunk) or accumulate ----
 #pragma unroll
     for (int g = 0; g < GG; ++g) {
         float tot = (acc[g][0] + acc[g][1]) + (acc[g][2] + acc[g][3]);
         tot += __shfl_xor(tot, 32, 64);
-        if (pm[g] != 0xffffffffu && half == 0) {
-            const float val = sc[g] * tot + poison;                 // (poison: 0, or NaN after a range-guard hit)
-            float *o = out + (size_t)(pm[g] >> 16) * Mp + (pm[g] & 0xffffu);
-            *o = chunk ? *o + val : val;
-        }
+        if (pm[g] != 0xffffffffu && half == 0)                      // (poison: 0, or NaN after a range-guard hit)
+            out[(size_t)(pm[g] >> 16) * Mp + (pm[g] & 0xffffu)] = old[g] + (sc[g] * tot + poison);
     }
 }
 
@@ -254,13 +265,26 @@ __global__ __launch_bounds__(256, PP_WAVES) void psi2_pairs_kernel(int N, int M,
 
         // ---- the wave's pair tiles: groups of G, the remainder in groups of 2 and 1 ----
         int tb = t0 + wv;
-        for (; tb + 4 * (G - 1) < t1; tb += 4 * G)
-            pairs_group<KS, G>(tb, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
+        if (tb + 4 * (G - 1) < t1) {
+            pp_h8 bop[G][KS];
+            pairs_load<KS, G>(bop, tb, img, l5, half);
+            for (; tb + 4 * (G - 1) < t1; tb += 4 * G) {
+                const int nx = tb + 4 * G;
+                pairs_group<KS, G>(tb, bop, nx + 4 * (G - 1) < t1 ? nx : -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out,
+                                   Mp, chunk);
+            }
+        }
         if constexpr (G > 2)
-            for (; tb + 4 < t1; tb += 8)
-                pairs_group<KS, 2>(tb, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
-        for (; tb < t1; tb += 4)
-            pairs_group<KS, 1>(tb, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
+            for (; tb + 4 < t1; tb += 8) {
+                pp_h8 bop[2][KS];
+                pairs_load<KS, 2>(bop, tb, img, l5, half);
+                pairs_group<KS, 2>(tb, bop, -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
+            }
+        for (; tb < t1; tb += 4) {
+            pp_h8 bop[1][KS];
+            pairs_load<KS, 1>(bop, tb, img, l5, half);
+            pairs_group<KS, 1>(tb, bop, -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
+        }
     }
 }
 
