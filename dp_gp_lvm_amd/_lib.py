@@ -16,6 +16,7 @@ ALGO = {'auto': 0, 'plain': 1, 'mfma_f32': 2, 'patch_f16': 3}
 PREC = {'f32': 0, 'mixed': 1, 'f64': 2}
 
 _vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+_ll = ctypes.c_longlong
 
 # name -> (restype, argtypes); one entry per symbol declared in include/dpgp.h
 SIGNATURES = {
@@ -46,6 +47,7 @@ SIGNATURES = {
     'dpgp_model_backward': (_i, [_i] * 8 + [_vp] * 10 + [_d, _d, _i] + [_vp] * 15 + [_vp]),
     'dpgp_model_pack': (_i, [_i, _vp, _vp, _vp, _vp]),
     'dpgp_model_finalize': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'dpgp_gemm_strided_f64': (_i, [_i, _i, _i, _i, _d, _vp, _ll, _ll, _ll, _vp, _ll, _ll, _ll, _d, _vp, _ll, _ll, _ll, _vp]),
 }
 for _t in ('f32', 'f64'):
     SIGNATURES.update({

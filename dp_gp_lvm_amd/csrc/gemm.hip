@@ -1,0 +1,97 @@
+// Strided batched fp64 matrix product on the matrix cores: C[b] = alpha A[b] B[b] + beta C[b] with element strides for every
+// index, so that a transposed, sliced or broadcast operand is a choice of strides and no copy.  It carries the plain products
+// of the composed models — the places where the reference calls tf.matmul on [D,M,M] / [T,M,N] x [N,D] operands
+// (/root/reference/src/models/dp_gp_lvm.py:657-658 Psi1^T Y of the over-T model; :640-676 its chain; the prediction bound
+// gaussian_process.py / dp_gp_lvm.py:300-420) and the adjoint algebra of the backward pass for M > 128 (B^-1 = L^-T L^-1,
+// K^-1 Psi2 K^-1): sizes of a few hundred, batches of 8 .. 512.
+//
+// Workgroup = one 64 x 64 tile of C for one batch element, 4 waves x (16 rows x 64 columns = 4 v_mfma_f64_16x16x4 tiles);
+// K is staged 32 at a time through LDS as As[i][k], Bs[j][k] (k contiguous, row stride 36 doubles: conflict-free operand
+// reads); the staging loop runs along whichever index is contiguous in memory.  Bounded by the fp64 matrix pipe only for
+// large K; at the sizes above a launch is a few microseconds of latency.
+#include "internal.h"
+#include "linalg_dev.h"
+
+#define CHECK_ARG(cond, idx) \
+    do {                     \
+        if (!(cond)) return -(idx); \
+    } while (0)
+
+#define GM_T 64
+#define GM_KC 32
+#define GM_LD (GM_KC + 4)
+
+template <bool KFAST>
+__device__ __forceinline__ void gm_stage(const double *__restrict__ g, long long si, long long sk, int i0, int imax, int k0,
+                                         int kmax, double *__restrict__ s) {
+    for (int e = threadIdx.x; e < GM_T * GM_KC; e += 256) {
+        int i, k;
+        if (KFAST) { i = e / GM_KC; k = e % GM_KC; } else { k = e / GM_T; i = e % GM_T; }
+        double v = 0.0;
+        if (i0 + i < imax && k0 + k < kmax) v = g[(long long)(i0 + i) * si + (long long)(k0 + k) * sk];
+        s[i * GM_LD + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_strided_f64_kernel(int batch, int m, int n, int k, double alpha,
+                                                                  const double *__restrict__ a, long long a_sb, long long a_si,
+                                                                  long long a_sk, const double *__restrict__ b, long long b_sb,
+                                                                  long long b_sk, long long b_sj, double beta,
+                                                                  double *__restrict__ c, long long c_sb, long long c_si,
+                                                                  long long c_sj) {
+    __shared__ __align__(16) double As[GM_T * GM_LD], Bs[GM_T * GM_LD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
+    const int i0 = GM_T * blockIdx.y, j0 = GM_T * blockIdx.x;
+    const bool a_kfast = (a_sk == 1), b_kfast = (b_sk == 1);
+    for (int bi = blockIdx.z; bi < batch; bi += gridDim.z) {
+        const double *ab = a + (long long)bi * a_sb, *bb = b + (long long)bi * b_sb;
+        double *cb = c + (long long)bi * c_sb;
+        f64x4 acc[4];
+#pragma unroll
+        for (int J = 0; J < 4; ++J) acc[J] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < k; k0 += GM_KC) {
+            __syncthreads();
+            if (a_kfast) gm_stage<true>(ab, a_si, a_sk, i0, m, k0, k, As);
+            else gm_stage<false>(ab, a_si, a_sk, i0, m, k0, k, As);
+            if (b_kfast) gm_stage<true>(bb, b_sj, b_sk, j0, n, k0, k, Bs);
+            else gm_stage<false>(bb, b_sj, b_sk, j0, n, k0, k, Bs);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < GM_KC / 4; ++ks) {
+                const double av = As[(16 * wv + li) * GM_LD + 4 * ks + kk];
+#pragma unroll
+                for (int J = 0; J < 4; ++J) acc[J] = Mfma<double>::mma(av, Bs[(16 * J + li) * GM_LD + 4 * ks + kk], acc[J]);
+            }
+        }
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = i0 + 16 * wv + Mfma<double>::row(lane, v), col = j0 + 16 * J + li;
+                if (r < m && col < n) {
+                    double *o = cb + (long long)r * c_si + (long long)col * c_sj;
+                    *o = (beta != 0.0) ? alpha * acc[J][v] + beta * *o : alpha * acc[J][v];
+                }
+            }
+    }
+}
+
+extern "C" int dpgp_gemm_strided_f64(int batch, int m, int n, int k, double alpha, const double *a, long long a_sb,
+                                     long long a_si, long long a_sk, const double *b, long long b_sb, long long b_sk,
+                                     long long b_sj, double beta, double *c, long long c_sb, long long c_si, long long c_sj,
+                                     void *stream) {
+    CHECK_ARG(batch >= 1, 1);
+    CHECK_ARG(m >= 1, 2);
+    CHECK_ARG(n >= 1, 3);
+    CHECK_ARG(k >= 0, 4);
+    CHECK_ARG(a != nullptr || k == 0, 6);
+    CHECK_ARG(b != nullptr || k == 0, 10);
+    CHECK_ARG(c != nullptr, 15);
+    const dim3 grid(dpgp_ceil_div(n, GM_T), dpgp_ceil_div(m, GM_T), batch < 65535 ? batch : 65535);
+    CHECK_ARG(grid.y <= 65535u, 2);
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(gemm_strided_f64_kernel, grid, dim3(256), 0, (hipStream_t)stream, batch, m, n, k, alpha, a, a_sb, a_si,
+                       a_sk, b, b_sb, b_sk, b_sj, beta, c, c_sb, c_si, c_sj);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}

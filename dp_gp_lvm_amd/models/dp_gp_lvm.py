@@ -503,16 +503,16 @@ def dp_gp_lvm(y_train,
             c = ops.trsm_batched(l_a, ops.trsm_batched(l_uu, psi_1.transpose(1, 2).contiguous()))          # [Du x M x N]
             c_pred = ops.trsm_batched(l_a, ops.trsm_batched(l_uu, psi_1t.transpose(1, 2).contiguous()))   # [Du x M x N*]
             y_u = _t(np.asarray(y_train)[:, do:]).transpose(0, 1).contiguous()[:, :, None]                 # [Du x N x 1]
-            cy = torch.matmul(c, y_u)                                                # [Du x M x 1]
-            predicted_mean = (bu[:, None] * torch.matmul(c_pred.transpose(1, 2), cy)[:, :, 0]).transpose(0, 1)   # [N* x Du]
+            cy = ops.matmul(c, y_u)                                                # [Du x M x 1]
+            predicted_mean = (bu[:, None] * ops.matmul(c_pred.transpose(1, 2), cy)[:, :, 0]).transpose(0, 1)   # [N* x Du]
             eye = torch.eye(m_, dtype=TORCH_DTYPE, device=device).expand(num_dimensions - do, m_, m_).contiguous()
             l_uu_inv, l_a_inv = ops.trsm_batched(l_uu, eye), ops.trsm_batched(l_a, eye)
-            ainv = torch.matmul(l_a_inv.transpose(1, 2), l_a_inv)                    # A^-1
-            g = psi_2t - torch.matmul(psi_1t.transpose(1, 2), psi_1t)               # [Du x M x M]
-            scale_yu = torch.matmul(torch.matmul(torch.matmul(l_uu_inv.transpose(1, 2), torch.matmul(ainv, l_uu_inv)),
+            ainv = ops.matmul(l_a_inv.transpose(1, 2), l_a_inv)                    # A^-1
+            g = psi_2t - ops.matmul(psi_1t.transpose(1, 2), psi_1t)               # [Du x M x M]
+            scale_yu = ops.matmul(ops.matmul(ops.matmul(l_uu_inv.transpose(1, 2), ops.matmul(ainv, l_uu_inv)),
                                                  psi_1.transpose(1, 2)), y_u)       # [Du x M x 1]
-            yu_var = bu * bu * torch.matmul(scale_yu.transpose(1, 2), torch.matmul(g, scale_yu))[:, 0, 0]
-            tr_term = torch.diagonal(torch.matmul(torch.matmul(l_uu_inv.transpose(1, 2), torch.matmul(eye - ainv, l_uu_inv)),
+            yu_var = bu * bu * ops.matmul(scale_yu.transpose(1, 2), ops.matmul(g, scale_yu))[:, 0, 0]
+            tr_term = torch.diagonal(ops.matmul(ops.matmul(l_uu_inv.transpose(1, 2), ops.matmul(eye - ainv, l_uu_inv)),
                                                   psi_2t), dim1=-2, dim2=-1).sum(-1)
             psi_0t = ops.psi0(num_test_points, au)[:, 0]
             predicted_covar = yu_var[:, None, None] + (psi_0t + 1.0 / bu + tr_term)[:, None, None] * \
@@ -540,7 +540,7 @@ def dp_gp_lvm_t(y_train,
         Psi1 [T,N,M], Psi2 [T,M,M], K_uu [T,M,M]       dpgp_psi1 / dpgp_psi2 / dpgp_ard_rbf_gram      (:611-620)
         L_K, L_B = chol(K), chol(K + beta Psi2)         dpgp_potrf_batched                             (:620,633)
         <K^-1, Psi2> by two triangular solves           dpgp_trsm_batched                              (:622-629)
-        V = Psi1^T Y  [T,M,D]                           one plain fp64 GEMM (rocBLAS through torch.matmul)
+        V = Psi1^T Y  [T,M,D]                           dpgp_gemm_strided_f64 (fp64 MFMA, ops.matmul)
         C = L_B^-1 V, 1/2 sum_td phi_td beta_t^2 |C_td|^2   dpgp_trsm_batched                          (:638-658)
 
     precision: 'f64', or 'mixed' = the Psi statistics in fp32 (f16-split MFMA kernels), everything after them in fp64.
@@ -625,7 +625,7 @@ def dp_gp_lvm_t(y_train,
             tr = torch.diagonal(ops.trsm_batched(l_k, h.transpose(1, 2).contiguous()), dim1=-2, dim2=-1).sum(-1)
             logdet = torch.log(torch.diagonal(l_b, dim1=-2, dim2=-1)).sum(-1) - \
                 torch.log(torch.diagonal(l_k, dim1=-2, dim2=-1)).sum(-1)
-            v = torch.matmul(psi_1.transpose(1, 2), y_dev)                       # [T x M x D]
+            v = ops.matmul(psi_1.transpose(1, 2), y_dev)                       # [T x M x D]
             c = ops.trsm_batched(l_b, v)
             quad = bat[:, None] ** 2 * torch.sum(c * c, dim=1)                   # [T x D]
             per_t = 0.5 * (n_ * torch.log(bat) + bat * (tr - n_ * aat)) - logdet
@@ -640,20 +640,20 @@ def dp_gp_lvm_t(y_train,
             eye = torch.eye(m_, dtype=TORCH_DTYPE, device=device)
             eyes = eye.expand(t_, m_, m_).contiguous()
             li = ops.trsm_batched(l_k, eyes)
-            k_inv = torch.matmul(li.transpose(1, 2), li)
+            k_inv = ops.matmul(li.transpose(1, 2), li)
             li = ops.trsm_batched(l_b, eyes)
-            b_inv = torch.matmul(li.transpose(1, 2), li)
+            b_inv = ops.matmul(li.transpose(1, 2), li)
             st = phit.sum(dim=1)[:, None, None]                                  # s_t = sum_d phi_td
             be = bat[:, None, None]
-            w = torch.matmul(b_inv, v)                                           # [T x M x D]
+            w = ops.matmul(b_inv, v)                                           # [T x M x D]
             wphi = w * phit[:, None, :]
             vwphi = torch.sum(v * wphi, dim=(1, 2))                              # sum_d phi_td v_td^T B^-1 v_td
-            gb = -0.5 * st * b_inv - 0.5 * be * be * torch.matmul(wphi, w.transpose(1, 2))
-            x = torch.matmul(torch.matmul(k_inv, p2), k_inv)
+            gb = -0.5 * st * b_inv - 0.5 * be * be * ops.matmul(wphi, w.transpose(1, 2))
+            x = ops.matmul(ops.matmul(k_inv, p2), k_inv)
             gk = 0.5 * st * k_inv - 0.5 * st * be * x + gb
             gp = 0.5 * st * be * k_inv + be * gb
             wk = gk * (k_uu - GP_DEFAULT_JITTER * eye)
-            g1 = be * be * torch.matmul(y_dev, wphi.transpose(1, 2))             # [T x N x M] adjoint of Psi1
+            g1 = be * be * ops.matmul(y_dev, wphi.transpose(1, 2))             # [T x N x M] adjoint of Psi1
             pad2 = (0, mp_ - m_, 0, mp_ - m_)
             dmu, ds, dz, dgam = ops.elbo_grad_psi(None, x_u_, x_mean_, s_, gat, aat,
                                                   torch.nn.functional.pad(gp, pad2).contiguous(),

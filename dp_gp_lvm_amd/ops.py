@@ -175,6 +175,43 @@ def trsm_batched(l_, rhs, algo='auto'):
     return x
 
 
+def matmul(a, b, out=None, alpha=1.0, beta=0.0):
+    """tf.matmul on fp64 device tensors of 2 or 3 dimensions (batch broadcast as in TensorFlow / torch.matmul), through the
+    library's strided batched MFMA kernel (dpgp_gemm_strided_f64): transposed or sliced VIEWS are passed by their strides, no
+    copies and no rocBLAS.  The reference's call sites: dp_gp_lvm.py:657-658 and the composed chains around it.
+    out (optional, [batch, m, n] or [m, n]): out = alpha a b + beta out."""
+    f64 = torch.float64
+    for t, name in ((a, 'a'), (b, 'b')):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != f64:
+            raise TypeError('%s must be a float64 tensor on the GPU (dp_gp_lvm_amd has no host path)' % name)
+        if t.dim() not in (2, 3):
+            raise ValueError('%s must have 2 or 3 dimensions' % name)
+    m, k, n = a.shape[-2], a.shape[-1], b.shape[-1]
+    if b.shape[-2] != k:
+        raise ValueError('inner dimensions differ: %s x %s' % (tuple(a.shape), tuple(b.shape)))
+    ba = a.shape[0] if a.dim() == 3 else 1
+    bb = b.shape[0] if b.dim() == 3 else 1
+    if ba != bb and ba != 1 and bb != 1:
+        raise ValueError('batch dimensions differ: %s x %s' % (tuple(a.shape), tuple(b.shape)))
+    batch = max(ba, bb)
+    three = a.dim() == 3 or b.dim() == 3
+    if out is None:
+        if beta != 0.0:
+            raise ValueError('beta needs out')
+        out = torch.empty((batch, m, n) if three else (m, n), dtype=f64, device=a.device)
+    else:
+        assert out.dtype == f64 and out.is_cuda and tuple(out.shape) == ((batch, m, n) if three else (m, n))
+    if m == 0 or n == 0:
+        return out
+    a_sb = a.stride(0) if (a.dim() == 3 and ba > 1) else 0
+    b_sb = b.stride(0) if (b.dim() == 3 and bb > 1) else 0
+    c_sb = out.stride(0) if three else 0
+    _lib.check(_lib.lib().dpgp_gemm_strided_f64(batch, m, n, k, float(alpha), a.data_ptr(), a_sb, a.stride(-2), a.stride(-1),
+                                                b.data_ptr(), b_sb, b.stride(-2), b.stride(-1), float(beta), out.data_ptr(),
+                                                c_sb, out.stride(-2), out.stride(-1), _stream()), 'dpgp_gemm_strided_f64')
+    return out
+
+
 def kl_qx(mu, s):
     """calculate_kl_divergence_standard_prior -> 0-d fp64 tensor  (gp_expressions.py:10-24)."""
     dt = _dtype_of(mu)
@@ -274,7 +311,7 @@ def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None):
 def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma):
     """Stage A for M > 128 (first version): the same adjoints as chain_grad_kernel (grad.hip), with B^-1 and K^-1 formed
     explicitly from the library's Cholesky factors — L^-1 by dpgp_trsm_batched on the identity, the M x M products as plain
-    fp64 GEMMs (rocBLAS through torch.matmul), element-wise work in torch.  Reads Psi2, Psi1^T y and y^T y from the
+    fp64 GEMMs (the library's strided MFMA kernel, ``matmul`` above), element-wise work in torch.  Reads Psi2, Psi1^T y and y^T y from the
     workspace of the forward evaluation (dpgp_elbo_workspace_layout); K_uu is rebuilt (one gram launch).
         G_B = -1/2 B^-1 - 1/2 beta^2 w w^T,  w = B^-1 v;   G_K = 1/2 K^-1 - 1/2 beta K^-1 P K^-1 + G_B;
         G_P = 1/2 beta K^-1 + beta G_B;   G_v = beta^2 w;   d/dalpha, d/dbeta complete (see chain_grad_kernel)."""
@@ -294,13 +331,13 @@ def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma):
     l_k, info_k = potrf_batched(k_uu)
     l_b, info_b = potrf_batched(k_uu + beta[:, None, None] * p2)
     li = trsm_batched(l_k, eye)
-    k_inv = torch.matmul(li.transpose(1, 2), li)
+    k_inv = matmul(li.transpose(1, 2), li)
     li = trsm_batched(l_b, eye)
-    b_inv = torch.matmul(li.transpose(1, 2), li)
+    b_inv = matmul(li.transpose(1, 2), li)
     del li
-    w = torch.matmul(b_inv, v[:, :, None])[:, :, 0]
+    w = matmul(b_inv, v[:, :, None])[:, :, 0]
     vw = torch.sum(v * w, dim=1)
-    x = torch.matmul(torch.matmul(k_inv, p2), k_inv)
+    x = matmul(matmul(k_inv, p2), k_inv)
     be = beta[:, None, None]
     gb = -0.5 * b_inv - 0.5 * be * be * w[:, :, None] * w[:, None, :]
     gk = 0.5 * k_inv - 0.5 * be * x + gb

@@ -116,6 +116,16 @@ int dpgp_trsm_batched_f32(int B, int M, int K, const float *l, float *rhs, void 
 int dpgp_trsm_batched_f64(int B, int M, int K, const double *l, double *rhs, void *ws, size_t ws_bytes, int algo,
                           void *stream);
 
+/* ---- strided batched matrix product, fp64, on the matrix cores:  C[b] = alpha A[b] B[b] + beta C[b],
+ *      A[b][i][k] = a[b a_sb + i a_si + k a_sk],  B[b][k][j] = b[b b_sb + k b_sk + j b_sj],  C likewise (element strides:
+ *      a transposed, sliced or batch-broadcast (stride 0) operand is a choice of strides).  m x k times k x n, batch >= 1.
+ *      Replaces the tf.matmul call sites of the composed models: Psi1^T Y of the over-T objective
+ *      (/root/reference/src/models/dp_gp_lvm.py:657-658), the prediction bound (dp_gp_lvm.py:300-420) and the adjoint
+ *      algebra of their backward passes.  beta == 0: C is not read.  Returns -(argument index) on a bad argument. */
+int dpgp_gemm_strided_f64(int batch, int m, int n, int k, double alpha, const double *a, long long a_sb, long long a_si,
+                          long long a_sk, const double *b, long long b_sb, long long b_sk, long long b_sj, double beta,
+                          double *c, long long c_sb, long long c_si, long long c_sj, void *stream);
+
 /* ---- calculate_kl_divergence_standard_prior (gp_expressions.py:10-24): out[1] (fp64) */
 int dpgp_kl_qx_f32(int N, int Q, const float *mu, const float *s, double *out, void *stream);
 int dpgp_kl_qx_f64(int N, int Q, const double *mu, const double *s, double *out, void *stream);

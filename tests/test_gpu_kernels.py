@@ -219,3 +219,51 @@ def test_operators_refuse_cpu_tensors():
     with pytest.raises(RuntimeError):
         ops.ard_rbf_gram(x, None, torch.ones(1, 2, dtype=torch.float64), torch.ones(1, 1, dtype=torch.float64),
                          torch.ones(1, 1, dtype=torch.float64))
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 7, 4), (8, 128, 128, 128), (2, 70, 33, 129), (4, 200, 1, 65), (1, 64, 64, 0),
+                                   (5, 1, 96, 31)])
+def test_matmul_strided_views_match_numpy(dev, shape):
+    """dpgp_gemm_strided_f64 (the tf.matmul call sites of the composed models: dp_gp_lvm.py:657-658 and around) on plain,
+    transposed, sliced and batch-broadcast views; fp64 against numpy's matmul of the same views (rtol 1e-13 of the row
+    norms: the MFMA accumulates in a different order)."""
+    b, m, n, k = shape
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((b, m, max(k, 1)))[:, :, :k]
+    bm = rng.standard_normal((b, max(k, 1), n))[:, :k, :]
+    ta, tb = T(np.ascontiguousarray(a), torch.float64, dev), T(np.ascontiguousarray(bm), torch.float64, dev)
+
+    def check(x, y, xn, yn):
+        got = ops.matmul(x, y).cpu().numpy()
+        want = np.matmul(xn, yn)
+        scale = np.abs(xn).sum(-1, keepdims=True).max() * max(np.abs(yn).max(), 1.0) if k else 1.0
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-13 * max(scale, 1.0))
+
+    check(ta, tb, a, bm)
+    # transposed views (k-fastest / i-fastest staging on either side)
+    at = T(np.ascontiguousarray(a.transpose(0, 2, 1)), torch.float64, dev)
+    bt = T(np.ascontiguousarray(bm.transpose(0, 2, 1)), torch.float64, dev)
+    check(at.transpose(1, 2), bt.transpose(1, 2), a, bm)
+    check(at.transpose(1, 2), tb, a, bm)
+    # batch broadcast of a 2-D operand on either side
+    check(ta[0], tb, a[0], bm)
+    check(ta, tb[0], a, bm[0])
+    # sliced (non-contiguous) rows
+    if m >= 4:
+        check(ta[:, ::2, :], tb, a[:, ::2, :], bm)
+    # out = alpha a b + beta out
+    if k:
+        out = T(np.ones((b, m, n)), torch.float64, dev)
+        ops.matmul(ta, tb, out=out, alpha=-0.5, beta=2.0)
+        np.testing.assert_allclose(out.cpu().numpy(), -0.5 * np.matmul(a, bm) + 2.0, rtol=0, atol=1e-12 * max(k, 1))
+
+
+def test_matmul_refuses_host_and_fp32_tensors(dev):
+    x = torch.zeros(4, 4, dtype=torch.float64)
+    with pytest.raises(TypeError):
+        ops.matmul(x, x)
+    y = torch.zeros(4, 4, dtype=torch.float32, device=dev)
+    with pytest.raises(TypeError):
+        ops.matmul(y, y)
+    with pytest.raises(ValueError):
+        ops.matmul(torch.zeros(2, 3, dtype=torch.float64, device=dev), torch.zeros(4, 2, dtype=torch.float64, device=dev))
