@@ -368,6 +368,10 @@ def elbo_grad_psi(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, prec='mixed', g
         g_psi1 = _prep(g_psi1, f64, 'g_psi1')
         assert g_psi1.shape == (d, n, g_psi2.shape[1])
     dev = mu.device
+    if prec == 'f64' and m > 128:
+        if g_psi1 is not None:
+            raise ValueError('a full Psi1 adjoint is taken in mixed precision only')
+        return _elbo_grad_psi_f64_blocks(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v)
     l = _lib.lib()
     wsb = l.dpgp_elbo_grad_psi_workspace_bytes(d, n, m, q)
     ws = _ws(wsb, dev)
@@ -379,4 +383,40 @@ def elbo_grad_psi(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, prec='mixed', g
                                        g_psi1.data_ptr() if g_psi1 is not None else None, _lib.PREC[prec], ws.data_ptr(), wsb,
                                        dmu.data_ptr(), ds.data_ptr(), dz.data_ptr(), dg.data_ptr(), _stream()),
                'dpgp_elbo_grad_psi_ex')
+    return dmu, ds, dz, dg
+
+
+def _elbo_grad_psi_f64_blocks(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v):
+    """Stage B in fp64 for M > 128.  The fp64 kernel keeps the M x M adjoint of one output dim in LDS (M <= 128); every term
+    of stage B is a sum over PAIRS of inducing points (Psi2 and K_uu terms) or over single ones (Psi1 term), so the sum is
+    split over the nb (nb - 1) / 2 unordered pairs {I, J} of blocks of <= 64 inducing points: pair {I, J} runs the same
+    kernel on the 128 points z_I, z_J with the adjoint blocks [[G_II / (nb - 1), G_IJ], [G_JI, G_JJ / (nb - 1)]] (a diagonal
+    block and a single point belong to nb - 1 pairs).  Exact in exact arithmetic, fp64 throughout, the same work as one
+    pass over the M x M square; the training configuration (precision='f64', backward_precision='mixed') does not come
+    here — this is the reference-precision check of it."""
+    f64 = torch.float64
+    dev = mu.device
+    d, (n, q), m = gamma.shape[0], mu.shape, z.shape[0]
+    nb = -(-m // 64)
+    blocks = [b.to(dev) for b in torch.tensor_split(torch.arange(m), nb)]
+    wd = 1.0 / (nb - 1)
+    dmu, ds = torch.zeros((n, q), dtype=f64, device=dev), torch.zeros((n, q), dtype=f64, device=dev)
+    dz, dg = torch.zeros((m, q), dtype=f64, device=dev), torch.zeros((d, q), dtype=f64, device=dev)
+    for i in range(nb):
+        for j in range(i + 1, nb):
+            idx = torch.cat([blocks[i], blocks[j]])
+            ni, ms = blocks[i].numel(), idx.numel()
+            mps = 16 * ((ms + 15) // 16)
+            scale = torch.ones((ms, ms), dtype=f64, device=dev)
+            scale[:ni, :ni] = wd
+            scale[ni:, ni:] = wd
+            pad2 = (0, mps - ms, 0, mps - ms)
+            gs = torch.nn.functional.pad(g_psi2[:, idx][:, :, idx] * scale, pad2).contiguous()
+            ws_ = torch.nn.functional.pad(w_kuu[:, idx][:, :, idx] * scale, pad2).contiguous()
+            gvs = torch.nn.functional.pad(g_v[:, idx] * wd, (0, mps - ms)).contiguous() if g_v is not None else None
+            a, b, c, e = elbo_grad_psi(y, z[idx].contiguous(), mu, s, gamma, alpha, gs, ws_, gvs, prec='f64')
+            dmu += a
+            ds += b
+            dz.index_add_(0, idx, c)
+            dg += e
     return dmu, ds, dz, dg

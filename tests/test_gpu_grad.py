@@ -186,8 +186,6 @@ def test_model_gradients_odd_shapes(dev, shape, prec):
     autograd oracle at random raw variables."""
     from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
     n, d, m, q, t, mask = shape
-    if m > 128 and prec == 'f64':
-        pytest.skip('backward pass for M > 128 exists in mixed precision only')
     rng = np.random.default_rng(n + d)
     y = rng.standard_normal((n, d))
     y = (y - y.mean(0)) / y.std(0)
@@ -294,8 +292,10 @@ def test_stage_b_beyond_128_inducing_points(dev, shape):
     dmu, ds, dz, dg = ops.elbo_grad_psi(t(y), t(z), t(mu), t(s), t(gamma), t(alpha), gp, wk, gv, prec='mixed')
     for name, got, want in (('d mu', dmu, ref['d_mu']), ('d S', ds, ref['d_s']), ('d z', dz, ref['d_z']), ('d gamma', dg, ref['d_gamma'])):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=3e-4 * np.abs(want).max(), err_msg=name)
-    with pytest.raises(ValueError):
-        ops.elbo_grad_psi(t(y), t(z), t(mu), t(s), t(gamma), t(alpha), gp, wk, gv, prec='f64')
+    # fp64: the M <= 128 kernel over pairs of 64-point blocks (ops._elbo_grad_psi_f64_blocks)
+    dmu, ds, dz, dg = ops.elbo_grad_psi(t(y), t(z), t(mu), t(s), t(gamma), t(alpha), gp, wk, gv, prec='f64')
+    for name, got, want in (('d mu', dmu, ref['d_mu']), ('d S', ds, ref['d_s']), ('d z', dz, ref['d_z']), ('d gamma', dg, ref['d_gamma'])):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-10 * np.abs(want).max(), err_msg=name + ' (f64)')
 
 
 def _ill_conditioned(g, scale):
