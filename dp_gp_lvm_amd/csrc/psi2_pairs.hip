@@ -319,6 +319,10 @@ static PairsGeom pairs_geom(int B, int N, int M, int Q, int ns, size_t chain_lds
     int nr = dpgp_ceil_div(512, B * ns);
     if (nr > dpgp_ceil_div(tiles, 32)) nr = dpgp_ceil_div(tiles, 32);   // >= 32 tiles (8 per wave) per range
     if (nr < 1) nr = 1;
+    if (const char *e = getenv("DPGP_PP_RANGES")) {             // (experiments only)
+        const int v = atoi(e);
+        if (v >= 1 && v <= tiles) nr = v;
+    }
     g.tiles_per_range = dpgp_ceil_div(tiles, nr);
     g.n_ranges = dpgp_ceil_div(tiles, g.tiles_per_range);
     return g;
