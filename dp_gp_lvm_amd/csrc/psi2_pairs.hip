@@ -46,6 +46,9 @@ typedef float pp_f16v __attribute__((ext_vector_type(16)));
 #endif
 template <int KS> struct PairsCfg { static constexpr int G = PP_G(KS); };
 
+#ifndef PP_DEEP_PREFETCH
+#define PP_DEEP_PREFETCH 1         // groups of two resident tiles fetch their row operands two row tiles ahead
+#endif
 #ifndef PP_SCALAR_ADD
 #define PP_SCALAR_ADD 1            // 1: the 16 accumulations per tile as v_add_f32 (inline asm keeps the compiler from packing
 #endif                             //    them into v_pk_add_f32, which costs more issue time beside MFMAs: MI355X guide)
@@ -140,26 +143,50 @@ __device__ __forceinline__ void pairs_group(int tb, pp_h8 (&bop)[GG][KS], int tb
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    pp_h8 a_cur[KS], a_nxt[KS];
     pp_f16v c0, c1;
-    load_a(a_cur, 0);
-    mma(c0, a_cur, bop[0]);
+    if constexpr (GG == 2 && PP_DEEP_PREFETCH) {
+        // Two resident tiles (Q > 16): the row tile fetched at the top of a step is needed by the step's SECOND stage already,
+        // ~250 cycles later, less than the latency of 8 ds_read_b128 on a busy LDS.  Three operand buffers, fetched two row
+        // tiles ahead, rotated by unrolling the loop three times (no register moves).
+        pp_h8 a0[KS], a1[KS], a2[KS];
+        load_a(a0, 0);
+        load_a(a1, min(1, ntile - 1));
+        mma(c0, a0, bop[0]);
 #pragma unroll 1
-    for (int nt = 0; nt < ntile; ++nt) {
-        load_a(a_nxt, min(nt + 1, ntile - 1));
-        if constexpr (GG == 1) {
-            stage(c1, a_nxt, bop[0], acc[0], c0);                  // (behind the last row tile: one surplus MFMA chain)
-            c0 = c1;
-        } else {
-#pragma unroll
-            for (int g = 0; g < GG; g += 2) {
-                stage(c1, a_cur, bop[g + 1], acc[g], c0);
-                if (g + 2 < GG) stage(c0, a_cur, bop[g + 2], acc[g + 1], c1);
-                else stage(c0, a_nxt, bop[0], acc[g + 1], c1);
-            }
+        for (int nt = 0; nt < ntile; nt += 3) {
+            load_a(a2, min(nt + 2, ntile - 1));
+            stage(c1, a0, bop[1], acc[0], c0);
+            stage(c0, a1, bop[0], acc[1], c1);                     // (behind the last row tile: one surplus MFMA chain)
+            if (nt + 1 >= ntile) break;
+            load_a(a0, min(nt + 3, ntile - 1));
+            stage(c1, a1, bop[1], acc[0], c0);
+            stage(c0, a2, bop[0], acc[1], c1);
+            if (nt + 2 >= ntile) break;
+            load_a(a1, min(nt + 4, ntile - 1));
+            stage(c1, a2, bop[1], acc[0], c0);
+            stage(c0, a0, bop[0], acc[1], c1);
         }
+    } else {
+        pp_h8 a_cur[KS], a_nxt[KS];
+        load_a(a_cur, 0);
+        mma(c0, a_cur, bop[0]);
+#pragma unroll 1
+        for (int nt = 0; nt < ntile; ++nt) {
+            load_a(a_nxt, min(nt + 1, ntile - 1));
+            if constexpr (GG == 1) {
+                stage(c1, a_nxt, bop[0], acc[0], c0);              // (behind the last row tile: one surplus MFMA chain)
+                c0 = c1;
+            } else {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+                for (int g = 0; g < GG; g += 2) {
+                    stage(c1, a_cur, bop[g + 1], acc[g], c0);
+                    if (g + 2 < GG) stage(c0, a_cur, bop[g + 2], acc[g + 1], c1);
+                    else stage(c0, a_nxt, bop[0], acc[g + 1], c1);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+        }
     }
     if (tb_next >= 0) pairs_load<KS, GG>(bop, tb_next, img, l5, half);
     // ---- column sums: add the lane halves, scale by alpha^2 exp2(beta_p), store (first chunk) or accumulate ----
