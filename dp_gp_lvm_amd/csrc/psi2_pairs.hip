@@ -98,6 +98,9 @@ __device__ __forceinline__ void pairs_group(int tb, pp_h8 (&bop)[GG][KS], int tb
         for (int i = 0; i < 4; ++i) acc[g][i] = 0.0f;
     const _Float16 *arow = aimg + (size_t)l5 * LDA + 8 * half;
     auto load_a = [&](pp_h8 (&a)[KS], int nt) __attribute__((always_inline)) {
+#ifdef PP_DIAG_NO_ALOAD                // (timing experiments only: wrong results)
+        if (nt > 1) return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const pp_h8 *>(arow + (size_t)nt * 32 * LDA + 16 * ks);
     };
