@@ -529,7 +529,7 @@ def dp_gp_lvm_t(y_train,
                 alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
                 mask_size=1,
                 seed=0,
-                device=None, precision='mixed', initial_values=None, _view_of_many=False):
+                device=None, precision='mixed', initial_values=None, _view_of_many=False, process_group=None):
     """
     Over-T formulation — mirror of the reference's ``dp_gp_lvm_t`` factory (src/models/dp_gp_lvm.py:513-676), SURVEY.md
     §8(f) row 3: the kernel batch is the T atoms, the mixture weights phi [T x D] enter outside the kernel, so an evaluation
@@ -544,6 +544,10 @@ def dp_gp_lvm_t(y_train,
         C = L_B^-1 V, 1/2 sum_td phi_td beta_t^2 |C_td|^2   dpgp_trsm_batched                          (:638-658)
 
     precision: 'f64', or 'mixed' = the Psi statistics in fp32 (f16-split MFMA kernels), everything after them in fp64.
+    process_group: a torch.distributed group -> the D output dims are sharded over its ranks as in ``dp_gp_lvm``
+    (shard_bounds): the T-atom chain is replicated (it does not depend on D), V = Psi1^T Y, the solves and every sum over d
+    run on the local columns; an evaluation exchanges ONE scalar (the local f_hat), a gradient evaluation ONE packed
+    all-reduce of all raw-variable gradients plus the trouble flag of optimise().
     """
     num_samples, num_dimensions = np.shape(y_train)
     # (_view_of_many: one view of a multi-view model, whose own check is against the views' total dimensionality)
@@ -588,14 +592,22 @@ def dp_gp_lvm_t(y_train,
     gamma_atoms_raw = _raw_pos('gamma_atoms', GP_INIT_GAMMA, (truncation_level, num_latent_dims))
     sig_var_atoms_raw = _raw_pos('alpha_atoms', GP_INIT_ALPHA, (truncation_level, 1))
     beta_atoms_raw = _raw_pos('beta_atoms', GP_INIT_BETA, (truncation_level, 1))
-    y_dev = _t(np.asarray(y_train))
-    yy = torch.sum(y_dev * y_dev, dim=0)                                       # [D]
+    sharded = process_group is not None
+    if sharded:
+        import torch.distributed as dist
+        rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        assert world <= num_dimensions, 'more ranks than output dimensions'
+    else:
+        rank, world = 0, 1
+    d_lo, d_hi = shard_bounds(num_dimensions, rank, world)
+    y_dev = _t(np.asarray(y_train)[:, d_lo:d_hi])                              # the local columns
+    yy = torch.sum(y_dev * y_dev, dim=0)                                       # [D_local]
     from ..distributions.log_normal import log_pdf as log_normal_log_pdf
     from ..distributions.beta import entropy as beta_dist_entropy
     from ..distributions.gamma import entropy as gamma_dist_entropy
     from ..distributions.multinomial import entropy as multinomial_dist_entropy
     s_1, s_2 = dp_model.prior
-    n_, d_, m_ = num_samples, num_dimensions, num_inducing_points
+    n_, d_, m_ = num_samples, d_hi - d_lo, num_inducing_points             # (d_: the LOCAL output dims; the sums over d are local)
     mp_ = 16 * ((m_ + 15) // 16)
     last_info = [torch.zeros((), dtype=torch.int32, device=device)]
 
@@ -687,7 +699,7 @@ def dp_gp_lvm_t(y_train,
         phi = torch.softmax(r['dp_logits'], dim=-1)
         if mask_size != 1:
             phi = torch.repeat_interleave(phi, mask_size, dim=0)
-        f_hat = _FHatT.apply(r['x_mean'], s, r['x_u'], gat, aat, bat, phi.transpose(0, 1).contiguous())
+        f_hat = _FHatT.apply(r['x_mean'], s, r['x_u'], gat, aat, bat, phi[d_lo:d_hi].transpose(0, 1).contiguous())   # local dims
         mu = r['x_mean']
         kl = 0.5 * (torch.sum(mu * mu) + torch.sum(s - torch.log(s)) - mu.shape[0] * mu.shape[1])     # gp_expressions.py:10-24
         hyper = torch.sum(log_normal_log_pdf(gat)) + torch.sum(log_normal_log_pdf(aat)) + torch.sum(log_normal_log_pdf(bat))
@@ -698,9 +710,17 @@ def dp_gp_lvm_t(y_train,
     raw_vars = dict(x_mean=x_mean, x_var=x_var_raw, x_u=x_u, gamma_atoms=gamma_atoms_raw, alpha_atoms=sig_var_atoms_raw,
                     beta_atoms=beta_atoms_raw, **{'dp_' + k: v for k, v in dp_model.raw.items()})
 
+    def _exchange(out):
+        """Sharded: out[1] is the f_hat of the local output dims; everything else is replicated."""
+        if sharded:
+            f_tot = out[1].clone()
+            dist.all_reduce(f_tot, op=dist.ReduceOp.SUM, group=process_group)
+            out = torch.stack([out[3] - (f_tot - out[2]) - out[4], f_tot, out[2], out[3], out[4]])
+        return out
+
     def evaluate():
         with torch.no_grad():
-            out = _objective_of(raw_vars)
+            out = _exchange(_objective_of(raw_vars))
         return out, last_info[0]
 
     graph = {}
@@ -723,14 +743,29 @@ def dp_gp_lvm_t(y_train,
                     graph['out'] = _objective_of(raw_vars)
             graph['g'] = g_
         graph['g'].replay()
-        return graph['out'].clone()
+        return _exchange(graph['out'].clone())              # (the all-reduce of a sharded model runs eagerly behind the replay)
 
     def _gradients():
         """d objective / d raw variable for all raw variables: torch autograd around the library-backed f_hat (above)."""
         leaves = {k: v.detach().clone().requires_grad_(True) for k, v in raw_vars.items()}
-        obj = _objective_of(leaves)[0]
+        terms = _objective_of(leaves)
+        # sharded: this rank's share of the objective = -(local f_hat) + (replicated terms) / world; the shares sum to it
+        obj = terms[0] if not sharded else -terms[1] + (terms[3] + terms[2] - terms[4]) / world
         grads = torch.autograd.grad(obj, list(leaves.values()), allow_unused=True)
-        return {k: (torch.zeros_like(v) if g is None else g) for (k, v), g in zip(leaves.items(), grads)}
+        grads = [torch.zeros_like(v) if g is None else g for v, g in zip(leaves.values(), grads)]
+        flat = torch.cat([g.reshape(-1) for g in grads] + [torch.zeros(1, dtype=TORCH_DTYPE, device=device)])
+        # trouble flag (failed factorisation / non-finite local gradient), reduced with the gradients: a collective decision
+        flat[-1] = ((last_info[0] != 0) | ~torch.isfinite(flat[:-1]).all()).to(TORCH_DTYPE)
+        if sharded:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)       # ONE packed exchange
+        grad_flag[0] = flat[-1]
+        out, o = {}, 0
+        for (k, v) in leaves.items():
+            out[k] = flat[o:o + v.numel()].reshape(v.shape)
+            o += v.numel()
+        return out
+
+    grad_flag = [torch.zeros((), dtype=TORCH_DTYPE, device=device)]
 
     def _optimise(num_iterations, learning_rate=0.01, callback=None):
         """Adam on the raw variables (the reference: tf.train.AdamOptimizer(...).minimize(objective))."""
@@ -739,7 +774,7 @@ def dp_gp_lvm_t(y_train,
             g = _gradients()
             # potrf replaces a failing pivot by 1 and goes on: a failed factorisation would give finite, meaningless
             # gradients.  The reference's tf.cholesky raises; so does this.
-            bad = ~torch.stack([torch.isfinite(v).all() for v in g.values()]).all() | (last_info[0] != 0)
+            bad = (grad_flag[0] != 0) | ~torch.stack([torch.isfinite(v).all() for v in g.values()]).all()
             if bool(bad):
                 raise FloatingPointError('iteration %d: failed Cholesky factorisation or non-finite gradient (precision=%r); '
                                          'use precision="f64"' % (it, precision))
@@ -790,6 +825,8 @@ def dp_gp_lvm_t(y_train,
         @property
         def cholesky_info(self):
             return evaluate()[1]
+
+        shard = (d_lo, d_hi)
 
         objective_terms_graph = staticmethod(_objective_terms_graph)
         gradients = staticmethod(_gradients)

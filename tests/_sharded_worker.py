@@ -38,6 +38,20 @@ def main():
         res['descended'] = int(res['after'] < before)
         res['x_u_after'] = model.raw['x_u'].cpu().numpy()
         res['precision'] = stats['precision']
+    elif mode == 'values_t':
+        # the over-T model (dp_gp_lvm_t), D-sharded: objective terms, all gradients, a 5-step Adam run
+        from functools import partial
+        from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+        from test_gpu_model_t import build
+        model = build(partial(dp_gp_lvm_t, process_group=dist.group.WORLD), g, dev, prec)
+        res['shard'] = np.array(model.shard)
+        res['terms'] = model.objective_terms.cpu().numpy()
+        res['terms_graph'] = model.objective_terms_graph().cpu().numpy()
+        for k, v in model.gradients().items():
+            res['grad_' + k] = v.cpu().numpy()
+        model.optimise(5, learning_rate=0.01)
+        res['after'] = float(model.objective)
+        res['x_u_after'] = model.raw['x_u'].cpu().numpy()
     elif mode == 'flag':
         # an ill-conditioning flag on ONE rank's output dims only: both ranks must raise in the same iteration (the flag
         # travels with the packed gradients), neither may be left waiting in the next all-reduce
