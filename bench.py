@@ -196,11 +196,19 @@ def main():
     if world != a.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (a.gpus, world, a.gpus))
+    # DPGP_BENCH_BACKEND=gloo (rehearsal only): the world > 1 code path with all ranks on the visible device(s) — RCCL refuses
+    # two ranks on one GPU, the development box has one.  Numbers of such a run are not benchmark results.
+    backend = os.environ.get('DPGP_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     group = None
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)      # nccl == RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     shape = CONFIGS[a.config]
