@@ -141,6 +141,7 @@ extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q)
         const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
         b += dpgp_align256(psi2_consts_bytes(M, Q)) + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)) +
              dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
+        b += dpgp_align256(psi2_pgrad_ws_bytes(D, N, M, Q));           // pair-tile form of the Psi2 term (Q <= 10)
     }
     return b;
 }
@@ -202,7 +203,6 @@ extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y
         double *part = reinterpret_cast<double *>(consts + dpgp_align256(psi2_consts_bytes(M, Q)));
         double *ws1 = reinterpret_cast<double *>((unsigned char *)part + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)));
         double *stage = reinterpret_cast<double *>((unsigned char *)ws1 + dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)));
-        (void)mx;
         rc = launch_psi2_consts<double>(z, M, Q, consts, st);
         if (rc != DPGP_OK) return rc;
         if (big) {                                               // K_uu term for any M (partials in the plain kernel's workspace)
@@ -211,6 +211,11 @@ extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y
         }
         rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, g_psi1, ws1, stage, d_mu, d_s, d_z, d_gamma, st);
         if (rc != DPGP_OK) return rc;
+        // the Psi2 term: pair-tile form (psi2_pairs_grad.hip) where it exists, else the per-observation patch form
+        if (psi2_pgrad_supported(M, Q) && !getenv("DPGP_GRAD_PATCH")) {       // (DPGP_GRAD_PATCH: experiments / cross-check)
+            unsigned char *pgws = reinterpret_cast<unsigned char *>(stage) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
+            return launch_psi2_pgrad(D, N, M, Q, consts, z, mu, s, gamma, alpha, g_psi2, pgws, stage, d_mu, d_s, d_z, d_gamma, st);
+        }
         return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, part, stage, d_mu, d_s, d_z, d_gamma, st);
     }
     if (dpgp_round_up(M, 16) > 128) return -30;

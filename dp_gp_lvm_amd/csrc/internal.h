@@ -108,3 +108,10 @@ int launch_psi2_grad(int B, int N, int M, int Q, const unsigned char *consts, co
                      const double *gamma, const double *alpha, const double *GP, double *part, double *stage, double *dmu,
                      double *ds, double *dz, double *dgamma, hipStream_t st);
 #define DPGP_PREP_ROWS 16   // output dims per row-block of dpgp_model_prepare (scal has 2 + ceil(D / 16) entries)
+
+// ---- psi2_pairs_grad.hip: the Psi2 term of stage B in the pair-tile form (Q <= 10) ---------------------------------------
+bool psi2_pgrad_supported(int M, int Q);
+size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q);
+int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
+                      const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
+                      double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st);

@@ -1,0 +1,532 @@
+// Stage B of the backward pass, Psi2 term, in the PAIR-TILE form of psi2_pairs.hip (reference: tf.gradients through
+// /root/reference/src/kernels/rbf_kernel.py:164-199).  With the forward's notation (psi2_pairs.hip)
+//      psi2[d, p] = alpha_d^2 exp2(beta_dp) sum_n exp2(E_dnp),     E = A_dn . B_p  (a' s2' + b s + c'' 1 over the K slots),
+// and L = sum_d sum_p g_dp psi2[d, p]  (g = the adjoint of Psi2 folded onto the pairs: 2 G[m, m'] off the diagonal), every
+// derivative is a contraction of the SAME matrix W_dnp = exp2(E_dnp) with the operands of the exponent GEMM:
+//      pair side   R2[d, p, :] = sum_n W_dnp (a'_dn., b_dn., 1)            -> d/dz (through s and beta), d/dgamma (through beta)
+//      obs. side   R1[d, n, :] = sum_p W_dnp u_dp (s2'_p., s_p., 1)        -> d/dmu, d/dS, d/dgamma (through a', b, c'')
+// with u_dp = g_dp alpha_d^2 exp2(beta_dp).  Both are second GEMMs on the matrix pipe whose one operand is the exponential
+// tile just computed: the 16 result registers of a lane ARE the B operand (8 k-slots per K-step) of
+// v_mfma_f32_32x32x16_f16 when the contraction runs over the tile's ROWS — so the pass whose rows are the observations gives
+// R2 and a second pass with the roles swapped (rows = pairs, columns = observations) gives R1; a transposition inside the
+// wave would cost as much as recomputing the exponentials.  The per-element work is exp2 + the (hi, lo) f16 split of W; the
+// factor u_dp never touches an element (it multiplies a column of R2 afterwards, and is folded into the features of pass 2).
+// The round-1 kernel (psi2_grad_kernel, psi2.hip) walks the FULL M x M square per observation patch by patch (twice the
+// exponentials) and re-forms operands per observation; it stays for Q > 10.
+//
+// Workgroup = (output dim, 8 column tiles: 4 waves x 2 resident tiles); it loops over ALL row chunks with the second-product
+// accumulators in registers and writes them once — no partial slabs, no atomics (bit-reproducible).
+#include <type_traits>
+#include "internal.h"
+#include "psi2_consts.h"
+
+typedef _Float16 pg_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pg_h2 __attribute__((ext_vector_type(2)));
+typedef float pg_f16v __attribute__((ext_vector_type(16)));
+typedef float pg_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
+
+#define PG_APAD 8
+#define PG_HDR 512
+#define PG_G 2                       // resident column tiles per wave
+#define PG_NF 32                     // feature rows of the second product (2Q + 1 used)
+
+// position of (feature f, row rr of a 32-row tile) in the transposed feature image of one (kind, row tile): the k-slot order
+// of the second product's operands = the register order the exponent tile arrives in
+__device__ __forceinline__ int pg_xt_index(int f, int rr) {
+    const int c = rr >> 3, h = (rr >> 2) & 1, j = rr & 3, s_ = c >> 1, t_ = 4 * (c & 1) + j;
+    return (((s_ * 2 + h) * 32) + f) * 8 + t_;
+}
+// feature f of row rr as an f16 (hi, lo) pair into the two transposed images (xh, xl: this row tile's)
+__device__ __forceinline__ void pg_put(_Float16 *xh, _Float16 *xl, int f, int rr, float v) {
+    v = dpgp_pin(v);
+    const _Float16 vh = (_Float16)v;
+    const int ix = pg_xt_index(f, rr);
+    xh[ix] = vh;
+    xl[ix] = (_Float16)(v - (float)vh);
+}
+
+// ---- the row of the exponent GEMM's A operand for observation n of output dim d (as phase A of psi2_pairs_kernel) --------
+// dst: 8 KS words (16 KS f16 slots); xh != nullptr: also the features a'_q, b_q (the values the slots were split from) of
+// this row (rr within its tile) into the transposed images
+template <int KS>
+__device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const double *__restrict__ mu, const double *__restrict__ s,
+                                           const float *gq, const float *zc, unsigned *dst, _Float16 *xh, _Float16 *xl, int rr) {
+    constexpr int SLP = 16 * KS;
+    bool oor = false;
+    float cc = -60000.0f;
+    if (valid) {
+        cc = 0.0f;
+        for (int q = 0; q < Q; ++q) {
+            const float g = gq[q], sv = (float)s[(size_t)n * Q + q], mc = (float)mu[(size_t)n * Q + q] - zc[q];
+            const float den = 2.0f * g * sv + 1.0f, w = g / den;
+            const float a = dpgp_pin((float)(-0.25 * DPGP_LOG2E / PSI2_PAIR_S2_SCALE) * w);
+            const float bb = dpgp_pin((float)DPGP_LOG2E * w * mc);
+            cc -= bb * mc + 0.5f * __builtin_amdgcn_logf(den);
+            const _Float16 ah = (_Float16)a, alo = (_Float16)(a - (float)ah);
+            const _Float16 bh = (_Float16)bb, blo = (_Float16)(bb - (float)bh);
+            const pg_h2 w0 = {ah, ah}, w1 = {alo, bh}, w2 = {bh, blo};
+            dst[3 * q] = __builtin_bit_cast(unsigned, w0);
+            dst[3 * q + 1] = __builtin_bit_cast(unsigned, w1);
+            dst[3 * q + 2] = __builtin_bit_cast(unsigned, w2);
+            if (xh) {
+                pg_put(xh, xl, 2 * q, rr, (float)ah + (float)alo);
+                pg_put(xh, xl, 2 * q + 1, rr, (float)bh + (float)blo);
+            }
+        }
+        oor = !(cc >= -8192.0f);                                  // range guard of the f16-split exponent (psi2_pairs.hip)
+        cc = fmaxf(cc, -60000.0f);
+    } else {
+        for (int q = 0; q < 3 * Q; ++q) dst[q] = 0u;
+        if (xh)
+            for (int f = 0; f < 2 * Q; ++f) pg_put(xh, xl, f, rr, 0.0f);
+    }
+    cc = dpgp_pin(cc);
+    const _Float16 ch = (_Float16)cc;
+    const float r1 = dpgp_pin(cc - (float)ch);
+    const _Float16 cm = (_Float16)r1;
+    const pg_h2 cw = {ch, cm}, cw2 = {(_Float16)(r1 - (float)cm), (_Float16)0.0f};
+    dst[3 * Q] = __builtin_bit_cast(unsigned, cw);
+    for (int k = 3 * Q + 1; k < SLP / 2; ++k) dst[k] = 0u;
+    if (6 * Q + 2 < SLP) dst[3 * Q + 1] = __builtin_bit_cast(unsigned, cw2);
+    return oor;
+}
+
+// ---- u[d][p] = g_dp alpha_d^2 exp2(beta_dp), and kap[d] = the power of two that brings max_p |u_dp| into [2^7, 2^8) (times |s| <= ~100: inside the f16 range) ----
+__global__ __launch_bounds__(256) void pg_u_kernel(int M, int Q, int Mp, const double *__restrict__ z,
+                                                   const double *__restrict__ gamma, const double *__restrict__ alpha,
+                                                   const double *__restrict__ GP, float *__restrict__ u, float *__restrict__ kap) {
+    __shared__ float red[256];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const int P = (int)((long long)M * (M + 1) / 2), Ppad = (P + 31) & ~31;
+    const float al = (float)alpha[d], al2 = al * al;
+    const double *Gd = GP + (size_t)d * Mp * Mp;
+    float mx = 0.0f;
+    for (int p = t; p < Ppad; p += 256) {
+        float val = 0.0f;
+        if (p < P) {
+            int m, mp;
+            psi2_pair_of(p, m, mp);
+            float bsum = 0.0f;
+            for (int q = 0; q < Q; ++q) {
+                const float dd = (float)(z[(size_t)m * Q + q] - z[(size_t)mp * Q + q]);
+                bsum += (float)gamma[(size_t)d * Q + q] * dd * dd;
+            }
+            const float g = (float)Gd[(size_t)m * Mp + mp] * (m == mp ? 1.0f : 2.0f);
+            val = g * al2 * __builtin_amdgcn_exp2f((float)(-0.25 * DPGP_LOG2E) * bsum);
+        }
+        u[(size_t)d * Ppad + p] = val;
+        mx = fmaxf(mx, fabsf(val));
+    }
+    red[t] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        float k = 1.0f;
+        const float m0 = red[0];
+        if (m0 > 0.0f && m0 < 3.0e38f) {
+            int ex;
+            (void)frexpf(m0, &ex);
+            ex = max(-100, min(100, ex));
+            k = ldexpf(1.0f, 8 - ex);
+        }
+        kap[d] = k;
+    }
+}
+
+// ---- the observation image of all (d, n) in MFMA operand order (the column operands of pass 2) ---------------------------
+// aimg[d][nt][ks][lane 0..63][8 halves]: lane = 32 half + n % 32 holds slots 16 ks + 8 half .. + 7 of observation 32 nt + lane % 32
+template <int KS>
+__global__ __launch_bounds__(256) void pg_obs_image_kernel(int N, int Q, const unsigned char *__restrict__ consts,
+                                                           const double *__restrict__ mu, const double *__restrict__ s,
+                                                           const double *__restrict__ gamma, _Float16 *__restrict__ aimg,
+                                                           int NT, int *__restrict__ flag) {
+    constexpr int SLP = 16 * KS;
+    __shared__ float gq[32], zc[32];
+    __shared__ __align__(16) unsigned rows[256][SLP / 2 + 4];
+    const int d = blockIdx.y, t = threadIdx.x, n0 = 256 * blockIdx.x;
+    if (t < 32) {
+        gq[t] = (t < Q) ? (float)gamma[(size_t)d * Q + t] : 0.0f;
+        zc[t] = reinterpret_cast<const float *>(consts)[t];
+    }
+    __syncthreads();
+    const bool oor = pg_obs_row<KS>(n0 + t < N, n0 + t, Q, mu, s, gq, zc, rows[t], nullptr, nullptr, 0);
+    if (oor) atomicOr(flag, 1);
+    __syncthreads();
+    // 8 row tiles x KS K-steps x 64 lanes of 16-byte words
+    pg_u4 *dst = reinterpret_cast<pg_u4 *>(aimg) + ((size_t)d * NT + n0 / 32) * KS * 64;
+    for (int e = t; e < 8 * KS * 64; e += 256) {
+        const int lane = e & 63, ks = (e >> 6) % KS, tl = e / (64 * KS);
+        if (n0 / 32 + tl >= NT) continue;
+        const int r = 32 * tl + (lane & 31), w0 = 8 * ks + 4 * (lane >> 5);
+        dst[e] = (pg_u4){rows[r][w0], rows[r][w0 + 1], rows[r][w0 + 2], rows[r][w0 + 3]};
+    }
+}
+
+// ---- one pass: rows (LDS, chunked) x resident column tiles; out[d][column][PG_NF] = sum_rows W X -------------------------
+// PASS 1: rows = observations of output dim d (image built here), columns = pairs (pair image of psi2_consts.h)
+// PASS 2: rows = pairs (image copied from the pair image, features scaled by kap_d u_dp), columns = observations (aimg)
+template <int KS, int PASS>
+__global__ __launch_bounds__(256, 2) void pg_pass_kernel(int N, int M, int Q, int D, const unsigned char *__restrict__ consts,
+                                                         const double *__restrict__ mu, const double *__restrict__ s,
+                                                         const double *__restrict__ gamma, const float *__restrict__ u,
+                                                         const float *__restrict__ kap, const _Float16 *__restrict__ aimg_g,
+                                                         float *__restrict__ out, int n_rows, int n_col_tiles, int groups_per_d,
+                                                         int R, int *__restrict__ flag) {
+    constexpr int SLP = 16 * KS, LDA = SLP + PG_APAD, G = PG_G;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *gq = reinterpret_cast<float *>(smem_raw), *zc = gq + 32;
+    _Float16 *ri = reinterpret_cast<_Float16 *>(smem_raw + PG_HDR);               // [R][LDA]
+    _Float16 *xt = ri + (size_t)R * LDA;                                            // [2 kinds][R / 32][2][64][8]
+    const Psi2Consts C = psi2_consts_layout(M, Q);
+    const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
+    const int d = blockIdx.x / groups_per_d, cg = blockIdx.x - d * groups_per_d;
+    const int t = threadIdx.x, lane = t & 63, l5 = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (t < 32) {
+        gq[t] = (t < Q) ? (float)gamma[(size_t)d * Q + t] : 0.0f;
+        zc[t] = reinterpret_cast<const float *>(consts)[t];
+    }
+    const int NTc = R / 32;
+    const float kd = (PASS == 2) ? kap[d] : 1.0f;
+    // resident column operands
+    const _Float16 *cimg = (PASS == 1) ? pimg : aimg_g + (size_t)d * n_col_tiles * KS * 64 * 8;
+    pg_h8 bop[G][KS];
+    int ct[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        ct[g] = min(cg * 4 * G + wv + 4 * g, n_col_tiles - 1);   // (a surplus tile of the last group repeats the last one; not stored)
+        const pg_h8 *row = reinterpret_cast<const pg_h8 *>(cimg) + (size_t)ct[g] * KS * 64 + 32 * half + l5;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bop[g][ks] = row[ks * 64];
+    }
+    pg_f16v acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[g][v] = 0.0f;
+    bool oor = false;
+    __syncthreads();
+
+    for (int r0 = 0; r0 < n_rows; r0 += R) {
+        const int rows = min(R, n_rows - r0), ntile = (rows + 31) >> 5;
+        if (r0) __syncthreads();
+        // ---- the row image and the transposed (hi, lo) feature image of this chunk: thread = row ----
+        for (int r = t; r < 32 * ntile; r += 256) {
+            unsigned *dst = reinterpret_cast<unsigned *>(ri + (size_t)r * LDA);
+            _Float16 *xh = xt + ((size_t)(0 * NTc + (r >> 5)) * 2 * 64) * 8, *xl = xt + ((size_t)(1 * NTc + (r >> 5)) * 2 * 64) * 8;
+            const int rr = r & 31;
+            float fone;
+            if (PASS == 1) {
+                const int n = r0 + r;
+                oor |= pg_obs_row<KS>(n < n_rows, n, Q, mu, s, gq, zc, dst, xh, xl, rr);
+                fone = (n < n_rows) ? 1.0f : 0.0f;
+            } else {
+                const int p = r0 + r;                              // (< Ppad: n_rows = Ppad is a multiple of 32)
+                const pg_u4 *src = reinterpret_cast<const pg_u4 *>(pimg) + ((size_t)(p >> 5) * KS) * 64 + (p & 31);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const pg_u4 w = src[ks * 64 + 32 * hf];
+                        dst[8 * ks + 4 * hf] = w[0]; dst[8 * ks + 4 * hf + 1] = w[1];
+                        dst[8 * ks + 4 * hf + 2] = w[2]; dst[8 * ks + 4 * hf + 3] = w[3];
+                    }
+                const float up = kd * u[(size_t)d * C.Ppad + p];
+                const _Float16 *hs = reinterpret_cast<const _Float16 *>(dst);
+                for (int q = 0; q < Q; ++q) {                      // slots {h, l, h | h, l, h} of (s^2 / 64, s)
+                    pg_put(xh, xl, 2 * q, rr, up * ((float)hs[6 * q] + (float)hs[6 * q + 1]));
+                    pg_put(xh, xl, 2 * q + 1, rr, up * ((float)hs[6 * q + 3] + (float)hs[6 * q + 4]));
+                }
+                fone = up;
+            }
+            pg_put(xh, xl, 2 * Q, rr, fone);
+            for (int f = 2 * Q + 1; f < PG_NF; ++f) pg_put(xh, xl, f, rr, 0.0f);
+        }
+        __syncthreads();
+        // ---- this wave's G column tiles against the chunk's row tiles ----
+        for (int nt = 0; nt < ntile; ++nt) {
+            pg_h8 a[KS], xh[2], xl[2];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                a[ks] = *reinterpret_cast<const pg_h8 *>(ri + (size_t)(32 * nt + l5) * LDA + 16 * ks + 8 * half);
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                xh[s_] = *reinterpret_cast<const pg_h8 *>(xt + (((size_t)(0 * NTc + nt) * 2 + s_) * 64 + lane) * 8);
+                xl[s_] = *reinterpret_cast<const pg_h8 *>(xt + (((size_t)(1 * NTc + nt) * 2 + s_) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                pg_f16v c;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) c[v] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bop[g][ks], c, 0, 0, 0);
+                pg_h8 wh[2], wl[2];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float e = dpgp_pin(__builtin_amdgcn_exp2f(c[v]));
+                    const _Float16 eh = (_Float16)e;
+                    wh[v >> 3][v & 7] = eh;
+                    wl[v >> 3][v & 7] = (_Float16)(e - (float)eh);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s_], wh[s_], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s_], wl[s_], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[s_], wh[s_], acc[g], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (__syncthreads_or(oor ? 1 : 0) && t == 0) atomicOr(flag, 1);
+    // ---- out[d][column][f]: register v of lane (column l5, half) is feature 8 (v / 4) + 4 half + v % 4 ----
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int tile = cg * 4 * G + wv + 4 * g;
+        if (tile >= n_col_tiles) continue;
+        float *o = out + (((size_t)d * n_col_tiles + tile) * 32 + l5) * PG_NF + 4 * half;
+#pragma unroll
+        for (int vq = 0; vq < 4; ++vq)
+            *reinterpret_cast<pg_f4 *>(o + 8 * vq) = (pg_f4){acc[g][4 * vq], acc[g][4 * vq + 1], acc[g][4 * vq + 2], acc[g][4 * vq + 3]};
+    }
+}
+
+// ---- finishing, pair side -----------------------------------------------------------------------------------------------
+// thread = pair p: t1[p][q] = ln2 sum_d u_dp (2 S2 s_pq R2[2q] + R2[2q+1]),  t2[p][q] = sum_d u_dp C_dp gamma_dq  (C = R2[2Q])
+__global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int D, int Ppad, const double *__restrict__ z,
+                                                              const double *__restrict__ gamma, const float *__restrict__ u,
+                                                              const float *__restrict__ r2, double *__restrict__ t1,
+                                                              double *__restrict__ t2) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int P = (int)((long long)M * (M + 1) / 2);
+    if (p >= P) return;
+    int m, mp;
+    psi2_pair_of(p, m, mp);
+    double a1[DPGP_MAX_Q], a2[DPGP_MAX_Q], a3[DPGP_MAX_Q];
+    for (int q = 0; q < Q; ++q) { a1[q] = 0.0; a2[q] = 0.0; a3[q] = 0.0; }
+    for (int d = 0; d < D; ++d) {
+        const float ud = u[(size_t)d * Ppad + p];
+        const float *row = r2 + ((size_t)d * Ppad + p) * PG_NF;
+        const double uc = (double)ud * (double)row[2 * Q];
+        for (int q = 0; q < Q; ++q) {
+            a1[q] += (double)ud * (double)row[2 * q];
+            a2[q] += (double)ud * (double)row[2 * q + 1];
+            a3[q] += uc * gamma[(size_t)d * Q + q];
+        }
+    }
+    // s = (z_m - c) + (z_m' - c): the centring constant is the one the images were built with (column means in fp32)
+    for (int q = 0; q < Q; ++q) {
+        t1[(size_t)p * Q + q] = a1[q];           // (x 2 S2 s_pq ln2 in the gather: s needs the column mean)
+        t1[(size_t)(P + p) * Q + q] = a2[q];
+        t2[(size_t)p * Q + q] = a3[q];
+    }
+}
+// thread = (m, q): dz[m][q] += sum over the pairs that hold m
+__global__ __launch_bounds__(256) void pg_gather_dz_kernel(int M, int Q, const double *__restrict__ z,
+                                                           const unsigned char *__restrict__ consts,
+                                                           const double *__restrict__ t1, const double *__restrict__ t2,
+                                                           double *__restrict__ dz) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * Q) return;
+    const int m = e / Q, q = e - m * Q;
+    const int P = (int)((long long)M * (M + 1) / 2);
+    const double c = (double)reinterpret_cast<const float *>(consts)[q];
+    const double zm = z[(size_t)m * Q + q];
+    double acc = 0.0;
+    for (int o = 0; o < M; ++o) {
+        const int hi = o > m ? o : m, lo = o > m ? m : o;
+        const size_t p = (size_t)hi * (hi + 1) / 2 + lo;
+        const double zo = z[(size_t)o * Q + q];
+        const double sp = (zm - c) + (zo - c);
+        const double d1 = 0.6931471805599453 * (2.0 * (double)PSI2_PAIR_S2_SCALE * sp * t1[p * Q + q] + t1[((size_t)P + p) * Q + q]);
+        const double d2 = -0.5 * (zm - zo) * t2[p * Q + q];      // (delta = z_first - z_second; antisymmetric in (m, o): one formula)
+        acc += d1 + d2;
+        if (o == m) acc += d1;
+    }
+    dz[e] += acc;
+}
+// block = output dim d: dgamma[d][q] += sum_p -1/4 delta_pq^2 u_dp C_dp
+__global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int Ppad, const double *__restrict__ z,
+                                                              const float *__restrict__ u, const float *__restrict__ r2,
+                                                              double *__restrict__ dgamma) {
+    __shared__ double red[256];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const int P = (int)((long long)M * (M + 1) / 2);
+    double a[DPGP_MAX_Q];
+    for (int q = 0; q < Q; ++q) a[q] = 0.0;
+    for (int p = t; p < P; p += 256) {
+        int m, mp;
+        psi2_pair_of(p, m, mp);
+        const double uc = (double)u[(size_t)d * Ppad + p] * (double)r2[((size_t)d * Ppad + p) * PG_NF + 2 * Q];
+        for (int q = 0; q < Q; ++q) {
+            const double dd = z[(size_t)m * Q + q] - z[(size_t)mp * Q + q];
+            a[q] += -0.25 * dd * dd * uc;
+        }
+    }
+    for (int q = 0; q < Q; ++q) {
+        red[t] = a[q];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) red[t] += red[t + o];
+            __syncthreads();
+        }
+        if (t == 0) dgamma[(size_t)d * Q + q] += red[0];
+        __syncthreads();
+    }
+}
+
+// ---- finishing, observation side: thread = observation n, loop over d ------------------------------------------------------
+// dmu[n][q] += sum_d ..., ds[n][q] += sum_d ...;  dg_part[block][d][q] = this block's share of dgamma (summed afterwards)
+__global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D, int NT, const unsigned char *__restrict__ consts,
+                                                            const double *__restrict__ mu, const double *__restrict__ s,
+                                                            const double *__restrict__ gamma, const float *__restrict__ kap,
+                                                            const float *__restrict__ r1, double *__restrict__ dmu,
+                                                            double *__restrict__ ds, double *__restrict__ dg_part) {
+    __shared__ double red[4][DPGP_MAX_Q];
+    const int t = threadIdx.x, n = blockIdx.x * 256 + t, lane = t & 63, wv = t >> 6;
+    const bool ok = n < N;
+    double mc[DPGP_MAX_Q], sv[DPGP_MAX_Q], am[DPGP_MAX_Q], as_[DPGP_MAX_Q];
+    for (int q = 0; q < Q; ++q) {
+        mc[q] = ok ? mu[(size_t)n * Q + q] - (double)reinterpret_cast<const float *>(consts)[q] : 0.0;
+        sv[q] = ok ? s[(size_t)n * Q + q] : 1.0;
+        am[q] = 0.0;
+        as_[q] = 0.0;
+    }
+    for (int d = 0; d < D; ++d) {
+        const double ik = 1.0 / (double)kap[d];
+        const float *row = r1 + ((size_t)d * NT * 32 + (ok ? n : 0)) * PG_NF;
+        const double rc = ok ? (double)row[2 * Q] * ik : 0.0;
+        for (int q = 0; q < Q; ++q) {
+            const double g = gamma[(size_t)d * Q + q];
+            const double ra = ok ? (double)row[2 * q] * ik : 0.0, rb = ok ? (double)row[2 * q + 1] * ik : 0.0;
+            const double den = 2.0 * g * sv[q] + 1.0, w = g / den;
+            const double dw = (-0.25 / (double)PSI2_PAIR_S2_SCALE) * ra + mc[q] * rb - mc[q] * mc[q] * rc;
+            const double dmc = w * (rb - 2.0 * mc[q] * rc);
+            const double dden = -0.5 * rc / den - (g / (den * den)) * dw;
+            am[q] += dmc;
+            as_[q] += 2.0 * g * dden;
+            double dgq = dw / den + 2.0 * sv[q] * dden;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dgq += __shfl_xor(dgq, o, 64);
+            if (lane == 0) red[wv][q] = dgq;
+        }
+        __syncthreads();
+        if (t < Q) dg_part[((size_t)blockIdx.x * D + d) * Q + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        __syncthreads();
+    }
+    if (ok)
+        for (int q = 0; q < Q; ++q) {
+            dmu[(size_t)n * Q + q] += am[q];
+            ds[(size_t)n * Q + q] += as_[q];
+        }
+}
+
+// a range-guard hit anywhere: the outputs become NaN (never a silently wrong gradient)
+__global__ void pg_poison_kernel(const int *__restrict__ flag, double *dmu, double *ds, double *dz, double *dgamma) {
+    if (*flag) {
+        const double nan = (double)__builtin_nanf("");
+        dmu[0] = nan; ds[0] = nan; dz[0] = nan; dgamma[0] = nan;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+bool psi2_pgrad_supported(int M, int Q) { return psi2_pairs_ksteps(Q) <= 4 && M >= 1 && M <= 4096; }
+
+struct PgLayout {
+    int KS, P, Ppad, NT, PT, nblk_obs;
+    size_t off_u, off_kap, off_flag, off_aimg, off_r2, off_r1, off_t1, off_t2, off_dgp, total;
+};
+static PgLayout pg_layout(int D, int N, int M, int Q) {
+    PgLayout L;
+    const Psi2Consts C = psi2_consts_layout(M, Q);
+    L.KS = C.KS; L.P = C.P; L.Ppad = C.Ppad; L.NT = dpgp_ceil_div(N, 32); L.PT = C.Ppad / 32;
+    L.nblk_obs = dpgp_ceil_div(N, 256);
+    size_t o = 0;
+    L.off_u = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad);
+    L.off_kap = o;  o += dpgp_align256(sizeof(float) * (size_t)D);
+    L.off_flag = o; o += 256;
+    L.off_aimg = o; o += dpgp_align256(sizeof(_Float16) * (size_t)D * L.NT * L.KS * 64 * 8);
+    L.off_r2 = o;   o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad * PG_NF);
+    L.off_r1 = o;   o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * PG_NF);
+    L.off_t1 = o;   o += dpgp_align256(sizeof(double) * (size_t)2 * L.P * Q);
+    L.off_t2 = o;   o += dpgp_align256(sizeof(double) * (size_t)L.P * Q);
+    L.off_dgp = o;  o += dpgp_align256(sizeof(double) * (size_t)L.nblk_obs * D * Q);
+    L.total = o;
+    return L;
+}
+size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q) { return psi2_pgrad_supported(M, Q) ? pg_layout(D, N, M, Q).total : 0; }
+
+template <int KS>
+static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
+                           const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
+                           double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+    const PgLayout L = pg_layout(D, N, M, Q);
+    const int Mp = dpgp_round_up(M, 16);
+    float *u = reinterpret_cast<float *>(ws + L.off_u), *kap = reinterpret_cast<float *>(ws + L.off_kap);
+    int *flag = reinterpret_cast<int *>(ws + L.off_flag);
+    _Float16 *aimg = reinterpret_cast<_Float16 *>(ws + L.off_aimg);
+    float *r2 = reinterpret_cast<float *>(ws + L.off_r2), *r1 = reinterpret_cast<float *>(ws + L.off_r1);
+    double *t1 = reinterpret_cast<double *>(ws + L.off_t1), *t2 = reinterpret_cast<double *>(ws + L.off_t2);
+    double *dgp = reinterpret_cast<double *>(ws + L.off_dgp);
+    if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return DPGP_ERR_LAUNCH;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_u_kernel, dim3(D), dim3(256), 0, st, M, Q, Mp, z, gamma, alpha, GP, u, kap);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_obs_image_kernel<KS>), dim3(dpgp_ceil_div(N, 256), D), dim3(256), 0, st, N, Q, consts, mu, s,
+                       gamma, aimg, L.NT, flag);
+    DPGP_LAUNCH_CHECK();
+    // rows per chunk: row image (LDA halves) + transposed feature image (64 halves) per row within 80 KB (2 workgroups per CU)
+    const size_t row = sizeof(_Float16) * (size_t)(16 * KS + PG_APAD + 64);
+    const int R = (int)((80 * 1024 - PG_HDR) / row) & ~31;
+    const size_t lds = PG_HDR + row * (size_t)R;
+    for (int pass = 1; pass <= 2; ++pass) {
+        auto kern = pass == 1 ? pg_pass_kernel<KS, 1> : pg_pass_kernel<KS, 2>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return DPGP_ERR_LAUNCH;
+        const int n_rows = pass == 1 ? N : L.Ppad, n_col_tiles = pass == 1 ? L.PT : L.NT;
+        const int groups = dpgp_ceil_div(n_col_tiles, 4 * PG_G);
+        const long long nwg = (long long)D * groups;
+        if (nwg > 0x7fffffffLL) return -1;
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, N, M, Q, D, consts, mu, s, gamma, (const float *)u,
+                           (const float *)kap, (const _Float16 *)aimg, pass == 1 ? r2 : r1, n_rows, n_col_tiles, groups, R, flag);
+        DPGP_LAUNCH_CHECK();
+    }
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_finish_pairs_kernel, dim3(dpgp_ceil_div(L.P, 256)), dim3(256), 0, st, M, Q, D, L.Ppad, z, gamma,
+                       (const float *)u, (const float *)r2, t1, t2);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_gather_dz_kernel, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, z, consts, (const double *)t1,
+                       (const double *)t2, dz);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_dgamma_pairs_kernel, dim3(D), dim3(256), 0, st, M, Q, L.Ppad, z, (const float *)u, (const float *)r2,
+                       dgamma);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_finish_obs_kernel, dim3(L.nblk_obs), dim3(256), 0, st, N, Q, D, L.NT, consts, mu, s, gamma,
+                       (const float *)kap, (const float *)r1, dmu, ds, dgp);
+    DPGP_LAUNCH_CHECK();
+    const size_t dq = (size_t)D * Q;
+    const int rc = launch_reduce_rows<double>(dq, dq, L.nblk_obs, dgp, dgamma, 1, stage, st);
+    if (rc != DPGP_OK) return rc;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_poison_kernel, dim3(1), dim3(1), 0, st, (const int *)flag, dmu, ds, dz, dgamma);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
+// Psi2 part of stage B, ADDED to dmu [N,Q], ds [N,Q], dz [M,Q], dgamma [D,Q]; GP [D][Mp][Mp]: the adjoint of Psi2 (lower
+// triangle read); consts: psi2_consts (launch_psi2_consts); ws: psi2_pgrad_ws_bytes; stage: as launch_reduce_rows.
+// A range-guard hit (see psi2_pairs.hip) poisons the outputs with NaN (checked by the caller through the trouble flag).
+int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
+                      const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
+                      double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+    if (!psi2_pgrad_supported(M, Q)) return -4;
+    switch (psi2_pairs_ksteps(Q)) {
+        case 2: return launch_pgrad_ks<2>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, ws, stage, dmu, ds, dz, dgamma, st);
+        case 4: return launch_pgrad_ks<4>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, ws, stage, dmu, ds, dz, dgamma, st);
+    }
+    return -4;
+}
