@@ -28,7 +28,9 @@ typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 
 #define PG_APAD 8
 #define PG_HDR 512
+#ifndef PG_G
 #define PG_G 2                       // resident column tiles per wave
+#endif
 #define PG_NF 32                     // feature rows of the second product (2Q + 1 used)
 
 // position of (feature f, row rr of a 32-row tile) in the transposed feature image of one (kind, row tile): the k-slot order
@@ -137,69 +139,127 @@ __global__ __launch_bounds__(256) void pg_u_kernel(int M, int Q, int Mp, const d
     }
 }
 
-// ---- the observation image of all (d, n) in MFMA operand order (the column operands of pass 2) ---------------------------
-// aimg[d][nt][ks][lane 0..63][8 halves]: lane = 32 half + n % 32 holds slots 16 ks + 8 half .. + 7 of observation 32 nt + lane % 32
+// ---- precomputed images -----------------------------------------------------------------------------------------------
+// Every workgroup of a pass re-reads the row images of its output dim chunk by chunk; they are built ONCE per evaluation
+// (observation side: per output dim; pair side: the exponent rows are shared by all output dims, the features carry u_dp):
+//   operand order   cimg[set][tile][ks][lane 0..63][8 halves]   lane = 32 half + row % 32 holds slots 16 ks + 8 half .. + 7
+//   row major       rimg[set][row][16 KS halves]                (the LDS copy adds the bank padding)
+//   features        ximg[set][tile][kind hi / lo][K-step 0 / 1][lane][8 halves]   (pg_xt_index: the second product's A operand)
 template <int KS>
-__global__ __launch_bounds__(256) void pg_obs_image_kernel(int N, int Q, const unsigned char *__restrict__ consts,
-                                                           const double *__restrict__ mu, const double *__restrict__ s,
-                                                           const double *__restrict__ gamma, _Float16 *__restrict__ aimg,
-                                                           int NT, int *__restrict__ flag) {
-    constexpr int SLP = 16 * KS;
-    __shared__ float gq[32], zc[32];
-    __shared__ __align__(16) unsigned rows[256][SLP / 2 + 4];
+__global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const unsigned char *__restrict__ consts,
+                                                            const double *__restrict__ mu, const double *__restrict__ s,
+                                                            const double *__restrict__ gamma, _Float16 *__restrict__ cimg,
+                                                            _Float16 *__restrict__ rimg, _Float16 *__restrict__ ximg, int NT,
+                                                            int *__restrict__ flag) {
+    constexpr int SLP = 16 * KS, RW = SLP / 2 + 4;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *gq = reinterpret_cast<float *>(smem_raw), *zc = gq + 32;
+    unsigned *rows = reinterpret_cast<unsigned *>(smem_raw + 256);                 // [256][RW]
+    _Float16 *xt = reinterpret_cast<_Float16 *>(rows + 256 * RW);                  // [8 tiles][2][2][64][8]
     const int d = blockIdx.y, t = threadIdx.x, n0 = 256 * blockIdx.x;
     if (t < 32) {
         gq[t] = (t < Q) ? (float)gamma[(size_t)d * Q + t] : 0.0f;
         zc[t] = reinterpret_cast<const float *>(consts)[t];
     }
     __syncthreads();
-    const bool oor = pg_obs_row<KS>(n0 + t < N, n0 + t, Q, mu, s, gq, zc, rows[t], nullptr, nullptr, 0);
-    if (oor) atomicOr(flag, 1);
-    __syncthreads();
-    // 8 row tiles x KS K-steps x 64 lanes of 16-byte words
-    pg_u4 *dst = reinterpret_cast<pg_u4 *>(aimg) + ((size_t)d * NT + n0 / 32) * KS * 64;
-    for (int e = t; e < 8 * KS * 64; e += 256) {
-        const int lane = e & 63, ks = (e >> 6) % KS, tl = e / (64 * KS);
-        if (n0 / 32 + tl >= NT) continue;
-        const int r = 32 * tl + (lane & 31), w0 = 8 * ks + 4 * (lane >> 5);
-        dst[e] = (pg_u4){rows[r][w0], rows[r][w0 + 1], rows[r][w0 + 2], rows[r][w0 + 3]};
+    {
+        _Float16 *xh = xt + (size_t)(t >> 5) * 2048, *xl = xh + 1024;
+        const bool valid = n0 + t < N;
+        const bool oor = pg_obs_row<KS>(valid, n0 + t, Q, mu, s, gq, zc, rows + t * RW, xh, xl, t & 31);
+        pg_put(xh, xl, 2 * Q, t & 31, valid ? 1.0f : 0.0f);
+        for (int f = 2 * Q + 1; f < PG_NF; ++f) pg_put(xh, xl, f, t & 31, 0.0f);
+        if (oor) atomicOr(flag, 1);
     }
+    __syncthreads();
+    const int tile0 = n0 / 32, ntl = min(8, NT - tile0);
+    pg_u4 *cd = reinterpret_cast<pg_u4 *>(cimg) + ((size_t)d * NT + tile0) * KS * 64;
+    for (int e = t; e < ntl * KS * 64; e += 256) {
+        const int lane = e & 63, ks = (e >> 6) % KS, tl = e / (64 * KS);
+        const unsigned *r = rows + (32 * tl + (lane & 31)) * RW + 8 * ks + 4 * (lane >> 5);
+        cd[e] = (pg_u4){r[0], r[1], r[2], r[3]};
+    }
+    pg_u4 *rd = reinterpret_cast<pg_u4 *>(rimg) + ((size_t)d * NT + tile0) * 32 * (SLP / 8);
+    for (int e = t; e < ntl * 32 * (SLP / 8); e += 256) {
+        const int row = e / (SLP / 8), w = e - row * (SLP / 8);
+        const unsigned *r = rows + row * RW + 4 * w;
+        rd[e] = (pg_u4){r[0], r[1], r[2], r[3]};
+    }
+    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * NT + tile0) * 256;
+    for (int e = t; e < ntl * 256; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
 }
 
-// ---- one pass: rows (LDS, chunked) x resident column tiles; out[d][column][PG_NF] = sum_rows W X -------------------------
-// PASS 1: rows = observations of output dim d (image built here), columns = pairs (pair image of psi2_consts.h)
-// PASS 2: rows = pairs (image copied from the pair image, features scaled by kap_d u_dp), columns = observations (aimg)
-template <int KS, int PASS>
-__global__ __launch_bounds__(256, 2) void pg_pass_kernel(int N, int M, int Q, int D, const unsigned char *__restrict__ consts,
-                                                         const double *__restrict__ mu, const double *__restrict__ s,
-                                                         const double *__restrict__ gamma, const float *__restrict__ u,
-                                                         const float *__restrict__ kap, const _Float16 *__restrict__ aimg_g,
-                                                         float *__restrict__ out, int n_rows, int n_col_tiles, int groups_per_d,
-                                                         int R, int *__restrict__ flag) {
-    constexpr int SLP = 16 * KS, LDA = SLP + PG_APAD, G = PG_G;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    float *gq = reinterpret_cast<float *>(smem_raw), *zc = gq + 32;
-    _Float16 *ri = reinterpret_cast<_Float16 *>(smem_raw + PG_HDR);               // [R][LDA]
-    _Float16 *xt = ri + (size_t)R * LDA;                                            // [2 kinds][R / 32][2][64][8]
+// pair side: thread = pair; ximg per output dim (features x kap_d u_dp), rimg once (blockIdx.y == 0)
+template <int KS>
+__global__ __launch_bounds__(256) void pg_pair_images_kernel(int M, int Q, const unsigned char *__restrict__ consts,
+                                                             const float *__restrict__ u, const float *__restrict__ kap,
+                                                             _Float16 *__restrict__ rimg, _Float16 *__restrict__ ximg) {
+    constexpr int SLP = 16 * KS;
+    __shared__ __align__(16) _Float16 xt[8 * 2048];
     const Psi2Consts C = psi2_consts_layout(M, Q);
     const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
+    const int d = blockIdx.y, t = threadIdx.x, p0 = 256 * blockIdx.x, p = p0 + t, PT = C.Ppad / 32;
+    const int tile0 = p0 / 32, ntl = min(8, PT - tile0);
+    if (p < C.Ppad) {
+        unsigned row[SLP / 2];
+        const pg_u4 *src = reinterpret_cast<const pg_u4 *>(pimg) + ((size_t)(p >> 5) * KS) * 64 + (p & 31);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const pg_u4 w = src[ks * 64 + 32 * hf];
+                row[8 * ks + 4 * hf] = w[0]; row[8 * ks + 4 * hf + 1] = w[1];
+                row[8 * ks + 4 * hf + 2] = w[2]; row[8 * ks + 4 * hf + 3] = w[3];
+            }
+        if (d == 0) {
+            pg_u4 *rd = reinterpret_cast<pg_u4 *>(rimg) + (size_t)p * (SLP / 8);
+#pragma unroll
+            for (int w = 0; w < SLP / 8; ++w) rd[w] = (pg_u4){row[4 * w], row[4 * w + 1], row[4 * w + 2], row[4 * w + 3]};
+        }
+        const float up = kap[d] * u[(size_t)d * C.Ppad + p];
+        _Float16 *xh = xt + (size_t)(t >> 5) * 2048, *xl = xh + 1024;
+        const int rr = t & 31;
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q) {                    // slots {h, l, h | h, l, h} of (s^2 / 64, s): words 3q .. 3q + 2
+            if (q < Q && 3 * q + 2 < SLP / 2) {
+                const pg_h2 w0 = __builtin_bit_cast(pg_h2, row[3 * q]), w1 = __builtin_bit_cast(pg_h2, row[3 * q + 1]),
+                            w2 = __builtin_bit_cast(pg_h2, row[3 * q + 2]);
+                pg_put(xh, xl, 2 * q, rr, up * ((float)w0[0] + (float)w0[1]));
+                pg_put(xh, xl, 2 * q + 1, rr, up * ((float)w1[1] + (float)w2[0]));
+            }
+        }
+        pg_put(xh, xl, 2 * Q, rr, up);
+        for (int f = 2 * Q + 1; f < PG_NF; ++f) pg_put(xh, xl, f, rr, 0.0f);
+    }
+    __syncthreads();
+    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * PT + tile0) * 256;
+    for (int e = t; e < ntl * 256; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
+}
+
+// ---- one pass: rows (LDS, chunked copies of rimg / ximg) x resident column tiles (cimg) ------------------------------------
+// out[set][column][PG_NF] = sum_rows exp2(E[row, column]) X[row, :].  Pass 1: rows = observations of output dim d, columns =
+// pairs; pass 2: rows = pairs, columns = observations of output dim d.  row_set / x_set / col_set: 1 = the images are per
+// output dim, 0 = shared.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
+                                                         const _Float16 *__restrict__ ximg, const _Float16 *__restrict__ cimg,
+                                                         int col_per_d, float *__restrict__ out, int n_row_tiles, int n_col_tiles,
+                                                         int groups_per_d, int R) {
+    constexpr int SLP = 16 * KS, LDA = SLP + PG_APAD, G = PG_G;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    _Float16 *ri = reinterpret_cast<_Float16 *>(smem_raw);                         // [R][LDA]
+    _Float16 *xt = ri + (size_t)R * LDA;                                            // [2 kinds][R / 32][2][64][8]
     const int d = blockIdx.x / groups_per_d, cg = blockIdx.x - d * groups_per_d;
     const int t = threadIdx.x, lane = t & 63, l5 = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (t < 32) {
-        gq[t] = (t < Q) ? (float)gamma[(size_t)d * Q + t] : 0.0f;
-        zc[t] = reinterpret_cast<const float *>(consts)[t];
-    }
     const int NTc = R / 32;
-    const float kd = (PASS == 2) ? kap[d] : 1.0f;
-    // resident column operands
-    const _Float16 *cimg = (PASS == 1) ? pimg : aimg_g + (size_t)d * n_col_tiles * KS * 64 * 8;
+    const pg_u4 *rsrc = reinterpret_cast<const pg_u4 *>(rimg) + (row_per_d ? (size_t)d * n_row_tiles * 32 * (SLP / 8) : 0);
+    const pg_u4 *xsrc = reinterpret_cast<const pg_u4 *>(ximg) + (size_t)d * n_row_tiles * 256;
+    const _Float16 *csrc = cimg + (col_per_d ? (size_t)d * n_col_tiles * KS * 64 * 8 : 0);
     pg_h8 bop[G][KS];
-    int ct[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        ct[g] = min(cg * 4 * G + wv + 4 * g, n_col_tiles - 1);   // (a surplus tile of the last group repeats the last one; not stored)
-        const pg_h8 *row = reinterpret_cast<const pg_h8 *>(cimg) + (size_t)ct[g] * KS * 64 + 32 * half + l5;
+        const int ct = min(cg * 4 * G + wv + 4 * g, n_col_tiles - 1);   // (a surplus tile of the last group repeats the last one; not stored)
+        const pg_h8 *row = reinterpret_cast<const pg_h8 *>(csrc) + (size_t)ct * KS * 64 + 32 * half + l5;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bop[g][ks] = row[ks * 64];
     }
@@ -208,46 +268,19 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(int N, int M, int Q, in
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[g][v] = 0.0f;
-    bool oor = false;
-    __syncthreads();
 
-    for (int r0 = 0; r0 < n_rows; r0 += R) {
-        const int rows = min(R, n_rows - r0), ntile = (rows + 31) >> 5;
-        if (r0) __syncthreads();
-        // ---- the row image and the transposed (hi, lo) feature image of this chunk: thread = row ----
-        for (int r = t; r < 32 * ntile; r += 256) {
-            unsigned *dst = reinterpret_cast<unsigned *>(ri + (size_t)r * LDA);
-            _Float16 *xh = xt + ((size_t)(0 * NTc + (r >> 5)) * 2 * 64) * 8, *xl = xt + ((size_t)(1 * NTc + (r >> 5)) * 2 * 64) * 8;
-            const int rr = r & 31;
-            float fone;
-            if (PASS == 1) {
-                const int n = r0 + r;
-                oor |= pg_obs_row<KS>(n < n_rows, n, Q, mu, s, gq, zc, dst, xh, xl, rr);
-                fone = (n < n_rows) ? 1.0f : 0.0f;
-            } else {
-                const int p = r0 + r;                              // (< Ppad: n_rows = Ppad is a multiple of 32)
-                const pg_u4 *src = reinterpret_cast<const pg_u4 *>(pimg) + ((size_t)(p >> 5) * KS) * 64 + (p & 31);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        const pg_u4 w = src[ks * 64 + 32 * hf];
-                        dst[8 * ks + 4 * hf] = w[0]; dst[8 * ks + 4 * hf + 1] = w[1];
-                        dst[8 * ks + 4 * hf + 2] = w[2]; dst[8 * ks + 4 * hf + 3] = w[3];
-                    }
-                const float up = kd * u[(size_t)d * C.Ppad + p];
-                const _Float16 *hs = reinterpret_cast<const _Float16 *>(dst);
-                for (int q = 0; q < Q; ++q) {                      // slots {h, l, h | h, l, h} of (s^2 / 64, s)
-                    pg_put(xh, xl, 2 * q, rr, up * ((float)hs[6 * q] + (float)hs[6 * q + 1]));
-                    pg_put(xh, xl, 2 * q + 1, rr, up * ((float)hs[6 * q + 3] + (float)hs[6 * q + 4]));
-                }
-                fone = up;
-            }
-            pg_put(xh, xl, 2 * Q, rr, fone);
-            for (int f = 2 * Q + 1; f < PG_NF; ++f) pg_put(xh, xl, f, rr, 0.0f);
+    for (int rt0 = 0; rt0 < n_row_tiles; rt0 += NTc) {
+        const int ntile = min(NTc, n_row_tiles - rt0);
+        if (rt0) __syncthreads();
+        for (int e = t; e < ntile * 32 * (SLP / 8); e += 256) {
+            const int row = e / (SLP / 8), w = e - row * (SLP / 8);
+            *reinterpret_cast<pg_u4 *>(ri + (size_t)row * LDA + 8 * w) = rsrc[(size_t)rt0 * 32 * (SLP / 8) + e];
+        }
+        for (int e = t; e < ntile * 256; e += 256) {
+            const int rt = e >> 8, rem = e & 255;
+            reinterpret_cast<pg_u4 *>(xt)[((rem >> 7) * NTc + rt) * 128 + (rem & 127)] = xsrc[(size_t)rt0 * 256 + e];
         }
         __syncthreads();
-        // ---- this wave's G column tiles against the chunk's row tiles ----
         for (int nt = 0; nt < ntile; ++nt) {
             pg_h8 a[KS], xh[2], xl[2];
 #pragma unroll
@@ -265,13 +298,26 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(int N, int M, int Q, in
                 for (int v = 0; v < 16; ++v) c[v] = 0.0f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bop[g][ks], c, 0, 0, 0);
+                // W = exp2(E) as f16 (hi, lo) pairs, two values per instruction where the ISA has it: v_cvt_pk_f16_f32 (round to
+                // nearest even) for the hi halves, v_fma_mix_f32 (f16 source) for the residuals e - hi, v_cvt_pk_f16_f32 again
+                pg_u4 whw[2], wlw[2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float e0 = __builtin_amdgcn_exp2f(c[2 * i]), e1 = __builtin_amdgcn_exp2f(c[2 * i + 1]);
+                    unsigned ph, pl;
+                    float l0, l1;
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(e0), "v"(e1));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph), "v"(e0));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(e1));
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pl) : "v"(l0), "v"(l1));
+                    whw[i >> 2][i & 3] = ph;
+                    wlw[i >> 2][i & 3] = pl;
+                }
                 pg_h8 wh[2], wl[2];
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float e = dpgp_pin(__builtin_amdgcn_exp2f(c[v]));
-                    const _Float16 eh = (_Float16)e;
-                    wh[v >> 3][v & 7] = eh;
-                    wl[v >> 3][v & 7] = (_Float16)(e - (float)eh);
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    wh[s_] = __builtin_bit_cast(pg_h8, whw[s_]);
+                    wl[s_] = __builtin_bit_cast(pg_h8, wlw[s_]);
                 }
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
@@ -282,7 +328,6 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(int N, int M, int Q, in
             }
         }
     }
-    if (__syncthreads_or(oor ? 1 : 0) && t == 0) atomicOr(flag, 1);
     // ---- out[d][column][f]: register v of lane (column l5, half) is feature 8 (v / 4) + 4 half + v % 4 ----
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -296,45 +341,57 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(int N, int M, int Q, in
 }
 
 // ---- finishing, pair side -----------------------------------------------------------------------------------------------
-// thread = pair p: t1[p][q] = ln2 sum_d u_dp (2 S2 s_pq R2[2q] + R2[2q+1]),  t2[p][q] = sum_d u_dp C_dp gamma_dq  (C = R2[2Q])
-__global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int D, int Ppad, const double *__restrict__ z,
+// thread = pair p, block row = chunk of output dims: partial sums over the chunk's d of
+//   tp[c][0][p][q] = sum_d u_dp R2[2q],  tp[c][1][p][q] = sum_d u_dp R2[2q+1],  tp[c][2][p][q] = sum_d u_dp C_dp gamma_dq  (C = R2[2Q])
+__global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int D, int Ppad, int dchunk,
                                                               const double *__restrict__ gamma, const float *__restrict__ u,
-                                                              const float *__restrict__ r2, double *__restrict__ t1,
-                                                              double *__restrict__ t2) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
+                                                              const float *__restrict__ r2, double *__restrict__ tp) {
+    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     const int P = (int)((long long)M * (M + 1) / 2);
     if (p >= P) return;
-    int m, mp;
-    psi2_pair_of(p, m, mp);
     double a1[DPGP_MAX_Q], a2[DPGP_MAX_Q], a3[DPGP_MAX_Q];
-    for (int q = 0; q < Q; ++q) { a1[q] = 0.0; a2[q] = 0.0; a3[q] = 0.0; }
-    for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int q = 0; q < DPGP_MAX_Q; ++q) { a1[q] = 0.0; a2[q] = 0.0; a3[q] = 0.0; }
+    const int d1 = min(D, (c + 1) * dchunk);
+    for (int d = c * dchunk; d < d1; ++d) {
         const float ud = u[(size_t)d * Ppad + p];
-        const float *row = r2 + ((size_t)d * Ppad + p) * PG_NF;
-        const double uc = (double)ud * (double)row[2 * Q];
-        for (int q = 0; q < Q; ++q) {
-            a1[q] += (double)ud * (double)row[2 * q];
-            a2[q] += (double)ud * (double)row[2 * q + 1];
-            a3[q] += uc * gamma[(size_t)d * Q + q];
+        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r2 + ((size_t)d * Ppad + p) * PG_NF);
+        float rv[PG_NF];
+#pragma unroll
+        for (int k = 0; k < PG_NF / 4; ++k) {
+            const pg_f4 v = row[k];
+            rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
         }
+        float cc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PG_NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
+        const double uc = (double)ud * (double)cc;
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q)
+            if (q < Q && 2 * q + 1 < PG_NF) {
+                a1[q] += (double)ud * (double)rv[2 * q];
+                a2[q] += (double)ud * (double)rv[2 * q + 1];
+                a3[q] += uc * gamma[(size_t)d * Q + q];
+            }
     }
-    // s = (z_m - c) + (z_m' - c): the centring constant is the one the images were built with (column means in fp32)
-    for (int q = 0; q < Q; ++q) {
-        t1[(size_t)p * Q + q] = a1[q];           // (x 2 S2 s_pq ln2 in the gather: s needs the column mean)
-        t1[(size_t)(P + p) * Q + q] = a2[q];
-        t2[(size_t)p * Q + q] = a3[q];
-    }
+    double *o = tp + (size_t)c * 3 * P * Q;
+#pragma unroll
+    for (int q = 0; q < DPGP_MAX_Q; ++q)
+        if (q < Q) {
+            o[(size_t)p * Q + q] = a1[q];
+            o[((size_t)P + p) * Q + q] = a2[q];
+            o[((size_t)2 * P + p) * Q + q] = a3[q];
+        }
 }
-// thread = (m, q): dz[m][q] += sum over the pairs that hold m
+// thread = (m, q): dz[m][q] += sum over the pairs that hold m of  ln2 (2 S2 s_pq t[0] + t[1]) -+ 1/2 delta_pq t[2]
 __global__ __launch_bounds__(256) void pg_gather_dz_kernel(int M, int Q, const double *__restrict__ z,
                                                            const unsigned char *__restrict__ consts,
-                                                           const double *__restrict__ t1, const double *__restrict__ t2,
-                                                           double *__restrict__ dz) {
+                                                           const double *__restrict__ tt, double *__restrict__ dz) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= M * Q) return;
     const int m = e / Q, q = e - m * Q;
-    const int P = (int)((long long)M * (M + 1) / 2);
-    const double c = (double)reinterpret_cast<const float *>(consts)[q];
+    const size_t P = (size_t)M * (M + 1) / 2;
+    const double c = (double)reinterpret_cast<const float *>(consts)[q];     // (the centring constant the images were built with)
     const double zm = z[(size_t)m * Q + q];
     double acc = 0.0;
     for (int o = 0; o < M; ++o) {
@@ -342,8 +399,8 @@ __global__ __launch_bounds__(256) void pg_gather_dz_kernel(int M, int Q, const d
         const size_t p = (size_t)hi * (hi + 1) / 2 + lo;
         const double zo = z[(size_t)o * Q + q];
         const double sp = (zm - c) + (zo - c);
-        const double d1 = 0.6931471805599453 * (2.0 * (double)PSI2_PAIR_S2_SCALE * sp * t1[p * Q + q] + t1[((size_t)P + p) * Q + q]);
-        const double d2 = -0.5 * (zm - zo) * t2[p * Q + q];      // (delta = z_first - z_second; antisymmetric in (m, o): one formula)
+        const double d1 = 0.6931471805599453 * (2.0 * (double)PSI2_PAIR_S2_SCALE * sp * tt[p * Q + q] + tt[(P + p) * Q + q]);
+        const double d2 = -0.5 * (zm - zo) * tt[(2 * P + p) * Q + q];      // (delta is antisymmetric in (m, o): one formula for both ends)
         acc += d1 + d2;
         if (o == m) acc += d1;
     }
@@ -357,17 +414,22 @@ __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int 
     const int d = blockIdx.x, t = threadIdx.x;
     const int P = (int)((long long)M * (M + 1) / 2);
     double a[DPGP_MAX_Q];
-    for (int q = 0; q < Q; ++q) a[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < DPGP_MAX_Q; ++q) a[q] = 0.0;
     for (int p = t; p < P; p += 256) {
         int m, mp;
         psi2_pair_of(p, m, mp);
         const double uc = (double)u[(size_t)d * Ppad + p] * (double)r2[((size_t)d * Ppad + p) * PG_NF + 2 * Q];
-        for (int q = 0; q < Q; ++q) {
-            const double dd = z[(size_t)m * Q + q] - z[(size_t)mp * Q + q];
-            a[q] += -0.25 * dd * dd * uc;
-        }
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q)
+            if (q < Q) {
+                const double dd = z[(size_t)m * Q + q] - z[(size_t)mp * Q + q];
+                a[q] += -0.25 * dd * dd * uc;
+            }
     }
-    for (int q = 0; q < Q; ++q) {
+#pragma unroll
+    for (int q = 0; q < DPGP_MAX_Q; ++q) {
+        if (q >= Q) break;
         red[t] = a[q];
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
@@ -379,30 +441,45 @@ __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int 
     }
 }
 
-// ---- finishing, observation side: thread = observation n, loop over d ------------------------------------------------------
-// dmu[n][q] += sum_d ..., ds[n][q] += sum_d ...;  dg_part[block][d][q] = this block's share of dgamma (summed afterwards)
-__global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D, int NT, const unsigned char *__restrict__ consts,
+// ---- finishing, observation side: thread = observation n, block row = chunk of output dims ---------------------------------
+// dmu_part / ds_part [chunk][N][Q]: partial sums over the chunk's d;  dg_part[n-block][d][q]: this block's share of dgamma
+__global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D, int NT, int dchunk,
+                                                            const unsigned char *__restrict__ consts,
                                                             const double *__restrict__ mu, const double *__restrict__ s,
                                                             const double *__restrict__ gamma, const float *__restrict__ kap,
-                                                            const float *__restrict__ r1, double *__restrict__ dmu,
-                                                            double *__restrict__ ds, double *__restrict__ dg_part) {
-    __shared__ double red[4][DPGP_MAX_Q];
-    const int t = threadIdx.x, n = blockIdx.x * 256 + t, lane = t & 63, wv = t >> 6;
+                                                            const float *__restrict__ r1, double *__restrict__ dmu_part,
+                                                            double *__restrict__ ds_part, double *__restrict__ dg_part) {
+    __shared__ double red[4][DPGP_MAX_Q + 2];
+    const int t = threadIdx.x, n = blockIdx.x * 256 + t, lane = t & 63, wv = t >> 6, c = blockIdx.y;
     const bool ok = n < N;
     double mc[DPGP_MAX_Q], sv[DPGP_MAX_Q], am[DPGP_MAX_Q], as_[DPGP_MAX_Q];
-    for (int q = 0; q < Q; ++q) {
-        mc[q] = ok ? mu[(size_t)n * Q + q] - (double)reinterpret_cast<const float *>(consts)[q] : 0.0;
-        sv[q] = ok ? s[(size_t)n * Q + q] : 1.0;
+#pragma unroll
+    for (int q = 0; q < DPGP_MAX_Q; ++q) {
+        const bool on = ok && q < Q;
+        mc[q] = on ? mu[(size_t)n * Q + q] - (double)reinterpret_cast<const float *>(consts)[q] : 0.0;
+        sv[q] = on ? s[(size_t)n * Q + q] : 1.0;
         am[q] = 0.0;
         as_[q] = 0.0;
     }
-    for (int d = 0; d < D; ++d) {
+    const int d1 = min(D, (c + 1) * dchunk);
+    for (int d = c * dchunk; d < d1; ++d) {
         const double ik = 1.0 / (double)kap[d];
-        const float *row = r1 + ((size_t)d * NT * 32 + (ok ? n : 0)) * PG_NF;
-        const double rc = ok ? (double)row[2 * Q] * ik : 0.0;
-        for (int q = 0; q < Q; ++q) {
+        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r1 + ((size_t)d * NT * 32 + (ok ? n : 0)) * PG_NF);
+        float rv[PG_NF];
+#pragma unroll
+        for (int k = 0; k < PG_NF / 4; ++k) {
+            const pg_f4 v = row[k];
+            rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
+        }
+        float cc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PG_NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
+        const double rc = ok ? (double)cc * ik : 0.0;
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q) {
+            if (q >= Q || 2 * q + 1 >= PG_NF) break;
             const double g = gamma[(size_t)d * Q + q];
-            const double ra = ok ? (double)row[2 * q] * ik : 0.0, rb = ok ? (double)row[2 * q + 1] * ik : 0.0;
+            const double ra = ok ? (double)rv[2 * q] * ik : 0.0, rb = ok ? (double)rv[2 * q + 1] * ik : 0.0;
             const double den = 2.0 * g * sv[q] + 1.0, w = g / den;
             const double dw = (-0.25 / (double)PSI2_PAIR_S2_SCALE) * ra + mc[q] * rb - mc[q] * mc[q] * rc;
             const double dmc = w * (rb - 2.0 * mc[q] * rc);
@@ -418,11 +495,14 @@ __global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D,
         if (t < Q) dg_part[((size_t)blockIdx.x * D + d) * Q + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
         __syncthreads();
     }
-    if (ok)
-        for (int q = 0; q < Q; ++q) {
-            dmu[(size_t)n * Q + q] += am[q];
-            ds[(size_t)n * Q + q] += as_[q];
-        }
+    if (ok) {
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q)
+            if (q < Q) {
+                dmu_part[((size_t)c * N + n) * Q + q] = am[q];
+                ds_part[((size_t)c * N + n) * Q + q] = as_[q];
+            }
+    }
 }
 
 // a range-guard hit anywhere: the outputs become NaN (never a silently wrong gradient)
@@ -436,27 +516,37 @@ __global__ void pg_poison_kernel(const int *__restrict__ flag, double *dmu, doub
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-bool psi2_pgrad_supported(int M, int Q) { return psi2_pairs_ksteps(Q) <= 4 && M >= 1 && M <= 4096; }
+bool psi2_pgrad_supported(int M, int Q) { return psi2_pairs_ksteps(Q) <= 4 && 2 * Q + 1 <= PG_NF && M >= 1 && M <= 4096; }
 
+#define PG_DC_PAIRS 16               // chunks of output dims of the finishing kernels
+#define PG_DC_OBS 64
 struct PgLayout {
     int KS, P, Ppad, NT, PT, nblk_obs;
-    size_t off_u, off_kap, off_flag, off_aimg, off_r2, off_r1, off_t1, off_t2, off_dgp, total;
+    size_t off_u, off_kap, off_flag, off_cobs, off_robs, off_xobs, off_rpair, off_xpair, off_r2, off_r1, off_tp, off_tt, off_dgp,
+        off_dmup, off_dsp, total;
 };
 static PgLayout pg_layout(int D, int N, int M, int Q) {
     PgLayout L;
     const Psi2Consts C = psi2_consts_layout(M, Q);
     L.KS = C.KS; L.P = C.P; L.Ppad = C.Ppad; L.NT = dpgp_ceil_div(N, 32); L.PT = C.Ppad / 32;
     L.nblk_obs = dpgp_ceil_div(N, 256);
+    const size_t h = sizeof(_Float16);
     size_t o = 0;
-    L.off_u = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad);
-    L.off_kap = o;  o += dpgp_align256(sizeof(float) * (size_t)D);
-    L.off_flag = o; o += 256;
-    L.off_aimg = o; o += dpgp_align256(sizeof(_Float16) * (size_t)D * L.NT * L.KS * 64 * 8);
-    L.off_r2 = o;   o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad * PG_NF);
-    L.off_r1 = o;   o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * PG_NF);
-    L.off_t1 = o;   o += dpgp_align256(sizeof(double) * (size_t)2 * L.P * Q);
-    L.off_t2 = o;   o += dpgp_align256(sizeof(double) * (size_t)L.P * Q);
-    L.off_dgp = o;  o += dpgp_align256(sizeof(double) * (size_t)L.nblk_obs * D * Q);
+    L.off_u = o;     o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad);
+    L.off_kap = o;   o += dpgp_align256(sizeof(float) * (size_t)D);
+    L.off_flag = o;  o += 256;
+    L.off_cobs = o;  o += dpgp_align256(h * (size_t)D * L.NT * L.KS * 64 * 8);
+    L.off_robs = o;  o += dpgp_align256(h * (size_t)D * L.NT * 32 * 16 * L.KS);
+    L.off_xobs = o;  o += dpgp_align256(h * (size_t)D * L.NT * 2048);
+    L.off_rpair = o; o += dpgp_align256(h * (size_t)L.Ppad * 16 * L.KS);
+    L.off_xpair = o; o += dpgp_align256(h * (size_t)D * L.PT * 2048);
+    L.off_r2 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad * PG_NF);
+    L.off_r1 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * PG_NF);
+    L.off_tp = o;    o += dpgp_align256(sizeof(double) * (size_t)PG_DC_PAIRS * 3 * L.P * Q);
+    L.off_tt = o;    o += dpgp_align256(sizeof(double) * (size_t)3 * L.P * Q);
+    L.off_dgp = o;   o += dpgp_align256(sizeof(double) * (size_t)L.nblk_obs * D * Q);
+    L.off_dmup = o;  o += dpgp_align256(sizeof(double) * (size_t)PG_DC_OBS * N * Q);
+    L.off_dsp = o;   o += dpgp_align256(sizeof(double) * (size_t)PG_DC_OBS * N * Q);
     L.total = o;
     return L;
 }
@@ -470,56 +560,80 @@ static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *cons
     const int Mp = dpgp_round_up(M, 16);
     float *u = reinterpret_cast<float *>(ws + L.off_u), *kap = reinterpret_cast<float *>(ws + L.off_kap);
     int *flag = reinterpret_cast<int *>(ws + L.off_flag);
-    _Float16 *aimg = reinterpret_cast<_Float16 *>(ws + L.off_aimg);
+    _Float16 *cobs = reinterpret_cast<_Float16 *>(ws + L.off_cobs), *robs = reinterpret_cast<_Float16 *>(ws + L.off_robs),
+             *xobs = reinterpret_cast<_Float16 *>(ws + L.off_xobs), *rpair = reinterpret_cast<_Float16 *>(ws + L.off_rpair),
+             *xpair = reinterpret_cast<_Float16 *>(ws + L.off_xpair);
     float *r2 = reinterpret_cast<float *>(ws + L.off_r2), *r1 = reinterpret_cast<float *>(ws + L.off_r1);
-    double *t1 = reinterpret_cast<double *>(ws + L.off_t1), *t2 = reinterpret_cast<double *>(ws + L.off_t2);
-    double *dgp = reinterpret_cast<double *>(ws + L.off_dgp);
+    double *tp = reinterpret_cast<double *>(ws + L.off_tp), *tt = reinterpret_cast<double *>(ws + L.off_tt);
+    double *dgp = reinterpret_cast<double *>(ws + L.off_dgp), *dmup = reinterpret_cast<double *>(ws + L.off_dmup),
+           *dsp = reinterpret_cast<double *>(ws + L.off_dsp);
+    const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + psi2_consts_layout(M, Q).off_pairs);
     if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_u_kernel, dim3(D), dim3(256), 0, st, M, Q, Mp, z, gamma, alpha, GP, u, kap);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_obs_image_kernel<KS>), dim3(dpgp_ceil_div(N, 256), D), dim3(256), 0, st, N, Q, consts, mu, s,
-                       gamma, aimg, L.NT, flag);
+    {
+        const size_t lds = 256 + sizeof(unsigned) * 256 * (8 * KS + 4) + sizeof(_Float16) * 8 * 2048;
+        auto kern = pg_obs_images_kernel<KS>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(dpgp_ceil_div(N, 256), D), dim3(256), lds, st, N, Q, consts, mu, s, gamma, cobs, robs, xobs,
+                           L.NT, flag);
+        DPGP_LAUNCH_CHECK();
+    }
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(L.Ppad, 256), D), dim3(256), 0, st, M, Q, consts,
+                       (const float *)u, (const float *)kap, rpair, xpair);
     DPGP_LAUNCH_CHECK();
     // rows per chunk: row image (LDA halves) + transposed feature image (64 halves) per row within 80 KB (2 workgroups per CU)
     const size_t row = sizeof(_Float16) * (size_t)(16 * KS + PG_APAD + 64);
-    const int R = (int)((80 * 1024 - PG_HDR) / row) & ~31;
-    const size_t lds = PG_HDR + row * (size_t)R;
+    const int R = (int)((80 * 1024) / row) & ~31;
+    const size_t lds = row * (size_t)R;
+    auto kern = pg_pass_kernel<KS>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DPGP_ERR_LAUNCH;
     for (int pass = 1; pass <= 2; ++pass) {
-        auto kern = pass == 1 ? pg_pass_kernel<KS, 1> : pg_pass_kernel<KS, 2>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return DPGP_ERR_LAUNCH;
-        const int n_rows = pass == 1 ? N : L.Ppad, n_col_tiles = pass == 1 ? L.PT : L.NT;
+        const int n_row_tiles = pass == 1 ? L.NT : L.PT, n_col_tiles = pass == 1 ? L.PT : L.NT;
         const int groups = dpgp_ceil_div(n_col_tiles, 4 * PG_G);
         const long long nwg = (long long)D * groups;
         if (nwg > 0x7fffffffLL) return -1;
-        DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, N, M, Q, D, consts, mu, s, gamma, (const float *)u,
-                           (const float *)kap, (const _Float16 *)aimg, pass == 1 ? r2 : r1, n_rows, n_col_tiles, groups, R, flag);
+        DPGP_PRELAUNCH();
+        if (pass == 1)
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, (const _Float16 *)robs, 1, (const _Float16 *)xobs, pimg, 0, r2,
+                               n_row_tiles, n_col_tiles, groups, R);
+        else
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, (const _Float16 *)rpair, 0, (const _Float16 *)xpair,
+                               (const _Float16 *)cobs, 1, r1, n_row_tiles, n_col_tiles, groups, R);
         DPGP_LAUNCH_CHECK();
     }
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_finish_pairs_kernel, dim3(dpgp_ceil_div(L.P, 256)), dim3(256), 0, st, M, Q, D, L.Ppad, z, gamma,
-                       (const float *)u, (const float *)r2, t1, t2);
+    const int dcp = dpgp_ceil_div(D, PG_DC_PAIRS), ncp = dpgp_ceil_div(D, dcp);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_finish_pairs_kernel, dim3(dpgp_ceil_div(L.P, 256), ncp), dim3(256), 0, st, M, Q, D, L.Ppad, dcp, gamma,
+                       (const float *)u, (const float *)r2, tp);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_gather_dz_kernel, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, z, consts, (const double *)t1,
-                       (const double *)t2, dz);
+    const size_t n3 = (size_t)3 * L.P * Q;
+    int rc = launch_reduce_rows<double>(n3, n3, ncp, tp, tt, 0, nullptr, st);
+    if (rc != DPGP_OK) return rc;
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_gather_dz_kernel, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, z, consts, (const double *)tt, dz);
     DPGP_LAUNCH_CHECK();
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_dgamma_pairs_kernel, dim3(D), dim3(256), 0, st, M, Q, L.Ppad, z, (const float *)u, (const float *)r2,
                        dgamma);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_finish_obs_kernel, dim3(L.nblk_obs), dim3(256), 0, st, N, Q, D, L.NT, consts, mu, s, gamma,
-                       (const float *)kap, (const float *)r1, dmu, ds, dgp);
+    const int dco = dpgp_ceil_div(D, PG_DC_OBS), nco = dpgp_ceil_div(D, dco);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_finish_obs_kernel, dim3(L.nblk_obs, nco), dim3(256), 0, st, N, Q, D, L.NT, dco, consts, mu, s, gamma,
+                       (const float *)kap, (const float *)r1, dmup, dsp, dgp);
     DPGP_LAUNCH_CHECK();
-    const size_t dq = (size_t)D * Q;
-    const int rc = launch_reduce_rows<double>(dq, dq, L.nblk_obs, dgp, dgamma, 1, stage, st);
+    const size_t dq = (size_t)D * Q, nq = (size_t)N * Q;
+    rc = launch_reduce_rows<double>(dq, dq, L.nblk_obs, dgp, dgamma, 1, nullptr, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dmup, dmu, 1, nullptr, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dsp, ds, 1, nullptr, st);
     if (rc != DPGP_OK) return rc;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_poison_kernel, dim3(1), dim3(1), 0, st, (const int *)flag, dmu, ds, dz, dgamma);
     DPGP_LAUNCH_CHECK();
+    (void)stage;
     return DPGP_OK;
 }
 
 // Psi2 part of stage B, ADDED to dmu [N,Q], ds [N,Q], dz [M,Q], dgamma [D,Q]; GP [D][Mp][Mp]: the adjoint of Psi2 (lower
-// triangle read); consts: psi2_consts (launch_psi2_consts); ws: psi2_pgrad_ws_bytes; stage: as launch_reduce_rows.
-// A range-guard hit (see psi2_pairs.hip) poisons the outputs with NaN (checked by the caller through the trouble flag).
+// triangle read); consts: psi2_consts (launch_psi2_consts); ws: psi2_pgrad_ws_bytes.
+// A range-guard hit (see psi2_pairs.hip) poisons the outputs with NaN (the caller's trouble flag sees it).
 int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
                       double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
