@@ -14,7 +14,7 @@
 // The round-1 kernel (psi2_grad_kernel, psi2.hip) walks the FULL M x M square per observation patch by patch (twice the
 // exponentials) and re-forms operands per observation; it stays for Q > 10.
 //
-// Workgroup = (output dim, 8 column tiles: 4 waves x 2 resident tiles); it loops over ALL row chunks with the second-product
+// Workgroup = (output dim, 16 column tiles: 4 waves x 4 resident tiles); it loops over ALL row chunks with the second-product
 // accumulators in registers and writes them once — no partial slabs, no atomics (bit-reproducible).
 #include <type_traits>
 #include "internal.h"
@@ -29,7 +29,10 @@ typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 #define PG_APAD 8
 #define PG_HDR 512
 #ifndef PG_G
-#define PG_G 2                       // resident column tiles per wave
+#define PG_G 4                       // resident column tiles per wave (2: the row images are re-read twice as often, 7.3 vs 6.6 ms at config 3)
+#endif
+#ifndef PG_STAGGER
+#define PG_STAGGER 1
 #endif
 #define PG_NF 32                     // feature rows of the second product (2Q + 1 used)
 
@@ -269,8 +272,12 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restr
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[g][v] = 0.0f;
 
-    for (int rt0 = 0; rt0 < n_row_tiles; rt0 += NTc) {
-        const int ntile = min(NTc, n_row_tiles - rt0);
+    // The copy of a chunk (L2 -> LDS) and the work on it do not overlap within a workgroup, and two workgroups that start
+    // together on a compute unit stay in step (same work): odd workgroups start with half a chunk, so that one copies while
+    // the other computes.
+    int first = (PG_STAGGER && (blockIdx.x & 1) && NTc > 1) ? NTc / 2 : NTc;
+    for (int rt0 = 0, step = first; rt0 < n_row_tiles; rt0 += step, step = NTc) {
+        const int ntile = min(step, n_row_tiles - rt0);
         if (rt0) __syncthreads();
         for (int e = t; e < ntile * 32 * (SLP / 8); e += 256) {
             const int row = e / (SLP / 8), w = e - row * (SLP / 8);
@@ -281,6 +288,9 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restr
             reinterpret_cast<pg_u4 *>(xt)[((rem >> 7) * NTc + rt) * 128 + (rem & 127)] = xsrc[(size_t)rt0 * 256 + e];
         }
         __syncthreads();
+#ifdef PG_DIAG_NO_COMPUTE           // (timing experiments only: wrong results)
+        if (ntile > 0) continue;
+#endif
         for (int nt = 0; nt < ntile; ++nt) {
             pg_h8 a[KS], xh[2], xl[2];
 #pragma unroll
@@ -298,32 +308,24 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restr
                 for (int v = 0; v < 16; ++v) c[v] = 0.0f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bop[g][ks], c, 0, 0, 0);
-                // W = exp2(E) as f16 (hi, lo) pairs, two values per instruction where the ISA has it: v_cvt_pk_f16_f32 (round to
-                // nearest even) for the hi halves, v_fma_mix_f32 (f16 source) for the residuals e - hi, v_cvt_pk_f16_f32 again
-                pg_u4 whw[2], wlw[2];
+                // W = exp2(E) as f16 (hi, lo) pairs.  Plain C on purpose: with the split written as inline asm (v_cvt_pk_f16_f32 +
+                // v_fma_mix_f32, 2 instructions per value instead of 3) the compiler's hazard recognizer does not see a VALU
+                // write, and with 4 resident tiles the registers of the previous tile's operands are overwritten while its
+                // MFMAs still read them (measured: non-deterministic garbage; 2 resident tiles happened to get fresh registers).
+                pg_h8 whv[2], wlv[2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float e0 = __builtin_amdgcn_exp2f(c[2 * i]), e1 = __builtin_amdgcn_exp2f(c[2 * i + 1]);
-                    unsigned ph, pl;
-                    float l0, l1;
-                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(e0), "v"(e1));
-                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph), "v"(e0));
-                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(e1));
-                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pl) : "v"(l0), "v"(l1));
-                    whw[i >> 2][i & 3] = ph;
-                    wlw[i >> 2][i & 3] = pl;
-                }
-                pg_h8 wh[2], wl[2];
-#pragma unroll
-                for (int s_ = 0; s_ < 2; ++s_) {
-                    wh[s_] = __builtin_bit_cast(pg_h8, whw[s_]);
-                    wl[s_] = __builtin_bit_cast(pg_h8, wlw[s_]);
+                for (int v = 0; v < 16; ++v) {
+                    const float e = dpgp_pin(__builtin_amdgcn_exp2f(c[v]));
+                    const _Float16 eh = (_Float16)e;
+                    whv[v >> 3][v & 7] = eh;
+                    wlv[v >> 3][v & 7] = (_Float16)(e - (float)eh);
                 }
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s_], wh[s_], acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s_], wl[s_], acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[s_], wh[s_], acc[g], 0, 0, 0);
+                    const pg_h8 wh = whv[s_], wl = wlv[s_];
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s_], wh, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s_], wl, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[s_], wh, acc[g], 0, 0, 0);
                 }
             }
         }
