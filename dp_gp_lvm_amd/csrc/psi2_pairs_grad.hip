@@ -31,9 +31,6 @@ typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 #ifndef PG_G
 #define PG_G 4                       // resident column tiles per wave (2: the row images are re-read twice as often, 7.3 vs 6.6 ms at config 3)
 #endif
-#ifndef PG_STAGGER
-#define PG_STAGGER 1
-#endif
 #define PG_NF 32                     // feature rows of the second product (2Q + 1 used)
 
 // position of (feature f, row rr of a 32-row tile) in the transposed feature image of one (kind, row tile): the k-slot order
@@ -249,15 +246,36 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restr
                                                          int groups_per_d, int R) {
     constexpr int SLP = 16 * KS, LDA = SLP + PG_APAD, G = PG_G;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    _Float16 *ri = reinterpret_cast<_Float16 *>(smem_raw);                         // [R][LDA]
-    _Float16 *xt = ri + (size_t)R * LDA;                                            // [2 kinds][R / 32][2][64][8]
+    // Two LDS buffers of NTb = R / 32 row tiles each, filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, the
+    // data lands while the waves compute on the other buffer).  The destination of one wave-instruction is lane-linear (base +
+    // 16 lane), so a buffer is one array of 16-byte slots — [row][LDA halves] rows, then the feature image [kind][tile][128
+    // slots] — and every lane computes the SOURCE address of its slot (the padding slots of a row fetch any valid word).
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int SPR = LDA / 8, DPR = SLP / 8;                 // 16-byte slots per LDS row / per image row
+    const int NTb = R / 32, ri_slots = ((NTb * 32 * SPR + 63) / 64) * 64;
+    const size_t buf_bytes = (size_t)16 * (ri_slots + NTb * 256);
     const int d = blockIdx.x / groups_per_d, cg = blockIdx.x - d * groups_per_d;
     const int t = threadIdx.x, lane = t & 63, l5 = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int NTc = R / 32;
-    const pg_u4 *rsrc = reinterpret_cast<const pg_u4 *>(rimg) + (row_per_d ? (size_t)d * n_row_tiles * 32 * (SLP / 8) : 0);
+    const int NTc = NTb;
+    const pg_u4 *rsrc = reinterpret_cast<const pg_u4 *>(rimg) + (row_per_d ? (size_t)d * n_row_tiles * 32 * DPR : 0);
     const pg_u4 *xsrc = reinterpret_cast<const pg_u4 *>(ximg) + (size_t)d * n_row_tiles * 256;
     const _Float16 *csrc = cimg + (col_per_d ? (size_t)d * n_col_tiles * KS * 64 * 8 : 0);
+    auto fill = [&](int buf, int rt0, int ntile) __attribute__((always_inline)) {
+        unsigned char *base = smem_raw + (size_t)buf * buf_bytes;
+        const int n_ri = ntile * 32 * SPR, n_ri_instr = (n_ri + 63) >> 6;
+        for (int i = wv; i < n_ri_instr; i += 4) {               // (wave-uniform trip count)
+            const int j = 64 * i + lane, row = j / SPR, col = j - row * SPR;
+            const pg_u4 *src = rsrc;
+            if (j < n_ri && col < DPR) src = rsrc + ((size_t)rt0 * 32 + row) * DPR + col;
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(base + (size_t)1024 * i), 16, 0, 0);
+        }
+        for (int i = wv; i < ntile * 4; i += 4) {                 // feature image: (tile, kind, half of 128 slots) per instruction
+            const int rt = i >> 2, kind = (i >> 1) & 1, hf = i & 1;
+            const pg_u4 *src = xsrc + ((size_t)(rt0 + rt) * 256 + kind * 128 + hf * 64 + lane);
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(base + (size_t)16 * (ri_slots + (kind * NTb + rt) * 128 + hf * 64)), 16, 0, 0);
+        }
+    };
     pg_h8 bop[G][KS];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -272,30 +290,51 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restr
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[g][v] = 0.0f;
 
-    // The copy of a chunk (L2 -> LDS) and the work on it do not overlap within a workgroup, and two workgroups that start
-    // together on a compute unit stay in step (same work): odd workgroups start with half a chunk, so that one copies while
-    // the other computes.
-    int first = (PG_STAGGER && (blockIdx.x & 1) && NTc > 1) ? NTc / 2 : NTc;
-    for (int rt0 = 0, step = first; rt0 < n_row_tiles; rt0 += step, step = NTc) {
-        const int ntile = min(step, n_row_tiles - rt0);
-        if (rt0) __syncthreads();
-        for (int e = t; e < ntile * 32 * (SLP / 8); e += 256) {
-            const int row = e / (SLP / 8), w = e - row * (SLP / 8);
-            *reinterpret_cast<pg_u4 *>(ri + (size_t)row * LDA + 8 * w) = rsrc[(size_t)rt0 * 32 * (SLP / 8) + e];
-        }
-        for (int e = t; e < ntile * 256; e += 256) {
-            const int rt = e >> 8, rem = e & 255;
-            reinterpret_cast<pg_u4 *>(xt)[((rem >> 7) * NTc + rt) * 128 + (rem & 127)] = xsrc[(size_t)rt0 * 256 + e];
-        }
-        __syncthreads();
-#ifdef PG_DIAG_NO_COMPUTE           // (timing experiments only: wrong results)
-        if (ntile > 0) continue;
-#endif
-        for (int nt = 0; nt < ntile; ++nt) {
-            pg_h8 a[KS], xh[2], xl[2];
+    fill(0, 0, min(NTb, n_row_tiles));
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    for (int rt0 = 0, cb = 0; rt0 < n_row_tiles; rt0 += NTb, cb ^= 1) {
+        const int ntile = min(NTb, n_row_tiles - rt0);
+        if (rt0 + NTb < n_row_tiles) fill(cb ^ 1, rt0 + NTb, min(NTb, n_row_tiles - rt0 - NTb));   // lands during the work below
+        const _Float16 *ri = reinterpret_cast<const _Float16 *>(smem_raw + (size_t)cb * buf_bytes);
+        const _Float16 *xt = ri + (size_t)8 * ri_slots;
+        // ---- software pipeline over the tile steps (row tile nt, resident tile g) --------------------------------------
+        // Per step the matrix pipe has KS + 6 MFMAs and the vector unit 16 exp + the (hi, lo) split of W; one wave's
+        // instruction stream alternates them.  Step k runs
+        //   first half  (values 0-7 of its exponent tile): the exponent chain of step k + 1  and  the K-step-1 products of step k - 1
+        //   second half (values 8-15):                      the K-step-0 products of step k (their operands are complete by then)
+        // two independent accumulation chains alternate on the pipe.  The last step of a row tile finishes its own products
+        // (the feature operands change with the row tile).
+        auto load_a = [&](pg_h8 (&a)[KS], int nt) __attribute__((always_inline)) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 a[ks] = *reinterpret_cast<const pg_h8 *>(ri + (size_t)(32 * nt + l5) * LDA + 16 * ks + 8 * half);
+        };
+        // values 2i, 2i + 1 of the exponent tile -> halves 2i, 2i + 1 of the (hi, lo) operands.  NOT inline asm
+        // (v_cvt_pk_f16_f32 + v_fma_mix_f32 would be 2 instructions per value instead of 3): the compiler's hazard recognizer
+        // does not see a VALU write inside an asm statement, and the operand registers of an MFMA still in flight were
+        // overwritten (measured: non-deterministic garbage as soon as registers are reused across tiles).
+        auto pair = [&](const pg_f16v &c, int i, pg_h8 (&wh)[2], pg_h8 (&wl)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int v = 2 * i; v < 2 * i + 2; ++v) {
+                const float e = dpgp_pin(__builtin_amdgcn_exp2f(c[v]));
+                const _Float16 eh = (_Float16)e;
+                wh[v >> 3][v & 7] = eh;
+                wl[v >> 3][v & 7] = (_Float16)(e - (float)eh);
+            }
+        };
+#define PG_MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+#define PG_PAIR(C, I) pair(C, I, wh, wl); __builtin_amdgcn_sched_barrier(0)
+        pg_h8 a_cur[KS], a_nxt[KS], xh[2], xl[2], wh[2], wl[2];
+        pg_f16v c_cur, c_nxt;
+        load_a(a_cur, 0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) c_cur[v] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) c_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[ks], bop[0][ks], c_cur, 0, 0, 0);
+#pragma unroll 1
+        for (int nt = 0; nt < ntile; ++nt) {
+            load_a(a_nxt, min(nt + 1, ntile - 1));
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) {
                 xh[s_] = *reinterpret_cast<const pg_h8 *>(xt + (((size_t)(0 * NTc + nt) * 2 + s_) * 64 + lane) * 8);
@@ -303,32 +342,49 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restr
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                pg_f16v c;
+                // the exponent chain of the next step: tile g + 1 of this row tile, or tile 0 of the next one (behind the last
+                // row tile of the chunk: one surplus chain)
+                const pg_h8 (&an)[KS] = (g + 1 < G) ? a_cur : a_nxt;
+                const pg_h8 (&bn)[KS] = bop[(g + 1) % G];
 #pragma unroll
-                for (int v = 0; v < 16; ++v) c[v] = 0.0f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bop[g][ks], c, 0, 0, 0);
-                // W = exp2(E) as f16 (hi, lo) pairs.  Plain C on purpose: with the split written as inline asm (v_cvt_pk_f16_f32 +
-                // v_fma_mix_f32, 2 instructions per value instead of 3) the compiler's hazard recognizer does not see a VALU
-                // write, and with 4 resident tiles the registers of the previous tile's operands are overwritten while its
-                // MFMAs still read them (measured: non-deterministic garbage; 2 resident tiles happened to get fresh registers).
-                pg_h8 whv[2], wlv[2];
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float e = dpgp_pin(__builtin_amdgcn_exp2f(c[v]));
-                    const _Float16 eh = (_Float16)e;
-                    whv[v >> 3][v & 7] = eh;
-                    wlv[v >> 3][v & 7] = (_Float16)(e - (float)eh);
+                for (int v = 0; v < 16; ++v) c_nxt[v] = 0.0f;
+                const pg_h8 wh1 = wh[1], wl1 = wl[1];             // (of step k - 1)
+                // ---- first half ----
+                PG_MMA(an[0], bn[0], c_nxt);
+                PG_PAIR(c_cur, 0);
+                if (g > 0) { PG_MMA(xh[1], wh1, acc[g > 0 ? g - 1 : 0]); }
+                if (KS > 1) { PG_MMA(an[1 % KS], bn[1 % KS], c_nxt); }
+                PG_PAIR(c_cur, 1);
+                if (g > 0) { PG_MMA(xh[1], wl1, acc[g > 0 ? g - 1 : 0]); }
+                if (KS > 2) { PG_MMA(an[2 % KS], bn[2 % KS], c_nxt); }
+                PG_PAIR(c_cur, 2);
+                if (g > 0) { PG_MMA(xl[1], wh1, acc[g > 0 ? g - 1 : 0]); }
+                if (KS > 3) { PG_MMA(an[3 % KS], bn[3 % KS], c_nxt); }
+                PG_PAIR(c_cur, 3);
+                // ---- second half ----
+                const pg_h8 wh0 = wh[0], wl0 = wl[0];
+                PG_MMA(xh[0], wh0, acc[g]);
+                PG_PAIR(c_cur, 4);
+                PG_MMA(xh[0], wl0, acc[g]);
+                PG_PAIR(c_cur, 5);
+                PG_MMA(xl[0], wh0, acc[g]);
+                PG_PAIR(c_cur, 6);
+                PG_PAIR(c_cur, 7);
+                if (g == G - 1) {                                  // the row tile's last step finishes its own K-step-1 products
+                    const pg_h8 wh1e = wh[1], wl1e = wl[1];
+                    PG_MMA(xh[1], wh1e, acc[g]);
+                    PG_MMA(xh[1], wl1e, acc[g]);
+                    PG_MMA(xl[1], wh1e, acc[g]);
                 }
-#pragma unroll
-                for (int s_ = 0; s_ < 2; ++s_) {
-                    const pg_h8 wh = whv[s_], wl = wlv[s_];
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s_], wh, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s_], wl, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[s_], wh, acc[g], 0, 0, 0);
-                }
+                c_cur = c_nxt;
             }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
         }
+#undef PG_MMA
+#undef PG_PAIR
+        __builtin_amdgcn_s_waitcnt(0);                            // this wave's LDS-DMAs of the next chunk have landed ...
+        __syncthreads();                                           // ... everybody's have, and everybody is done with this buffer
     }
     // ---- out[d][column][f]: register v of lane (column l5, half) is feature 8 (v / 4) + 4 half + v % 4 ----
 #pragma unroll
@@ -585,10 +641,13 @@ static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *cons
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(L.Ppad, 256), D), dim3(256), 0, st, M, Q, consts,
                        (const float *)u, (const float *)kap, rpair, xpair);
     DPGP_LAUNCH_CHECK();
-    // rows per chunk: row image (LDA halves) + transposed feature image (64 halves) per row within 80 KB (2 workgroups per CU)
+    // two LDS buffers per workgroup within 80 KB (2 workgroups per CU): row tiles per buffer from the bytes of a row (row image
+    // LDA halves + feature image 64 halves); the row-image region is rounded up to whole wave-instructions of the LDS-DMA fill
     const size_t row = sizeof(_Float16) * (size_t)(16 * KS + PG_APAD + 64);
-    const int R = (int)((80 * 1024) / row) & ~31;
-    const size_t lds = row * (size_t)R;
+    int NTb = (int)((40 * 1024) / (32 * row));
+    while (NTb > 1 && (size_t)16 * (((NTb * 32 * (16 * KS + PG_APAD) / 8 + 63) / 64) * 64 + NTb * 256) > 40 * 1024) --NTb;
+    const int R = 32 * NTb;
+    const size_t lds = (size_t)2 * 16 * (((NTb * 32 * (16 * KS + PG_APAD) / 8 + 63) / 64) * 64 + NTb * 256);
     auto kern = pg_pass_kernel<KS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DPGP_ERR_LAUNCH;
