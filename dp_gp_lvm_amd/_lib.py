@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('DPGP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libdpg
 
 FLAG_NOISE, FLAG_JITTER = 1, 2
 ALGO = {'auto': 0, 'plain': 1, 'mfma_f32': 2, 'patch_f16': 3}
-PREC = {'f32': 0, 'mixed': 1, 'f64': 2}
+PREC = {'f32': 0, 'mixed': 1, 'f64': 2, 'mixed_patch': 3}
 
 _vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
 _ll = ctypes.c_longlong

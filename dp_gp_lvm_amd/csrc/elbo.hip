@@ -176,6 +176,8 @@ extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y
     if (!g_psi2) return -12;
     if (!w_kuu) return -13;
     if (!g_v && !g_psi1) return -14;
+    const bool patch_form = (prec == DPGP_PREC_MIXED_PATCH);
+    if (patch_form) prec = DPGP_PREC_MIXED;
     if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_F64) return -15;
     if (g_psi1 && (prec != DPGP_PREC_MIXED || !psi2_grad_supported(M, Q))) return -15;
     if (!ws) return -16;
@@ -212,7 +214,7 @@ extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y
         rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, g_psi1, ws1, stage, d_mu, d_s, d_z, d_gamma, st);
         if (rc != DPGP_OK) return rc;
         // the Psi2 term: pair-tile form (psi2_pairs_grad.hip) where it exists, else the per-observation patch form
-        if (psi2_pgrad_supported(M, Q) && !getenv("DPGP_GRAD_PATCH")) {       // (DPGP_GRAD_PATCH: experiments / cross-check)
+        if (psi2_pgrad_supported(M, Q) && !patch_form && !getenv("DPGP_GRAD_PATCH")) {   // (DPGP_GRAD_PATCH: experiments)
             unsigned char *pgws = reinterpret_cast<unsigned char *>(stage) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
             return launch_psi2_pgrad(D, N, M, Q, consts, z, mu, s, gamma, alpha, g_psi2, pgws, stage, d_mu, d_s, d_z, d_gamma, st);
         }

@@ -31,6 +31,8 @@ typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 #ifndef PG_G
 #define PG_G 4                       // resident column tiles per wave (2: the row images are re-read twice as often, 7.3 vs 6.6 ms at config 3)
 #endif
+#define PG_WSHIFT 12.0f              // the exponent tiles carry + PG_WSHIFT: W = 2^12 exp2(E) <= 4096 uses the f16 range downwards
+                                     // (f16 pairs resolve W / max W down to ~2^-36 instead of 2^-24); undone in the finishing kernels
 #define PG_NF 32                     // feature rows of the second product (2Q + 1 used)
 
 // position of (feature f, row rr of a 32-row tile) in the transposed feature image of one (kind, row tile): the k-slot order
@@ -77,7 +79,7 @@ __device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const doubl
             }
         }
         oor = !(cc >= -8192.0f);                                  // range guard of the f16-split exponent (psi2_pairs.hip)
-        cc = fmaxf(cc, -60000.0f);
+        cc = fmaxf(cc, -60000.0f) + PG_WSHIFT;
     } else {
         for (int q = 0; q < 3 * Q; ++q) dst[q] = 0u;
         if (xh)
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int 
     for (int q = 0; q < DPGP_MAX_Q; ++q) { a1[q] = 0.0; a2[q] = 0.0; a3[q] = 0.0; }
     const int d1 = min(D, (c + 1) * dchunk);
     for (int d = c * dchunk; d < d1; ++d) {
-        const float ud = u[(size_t)d * Ppad + p];
+        const float ud = u[(size_t)d * Ppad + p] * (1.0f / 4096.0f);          // (x 2^-PG_WSHIFT)
         const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r2 + ((size_t)d * Ppad + p) * PG_NF);
         float rv[PG_NF];
 #pragma unroll
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int 
     for (int p = t; p < P; p += 256) {
         int m, mp;
         psi2_pair_of(p, m, mp);
-        const double uc = (double)u[(size_t)d * Ppad + p] * (double)r2[((size_t)d * Ppad + p) * PG_NF + 2 * Q];
+        const double uc = (double)u[(size_t)d * Ppad + p] * (double)r2[((size_t)d * Ppad + p) * PG_NF + 2 * Q] * (1.0 / 4096.0);
 #pragma unroll
         for (int q = 0; q < DPGP_MAX_Q; ++q)
             if (q < Q) {
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D,
     }
     const int d1 = min(D, (c + 1) * dchunk);
     for (int d = c * dchunk; d < d1; ++d) {
-        const double ik = 1.0 / (double)kap[d];
+        const double ik = 1.0 / ((double)kap[d] * 4096.0);            // (kap_d and 2^PG_WSHIFT)
         const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r1 + ((size_t)d * NT * 32 + (ok ? n : 0)) * PG_NF);
         float rv[PG_NF];
 #pragma unroll

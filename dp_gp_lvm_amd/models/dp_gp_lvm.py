@@ -70,6 +70,11 @@ def dp_gp_lvm(y_train,
         'less than the number of observations.'
     assert precision in _lib.PREC, 'precision must be one of %s' % sorted(_lib.PREC)
     assert backward_precision in (None, 'mixed', 'f64'), "backward_precision must be None, 'mixed' or 'f64'"
+    # stage B behind an fp64 forward pass (the training configuration): the patch form of the Psi2 term, which keeps its accuracy
+    # where the adjoints cancel (include/dpgp.h, DPGP_PREC_MIXED_PATCH); behind a mixed forward pass the faster pair-tile form
+    stage_b_precision = backward_precision or precision
+    if precision == 'f64' and backward_precision == 'mixed':
+        stage_b_precision = 'mixed_patch'
     assert psi_algo in _lib.ALGO, 'psi_algo must be one of %s' % sorted(_lib.ALGO)
     assert truncation_level <= 64, 'truncation levels above 64 are not supported by the HIP model kernels (PREP_MAX_T)'
     device = default_device() if device is None else torch.device(device)
@@ -214,7 +219,7 @@ def dp_gp_lvm(y_train,
                                                  gamma=buf['gamma'])
         mark(1)
         dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
-                                            prec=backward_precision or precision)
+                                            prec=stage_b_precision)
         mark(2)
         rows = r['logits'].shape[0]
         sizes = [num_samples * num_latent_dims, num_samples * num_latent_dims, num_inducing_points * num_latent_dims,

@@ -45,6 +45,12 @@ extern "C" {
 #define DPGP_PREC_F32 0   /* psi-statistics fp32, Cholesky chain fp32                          */
 #define DPGP_PREC_MIXED 1 /* psi-statistics fp32 (MFMA), Cholesky chain + reductions fp64      */
 #define DPGP_PREC_F64 2   /* everything fp64                                                   */
+#define DPGP_PREC_MIXED_PATCH 3 /* dpgp_elbo_grad_psi[_ex] only: as DPGP_PREC_MIXED, the Psi2 term in the per-observation patch
+                                 * form (psi2_grad_kernel) instead of the pair-tile form (psi2_pairs_grad.hip).  The pair-tile form
+                                 * is faster (config 3: 6.7 vs 8.0 ms) but sums a' and b weighted exponentials SEPARATELY before
+                                 * they cancel in 2 a s + b; where the adjoints themselves cancel heavily (K_uu nearly singular:
+                                 * an fp64 forward pass with this stage in mixed precision) the patch form keeps 2e-3 of the
+                                 * largest gradient entry, the pair form 7e-3 (tests/test_gpu_illcond.py) */
 
 /* info[] codes besides the LAPACK-style positive ones (fused ELBO only; 0 = fine):
  *   DPGP_INFO_ILL_CONDITIONED: with an fp32 Psi2 (DPGP_PREC_MIXED / DPGP_PREC_F32) the rounding of Psi2, amplified by

@@ -341,3 +341,30 @@ def test_fp64_forward_with_matrix_pipe_stage_b(dev, fixture):
         want = g['grad_' + ref_name]
         have = got[raw_name].cpu().numpy().reshape(want.shape)
         np.testing.assert_allclose(have, want, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(want).max()), err_msg=ref_name)
+
+
+@pytest.mark.parametrize('shape', [(40, 6, 12, 3), (33, 5, 17, 5), (200, 6, 70, 4), (300, 16, 100, 10), (260, 3, 200, 7)])
+def test_pair_tile_and_patch_forms_of_stage_b_agree(dev, shape):
+    """The Psi2 term of stage B exists in two forms (include/dpgp.h: DPGP_PREC_MIXED = pair tiles, psi2_pairs_grad.hip;
+    DPGP_PREC_MIXED_PATCH = per-observation patches, psi2_grad_kernel): same adjoints in, the four gradients must agree to the
+    mixed tolerance (measured 1e-5 ... 4e-5 of the largest entry on well-conditioned adjoints; the test feeds a smooth positive
+    definite adjoint — with a random indefinite one the two differ by 5e-3 through cancellation)."""
+    n, d, m, q = shape
+    rng = np.random.default_rng(m)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    y = rng.standard_normal((n, d))
+    z = rng.standard_normal((m, q)) * 2.0
+    mu = rng.standard_normal((n, q)) * 1.5
+    s = np.exp(0.3 * rng.standard_normal((n, q)))
+    gamma = np.exp(0.3 * rng.standard_normal((d, q))) * 1.5
+    alpha = np.exp(0.2 * rng.standard_normal(d))
+    mp = 16 * ((m + 15) // 16)
+    dist = ((z[:, None, :] - z[None, :, :]) ** 2).sum(-1)
+    g = np.zeros((d, mp, mp))
+    g[:, :m, :m] = np.exp(-0.1 * dist)[None] * (1.0 + 0.1 * rng.standard_normal((d, 1, 1)))
+    wk, gv = np.zeros((d, mp, mp)), np.zeros((d, mp))
+    args = (t(y), t(z), t(mu), t(s), t(gamma), t(alpha), t(g), t(wk), t(gv))
+    pair = ops.elbo_grad_psi(*args, prec='mixed')
+    patch = ops.elbo_grad_psi(*args, prec='mixed_patch')
+    for name, a, b in zip(('d mu', 'd S', 'd z', 'd gamma'), pair, patch):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-4 * float(b.abs().max()), err_msg=name)
