@@ -352,8 +352,10 @@ def main():
                 return 1e3 * (time.perf_counter() - t1) / reps
             reps = 10
             res['objective_and_gradients'] = {'ms': grad_ms(model, reps), 'reps': reps,
-                                              'note': 'stage B of the backward pass on the matrix pipe in mixed precision '
-                                                      '(psi2_grad_kernel), plain kernel in f64; DESIGN.md 7.1'}
+                                              'note': 'stage B of the backward pass on the matrix pipe in mixed precision: '
+                                                      'Psi2 term in the pair-tile form (psi2_pairs_grad.hip, Q <= 10; patch form '
+                                                      'psi2_grad_kernel otherwise and behind an fp64 forward pass), plain kernel '
+                                                      'in f64; DESIGN.md 7.1'}
             # breakdown of one more iteration (torch events on the launch stream): forward, stage A, stage B, chain rule; and
             # the exponential rate of stage B (its Psi2 term evaluates the FULL M x M square of every (d, n))
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -362,8 +364,11 @@ def main():
             torch.cuda.synchronize()
             t_fwd, t_a, t_b, t_c = (evs[4].elapsed_time(evs[0]), evs[0].elapsed_time(evs[1]), evs[1].elapsed_time(evs[2]),
                                     evs[2].elapsed_time(evs[3]))
+            # exponentials of the Psi2 term: two passes over the M (M + 1) / 2 pairs (pair-tile form), or the full square of
+            # 64 x 64 patches (patch form)
             mp64 = 64 * ((m + 63) // 64)
-            exps_b = float(n) * (d_hi - d_lo) * mp64 * mp64
+            pair_form = a.prec == 'mixed' and q <= 10
+            exps_b = float(n) * (d_hi - d_lo) * (2.0 * (m * (m + 1) // 2) if pair_form else mp64 * mp64)
             res['objective_and_gradients'].update({
                 'forward_ms': t_fwd, 'stage_a_ms': t_a, 'stage_b_ms': t_b, 'chain_rule_ms': t_c,
                 'stage_b_exp_per_s': exps_b / (t_b * 1e-3), 'stage_b_exp_frac_of_v_exp_rate': exps_b / (t_b * 1e-3) / exp_peak})
