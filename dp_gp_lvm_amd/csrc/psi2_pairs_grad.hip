@@ -33,6 +33,9 @@ typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 #endif
 #define PG_WSHIFT 12.0f              // the exponent tiles carry + PG_WSHIFT: W = 2^12 exp2(E) <= 4096 uses the f16 range downwards
                                      // (f16 pairs resolve W / max W down to ~2^-36 instead of 2^-24); undone in the finishing kernels
+#ifndef PG_OCC
+#define PG_OCC 2                     // workgroups per compute unit the pass kernel is built for (registers, LDS buffers)
+#endif
 #define PG_NF 32                     // feature rows of the second product (2Q + 1 used)
 
 // position of (feature f, row rr of a 32-row tile) in the transposed feature image of one (kind, row tile): the k-slot order
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void pg_pair_images_kernel(int M, int Q, const
 // pairs; pass 2: rows = pairs, columns = observations of output dim d.  row_set / x_set / col_set: 1 = the images are per
 // output dim, 0 = shared.
 template <int KS>
-__global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
+__global__ __launch_bounds__(256, PG_OCC) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
                                                          const _Float16 *__restrict__ ximg, const _Float16 *__restrict__ cimg,
                                                          int col_per_d, float *__restrict__ out, int n_row_tiles, int n_col_tiles,
                                                          int groups_per_d, int R) {
@@ -325,8 +328,16 @@ __global__ __launch_bounds__(256, 2) void pg_pass_kernel(const _Float16 *__restr
                 wl[v >> 3][v & 7] = (_Float16)(e - (float)eh);
             }
         };
+#ifdef PG_DIAG_NO_MMA               // (timing experiments only: wrong results)
+#define PG_MMA(A, B, C) __builtin_amdgcn_sched_barrier(0)
+#else
 #define PG_MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef PG_DIAG_NO_VALU              // (timing experiments only: wrong results)
+#define PG_PAIR(C, I) __builtin_amdgcn_sched_barrier(0)
+#else
 #define PG_PAIR(C, I) pair(C, I, wh, wl); __builtin_amdgcn_sched_barrier(0)
+#endif
         pg_h8 a_cur[KS], a_nxt[KS], xh[2], xl[2], wh[2], wl[2];
         pg_f16v c_cur, c_nxt;
         load_a(a_cur, 0);
@@ -646,8 +657,9 @@ static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *cons
     // two LDS buffers per workgroup within 80 KB (2 workgroups per CU): row tiles per buffer from the bytes of a row (row image
     // LDA halves + feature image 64 halves); the row-image region is rounded up to whole wave-instructions of the LDS-DMA fill
     const size_t row = sizeof(_Float16) * (size_t)(16 * KS + PG_APAD + 64);
-    int NTb = (int)((40 * 1024) / (32 * row));
-    while (NTb > 1 && (size_t)16 * (((NTb * 32 * (16 * KS + PG_APAD) / 8 + 63) / 64) * 64 + NTb * 256) > 40 * 1024) --NTb;
+    const size_t buf_budget = (size_t)(160 * 1024 / PG_OCC) / 2;
+    int NTb = (int)(buf_budget / (32 * row));
+    while (NTb > 1 && (size_t)16 * (((NTb * 32 * (16 * KS + PG_APAD) / 8 + 63) / 64) * 64 + NTb * 256) > buf_budget) --NTb;
     const int R = 32 * NTb;
     const size_t lds = (size_t)2 * 16 * (((NTb * 32 * (16 * KS + PG_APAD) / 8 + 63) / 64) * 64 + NTb * 256);
     auto kern = pg_pass_kernel<KS>;
