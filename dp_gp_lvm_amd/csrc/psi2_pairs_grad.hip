@@ -315,18 +315,24 @@ __global__ __launch_bounds__(256, PG_OCC) void pg_pass_kernel(const _Float16 *__
             for (int ks = 0; ks < KS; ++ks)
                 a[ks] = *reinterpret_cast<const pg_h8 *>(ri + (size_t)(32 * nt + l5) * LDA + 16 * ks + 8 * half);
         };
-        // values 2i, 2i + 1 of the exponent tile -> halves 2i, 2i + 1 of the (hi, lo) operands.  NOT inline asm
-        // (v_cvt_pk_f16_f32 + v_fma_mix_f32 would be 2 instructions per value instead of 3): the compiler's hazard recognizer
-        // does not see a VALU write inside an asm statement, and the operand registers of an MFMA still in flight were
-        // overwritten (measured: non-deterministic garbage as soon as registers are reused across tiles).
+        // values 2i, 2i + 1 of the exponent tile -> word i of the (hi, lo) operands: v_exp_f32 x 2, v_cvt_pk_f16_f32 (hi pair),
+        // v_fma_mix_f32 x 2 (e - hi from the f16 halves: one instruction instead of v_cvt_f32_f16 + v_sub_f32), v_cvt_pk_f16_f32
+        // (lo pair).  Only the fma_mix is inline asm, and it works IN PLACE on the register of e: inline-asm VALU writes are
+        // invisible to the compiler's hazard recognizer — with the conversions that write the MFMA OPERANDS in asm, operand
+        // registers of an MFMA still in flight were overwritten (measured: non-deterministic garbage as soon as registers were
+        // reused across tiles).  e's register was just written by v_exp_f32 (checked by the compiler, never an MFMA operand),
+        // and the operand words are written by compiler-visible conversions.
+        typedef _Float16 pg_h2v __attribute__((ext_vector_type(2)));
         auto pair = [&](const pg_f16v &c, int i, pg_h8 (&wh)[2], pg_h8 (&wl)[2]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int v = 2 * i; v < 2 * i + 2; ++v) {
-                const float e = dpgp_pin(__builtin_amdgcn_exp2f(c[v]));
-                const _Float16 eh = (_Float16)e;
-                wh[v >> 3][v & 7] = eh;
-                wl[v >> 3][v & 7] = (_Float16)(e - (float)eh);
-            }
+            float e0 = __builtin_amdgcn_exp2f(c[2 * i]), e1 = __builtin_amdgcn_exp2f(c[2 * i + 1]);
+            const pg_h2v hi = {(_Float16)e0, (_Float16)e1};
+            const unsigned ph = __builtin_bit_cast(unsigned, hi);
+            asm("s_nop 0\n\tv_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(e0) : "v"(ph));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(e1) : "v"(ph));
+            const pg_h2v lo = {(_Float16)e0, (_Float16)e1};
+            const int v = 2 * i;
+            wh[v >> 3][v & 7] = hi[0]; wh[v >> 3][(v & 7) + 1] = hi[1];
+            wl[v >> 3][v & 7] = lo[0]; wl[v >> 3][(v & 7) + 1] = lo[1];
         };
 #ifdef PG_DIAG_NO_MMA               // (timing experiments only: wrong results)
 #define PG_MMA(A, B, C) __builtin_amdgcn_sched_barrier(0)
