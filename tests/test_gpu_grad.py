@@ -368,3 +368,23 @@ def test_pair_tile_and_patch_forms_of_stage_b_agree(dev, shape):
     patch = ops.elbo_grad_psi(*args, prec='mixed_patch')
     for name, a, b in zip(('d mu', 'd S', 'd z', 'd gamma'), pair, patch):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-4 * float(b.abs().max()), err_msg=name)
+
+
+def test_pair_tile_stage_b_range_guard_poisons_the_gradients(dev):
+    """Observations ~100 length scales from the inducing inputs: the f16-split exponent of the pair-tile kernels is out of range
+    (|c''| > 8192, psi2_pairs.hip); the gradients must come back NaN — never finite garbage."""
+    n, d, m, q = 64, 4, 12, 3
+    rng = np.random.default_rng(5)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    z = rng.standard_normal((m, q))
+    mu = rng.standard_normal((n, q))
+    mu[7] += 300.0                                              # one observation far away in every latent dim
+    s = np.full((n, q), 0.01)
+    gamma = np.full((d, q), 4.0)
+    alpha = np.ones(d)
+    mp = 16
+    g = np.zeros((d, mp, mp))
+    g[:, :m, :m] = 1.0
+    out = ops.elbo_grad_psi(t(rng.standard_normal((n, d))), t(z), t(mu), t(s), t(gamma), t(alpha), t(g), t(np.zeros((d, mp, mp))),
+                            t(np.zeros((d, mp))), prec='mixed')
+    assert all(bool(torch.isnan(o).any()) for o in out)
