@@ -217,6 +217,8 @@ __global__ __launch_bounds__(256) void psi1T_y_kernel(int N, int M, int Q, int B
     __shared__ T mus[P1Y_NT][DPGP_MAX_Q + 2];
     __shared__ T cn[P1Y_NT], yn[P1Y_NT];
     __shared__ double red[4][128];
+    __shared__ double etab[DPGP_EXP2_TAB_ELEMS];             // fp64: table-based exp2 (dpgp_exp2_tab, common.h); unused in fp32
+    if (sizeof(T) == 8) dpgp_exp2_tab_init(etab);
     const int b = blockIdx.z, mc = blockIdx.y * 128, sp = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const TIN *g = gamma + (size_t)b * Q;
@@ -260,8 +262,8 @@ __global__ __launch_bounds__(256) void psi1T_y_kernel(int N, int M, int Q, int B
                     e1 = fma(wq * d1, d1, e1);
                 }
             }
-            tacc[0] = fma(yn[r], dpgp_exp2(e0), tacc[0]);
-            tacc[1] = fma(yn[r], dpgp_exp2(e1), tacc[1]);
+            tacc[0] = fma(yn[r], dpgp_exp2_hot(e0, etab), tacc[0]);
+            tacc[1] = fma(yn[r], dpgp_exp2_hot(e1, etab), tacc[1]);
         }
         acc[0] += (double)tacc[0];
         acc[1] += (double)tacc[1];
