@@ -1888,7 +1888,9 @@ int launch_psi2_partial(int B, int N, int M, int Q, const TIN *z, const TIN *mu,
                         const TIN *alpha, T *part, int ns, int algo, hipStream_t st, void *chain_ws, int chain_elem,
                         double *logdet_k, int *info_k, unsigned char *consts, int consts_ready, float *pair_scale) {
     const int Mp = dpgp_round_up(M, 16);
-    ChainKTask task = {chain_ws, la_chain_ws_elems_inline(M), logdet_k, info_k, M, Mp, chain_elem, B >= 256 ? 1 : 0};
+    int chain_last = B >= 256 ? 1 : 0;
+    if (const char *e = getenv("DPGP_CHAIN_LAST")) chain_last = atoi(e) ? 1 : 0;      // (experiments only)
+    ChainKTask task = {chain_ws, la_chain_ws_elems_inline(M), logdet_k, info_k, M, Mp, chain_elem, chain_last};
     if (algo == DPGP_ALGO_PLAIN && chain_ws) return -16;     // the plain path launches chain_k on its own
     if (algo == DPGP_ALGO_PLAIN) {
         // slabs 1.. are expected to exist by the consumer: zero them, slab 0 carries the result
