@@ -1734,6 +1734,21 @@ int psi2_nsplit(int B, int N, int M) {
     int max_ns = N / 128;
     if (max_ns > 8) max_ns = 8;
     if (max_ns < 1) max_ns = 1;
+    if (nchain > 0 && B < 256) {
+        // The K_uu tasks hold B of the 512 slots from the start (psi2_task_1d): the pair-tile kernel — the default — runs
+        // B ns nr workgroups (nr tile ranges, pairs_geom), all in ONE round if B ns nr + B <= 512.  Most workgroups that fit;
+        // among equals the most n-splits (fewer, longer tile ranges per workgroup).  Config 2 (B = 64): 7 x 1 (448 + 64
+        // workgroups) 0.182 ms against 0.190 ms for the 5 x 2 of the list-schedule model below, which describes the patch kernels.
+        int best_ns = 1;
+        long long best_wg = 0;
+        for (int ns = 1; ns <= max_ns; ++ns) {
+            const long long per = (long long)B * ns, nr = (R - nchain) / per;
+            if (nr < 1) break;
+            const long long wg = per * nr;
+            if (wg >= best_wg) { best_wg = wg; best_ns = ns; }
+        }
+        if (best_wg > 0) return best_ns;
+    }
     int best = 1;
     double best_t = 1e300;
     for (int ns = 1; ns <= max_ns; ++ns) {
