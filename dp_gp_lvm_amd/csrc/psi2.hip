@@ -1734,20 +1734,37 @@ int psi2_nsplit(int B, int N, int M) {
     int max_ns = N / 128;
     if (max_ns > 8) max_ns = 8;
     if (max_ns < 1) max_ns = 1;
-    if (nchain > 0 && B < 256) {
-        // The K_uu tasks hold B of the 512 slots from the start (psi2_task_1d): the pair-tile kernel — the default — runs
-        // B ns nr workgroups (nr tile ranges, pairs_geom), all in ONE round if B ns nr + B <= 512.  Most workgroups that fit;
-        // among equals the most n-splits (fewer, longer tile ranges per workgroup).  Config 2 (B = 64): 7 x 1 (448 + 64
-        // workgroups) 0.182 ms against 0.190 ms for the 5 x 2 of the list-schedule model below, which describes the patch kernels.
+    if (nchain > 0) {
+        // The pair-tile kernel — the default for these sizes — runs B ns nr workgroups (nr tile ranges, pairs_geom).  Measured
+        // on config 3 sliced to B output dims (scratch/time_by_d.py, ms per evaluation, (ns, nr)): the best split has ONE round
+        // of workgroups, 512 of them — B = 512: (1,1) 1.376 against (2,1) 1.400; B = 256: (2,1) 0.729, (1,2) 0.731 against
+        // (4,1) 0.755 and 0.766 for the list-schedule model below (which describes the patch kernels); B = 128: (4,1) 0.432
+        // against (3,1) 0.476 — except that few output dims leave the B slots their K_uu tasks hold from the start free:
+        // B = 64: (7,1) 0.182 against (8,1) 0.202.  Hence: as many workgroups as fit the target, among equals the most n-splits.
+        const long long target = B < 128 ? R - nchain : R;
+        if (B > target) {
+            // more output dims than slots: several rounds of workgroups; n-splits shorten the partly filled last round
+            // (config 5, B = 560: 1 split 0.797 ms (1.09 rounds), 4 splits 0.660, 8 splits 0.665)
+            int best_ns = 1;
+            double best_score = -1.0;
+            for (int ns = 1; ns <= max_ns; ++ns) {
+                const long long wg = (long long)B * ns, rounds = (wg + R - 1) / R;
+                const double score = (double)wg / (double)(rounds * R) - 0.01 * ns;
+                if (score > best_score) { best_score = score; best_ns = ns; }
+            }
+            return best_ns;
+        }
         int best_ns = 1;
         long long best_wg = 0;
         for (int ns = 1; ns <= max_ns; ++ns) {
-            const long long per = (long long)B * ns, nr = (R - nchain) / per;
-            if (nr < 1) break;
+            const long long per = (long long)B * ns;
+            long long nr = target / per;
+            if (nr < 1) nr = 1;
             const long long wg = per * nr;
+            if (wg > target && ns > 1) break;
             if (wg >= best_wg) { best_wg = wg; best_ns = ns; }
         }
-        if (best_wg > 0) return best_ns;
+        return best_ns;
     }
     int best = 1;
     double best_t = 1e300;

@@ -346,8 +346,9 @@ static PairsGeom pairs_geom(int B, int N, int M, int Q, int ns, size_t chain_lds
     if (chain_lds > g.lds) g.lds = chain_lds;
     // tile ranges: only when the (output dim, n-split) workgroups alone cannot fill the GPU (small batches)
     const int tiles = C.Ppad / 32;
-    // (B < 256 with the K_uu tasks in the dispatch: they hold B slots from the start, so B ns nr + B <= 512 keeps one round)
-    int nr = (chain_lds && B < 256) ? (512 - B) / (B * ns) : dpgp_ceil_div(512, B * ns);
+    // (with the K_uu tasks in the dispatch: one round of <= 512 workgroups, less the B slots the tasks hold from the start
+    //  when there are few output dims — the rule psi2_nsplit chose ns by)
+    int nr = chain_lds ? (B < 128 ? 512 - B : 512) / (B * ns) : dpgp_ceil_div(512, B * ns);
     if (nr > dpgp_ceil_div(tiles, 32)) nr = dpgp_ceil_div(tiles, 32);   // >= 32 tiles (8 per wave) per range
     if (nr < 1) nr = 1;
     if (const char *e = getenv("DPGP_PP_RANGES")) {             // (experiments only)
