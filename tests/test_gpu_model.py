@@ -154,3 +154,29 @@ def test_objective_replayed_from_a_hip_graph_follows_the_parameters(dev):
     model.evaluate_graph(out=out)
     np.testing.assert_array_equal(out.cpu().numpy(), eager2)
     assert eager2[0] != eager[0]
+
+
+def test_per_gpu_shares_of_config_3_agree_with_the_whole(dev):
+    """The split of the observations / pair tiles over workgroups depends on the number of output dims a GPU holds (psi2_nsplit,
+    pairs_geom: one round of workgroups for D = 64 / 128 / 256 / 512): the per-dim ELBO terms of the first D output dims of
+    BASELINE config 3 must not depend on it (mixed precision: fp32 sums in a different association, 2e-6 of the largest term)."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    from dp_gp_lvm_amd.utils.synthetic import make_problem, CONFIGS
+    n, dfull, m, q = CONFIGS[3]
+    p = make_problem(3)
+    t = p['phi'].shape[1]
+
+    def terms(d):
+        init = dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi'][:d]), gamma_atoms=p['gamma_atoms'],
+                    alpha_atoms=p['alpha_atoms'], beta_atoms=p['beta_atoms'], gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'], w_2=p['w2'])
+        model = dp_gp_lvm(p['y'][:, :d], num_latent_dims=q, num_inducing_points=m, truncation_level=t,
+                          alpha_prior_params=np.array([p['s1'], p['s2']]), device=dev, initial_values=init, precision='mixed')
+        float(model.objective)                                     # (per_dimension_terms: of the LAST evaluation)
+        tm, info = model.per_dimension_terms
+        assert int(info.abs().max()) == 0
+        return tm.cpu().numpy()
+
+    whole = terms(dfull)
+    for d in (64, 128, 256):
+        part = terms(d)
+        np.testing.assert_allclose(part, whole[:d], rtol=0, atol=2e-6 * np.abs(whole).max(), err_msg='D = %d' % d)
