@@ -232,9 +232,10 @@ class ElboWorkspace:
         l = _lib.lib()
         self.nbytes = l.dpgp_elbo_workspace_bytes(d, n, m, q, _lib.PREC[prec])
         self.ws = _ws(self.nbytes, device)
-        self.terms = torch.empty((d, 5), dtype=torch.float64, device=device)
-        self.sums = torch.empty(2, dtype=torch.float64, device=device)
-        self.info = torch.empty(d, dtype=torch.int32, device=device)
+        # (before the first evaluation: NaN terms and zero flags, not whatever the allocator hands out)
+        self.terms = torch.full((d, 5), float('nan'), dtype=torch.float64, device=device)
+        self.sums = torch.full((2,), float('nan'), dtype=torch.float64, device=device)
+        self.info = torch.zeros(d, dtype=torch.int32, device=device)
         self.exec = _lib.ExecResources()
         import ctypes
         lay = (ctypes.c_size_t * 10)()
