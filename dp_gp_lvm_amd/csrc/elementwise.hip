@@ -587,13 +587,19 @@ __global__ __launch_bounds__(256) void elbo_front_kernel(int N, int Q, const dou
     __shared__ double scratch[5][64];
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int blk = (int)blockIdx.x;
+#ifdef FRONT_DIAG_SKIP             // (timing experiments only: wrong results) bit 0: KL / y'y / constants, 1: K_uu tiles, 2: scale table
+    if ((FRONT_DIAG_SKIP & 1) && blk < first_gram_block) return;
+    if ((FRONT_DIAG_SKIP & 2) && blk >= first_gram_block && blk < first_scale_block) return;
+    if ((FRONT_DIAG_SKIP & 4) && blk >= first_scale_block) return;
+#endif
     if (blk < first_gram_block) {
         kl_yy_block<double>(blk, N, Q, mu, s, kl_out, D, y, ldy, yy_out, z, M, consts, first_consts_block, scratch);
         return;
     }
     if (blk >= first_scale_block) {                       // the pair-scale table of the pair-tile psi2 kernel (psi2_consts.h)
         const int nb = (psi2_consts_layout(M, Q).Ppad + 255) / 256, sb = blk - first_scale_block;
-        psi2_pair_scale_block<double, double>(sb / nb, sb % nb, M, Q, z, gamma, alpha, pair_scale);
+        const int dch = psi2_scale_dchunk(D), b0 = (sb / nb) * dch;
+        psi2_pair_scale_chunk<double, double>(b0, min(dch, D - b0), sb % nb, M, Q, z, gamma, alpha, pair_scale);
         return;
     }
     const int tm = (M + GRAM_T - 1) / GRAM_T, g = blk - first_gram_block, b = g / (tm * tm), r = g - b * tm * tm;
@@ -610,8 +616,8 @@ int launch_elbo_front(int N, int Q, const double *mu, const double *s, double *k
     blocks += dpgp_ceil_div(M, 64) + dpgp_ceil_div(psi2_consts_layout(M, Q).Ppad, PSI2_PAIR_ROWS_PER_BLOCK);
     const int first_gram = blocks, tm = dpgp_ceil_div(M, GRAM_T);
     blocks += D * tm * tm;
-    const int first_scale = blocks;                     // pair_scale != nullptr: D x ceil(Ppad / 256) more blocks
-    if (pair_scale) blocks += D * dpgp_ceil_div(psi2_consts_layout(M, Q).Ppad, 256);
+    const int first_scale = blocks;                     // pair_scale != nullptr: ceil(D / chunk) x ceil(Ppad / 256) more blocks
+    if (pair_scale) blocks += dpgp_ceil_div(D, psi2_scale_dchunk(D)) * dpgp_ceil_div(psi2_consts_layout(M, Q).Ppad, 256);
     const size_t lds = sizeof(TL) * 2 * GRAM_T * (Q + 1);
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((elbo_front_kernel<TL>), dim3(blocks), dim3(256), lds, st, N, Q, mu, s, kl_out, D, y, ldy, yy_out,
                        z, M, psi2_consts, first_consts, first_gram, gamma, alpha, beta, (TL)jitter, kuu, ld_kuu, kuu_stride,

@@ -154,22 +154,47 @@ __device__ __forceinline__ void psi2_pair_rows(const TIN *__restrict__ z, int M,
 // pair of the pair-tile psi2 kernel (applied once per column sum instead of once per exponent); 256 pairs per block, thread =
 // pair, straight from z (no dependency on the other constants).  Runs as extra blocks of the front launch of the fused ELBO,
 // or as a launch of its own (psi2_pairs.hip).
+// output dims per workgroup of the scale role: 16 at D = 512 (the gather amortised), fewer for few output dims (D = 64: 2 —
+// with 16 the role is 132 long workgroups and the front launch of the per-GPU share takes 16.0 instead of 14.6 us)
+__host__ __device__ inline int psi2_scale_dchunk(int D) {
+    const int c = D / 32;
+    return c < 1 ? 1 : (c > 16 ? 16 : c);
+}
+// output dims [b0, b0 + nb) of pair block pblk: the pair's squared differences are formed ONCE (the gather of two z rows and
+// the index arithmetic of psi2_pair_of were the cost of the per-(output dim, pair) form: 43.6 us at config 3 for 17 MB of
+// output) and every output dim adds Q FMAs, one v_exp_f32 and one coalesced store
 template <typename TIN, typename TG>
-__device__ __forceinline__ void psi2_pair_scale_block(int b, int pblk, int M, int Q, const TIN *__restrict__ z,
+__device__ __forceinline__ void psi2_pair_scale_chunk(int b0, int nb, int pblk, int M, int Q, const TIN *__restrict__ z,
                                                       const TG *__restrict__ gamma, const TG *__restrict__ alpha,
                                                       float *__restrict__ scale) {
     const int P = (int)((long long)M * (M + 1) / 2), Ppad = (P + 31) & ~31;
     const int p = pblk * 256 + (int)threadIdx.x;
     if (p >= Ppad) return;
-    float bsum = 0.0f;
+    float d2[DPGP_MAX_Q];
+#pragma unroll
+    for (int q = 0; q < DPGP_MAX_Q; ++q) d2[q] = 0.0f;
     if (p < P) {
         int m, mp;
         psi2_pair_of(p, m, mp);
-        for (int q = 0; q < Q; ++q) {
-            const float d = (float)((double)z[(size_t)m * Q + q] - (double)z[(size_t)mp * Q + q]);
-            bsum += (float)gamma[(size_t)b * Q + q] * d * d;
-        }
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q)
+            if (q < Q) {
+                const float d = (float)((double)z[(size_t)m * Q + q] - (double)z[(size_t)mp * Q + q]);
+                d2[q] = d * d;
+            }
     }
-    const float al = (float)alpha[b];
-    scale[(size_t)b * Ppad + p] = al * al * __builtin_amdgcn_exp2f((float)(-0.25 * DPGP_LOG2E) * bsum);
+    for (int b = b0; b < b0 + nb; ++b) {
+        float bsum = 0.0f;
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q)
+            if (q < Q) bsum += (float)gamma[(size_t)b * Q + q] * d2[q];
+        const float al = (float)alpha[b];
+        scale[(size_t)b * Ppad + p] = al * al * __builtin_amdgcn_exp2f((float)(-0.25 * DPGP_LOG2E) * bsum);
+    }
+}
+template <typename TIN, typename TG>
+__device__ __forceinline__ void psi2_pair_scale_block(int b, int pblk, int M, int Q, const TIN *__restrict__ z,
+                                                      const TG *__restrict__ gamma, const TG *__restrict__ alpha,
+                                                      float *__restrict__ scale) {
+    psi2_pair_scale_chunk<TIN, TG>(b, 1, pblk, M, Q, z, gamma, alpha, scale);
 }
