@@ -269,10 +269,12 @@ def test_matrix_pipe_stage_b_against_fp64(dev, shape):
             np.testing.assert_allclose(got, want, rtol=0, atol=5e-4 * np.abs(want).max(), err_msg=name)
 
 
-@pytest.mark.parametrize('shape', [(150, 4, 130, 5), (260, 3, 200, 7), (300, 2, 257, 14)])
+@pytest.mark.parametrize('shape', [(150, 4, 130, 5), (260, 3, 200, 7), (300, 2, 257, 14), (1, 3, 200, 4)])
 def test_stage_b_beyond_128_inducing_points(dev, shape):
-    """Stage B alone for M > 128 (K_uu term by kuu_grad_kernel, Psi1 kernels over row blocks, psi2_grad_kernel over an
-    nps x nps patch grid), fed with the stage-A adjoints of the oracle; against autograd of the oracle."""
+    """Stage B alone for M > 128 (K_uu term by kuu_grad_kernel, Psi1 kernels over row blocks, the Psi2 term in the pair-tile
+    or the patch form), fed with the stage-A adjoints of the oracle; against autograd of the oracle.  The last shape is ONE
+    observation against 200 inducing points — the prediction paths' M > N (the K_uu term's partial sums used to
+    overrun the workspace region sized by N)."""
     n, d, m, q = shape
     rng = np.random.default_rng(m)
     y = rng.standard_normal((n, d))
