@@ -22,11 +22,15 @@
 #include "internal.h"
 #ifdef DPGP_PROFILE_CHAIN
 // diagnostic build only (scratch/): per-phase clock stamps of workgroup 0, read back with dpgp_debug_stamps()
-__device__ long long g_chain_stamps[16];
-#define STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_chain_stamps[i] = wall_clock64(); } while (0)
-extern "C" void dpgp_debug_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * 16); }
-#define ACC_BEGIN() long long t__ = wall_clock64()
-#define ACC_END(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == ((i) == 4 ? 0 : 1)) g_chain_stamps[i] += wall_clock64() - t__; } while (0)
+__device__ long long g_chain_stamps[64];
+#define STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { g_chain_stamps[i] = wall_clock64(); g_chain_stamps[8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+extern "C" void dpgp_debug_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * 64); }
+#define ACC_BEGIN() long long t__ = __builtin_amdgcn_s_memtime()
+// slots 16 + k / 32 + k: shader cycles of panel / update phase k of the last evaluation (wave 0 / wave 1 of workgroup 0)
+#define ACC_END(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == ((i) == 4 ? 0 : 1)) { const long long dt__ = __builtin_amdgcn_s_memtime() - t__; g_chain_stamps[i] += dt__; g_chain_stamps[((i) == 4 ? 16 : 32) + k] = dt__; } } while (0)
+// slot 48 + k: cycles inside UpdItem::run of update phase k (wave 1), summed over its items
+#define SUB_BEGIN() const long long ts__ = __builtin_amdgcn_s_memtime()
+#define SUB_END(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 1) g_chain_stamps[(i) + k] += __builtin_amdgcn_s_memtime() - ts__; } while (0)
 #endif
 #include "linalg_dev.h"
 

@@ -7,6 +7,10 @@
 #define ACC_BEGIN()
 #define ACC_END(i)
 #endif
+#ifndef SUB_BEGIN
+#define SUB_BEGIN()
+#define SUB_END(i)
+#endif
 
 #define LDT 17          // LDS tile row stride (16 + 1 pad)
 #define TSZ (16 * LDT)  // elements per LDS tile
@@ -90,7 +94,7 @@ __device__ __forceinline__ void diag_tile(T *A, int ld, T *dinv_lds, T *dinv_glo
     if (lane < 16) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            dinv_lds[i * LDT + li] = x[i];
+            if (dinv_lds) dinv_lds[i * LDT + li] = x[i];
             if (dinv_glob) dinv_glob[i * 16 + li] = x[i];
         }
     }
@@ -296,98 +300,385 @@ static inline size_t lds_chol_elems(int nbf, int nborder) {      // dinv tile + 
     return (size_t)TSZ * (size_t)(1 + nbf * (nbf + 1) / 2) + (size_t)nborder * nbf * LDT;
 }
 
-// tiles: LDS array of TSZ-element tiles followed by the border vectors; dinv: one more LDS tile.  On exit the tiles hold L
-// and the border vectors L^-1 v.  dinv_glob (optional): [nbf][256] global array that receives the inverted diagonal tiles.
-// OCC only separates instantiations: a kernel bounded to 2 workgroups per CU (256 VGPRs) must not share this function's
-// register allocation with an unbounded one (the fp64 diagonal tile wants ~330 registers and spills when held to 256).
-template <typename T, int OCC = 1>
-__device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail, T *dinv_glob = nullptr) {
+// ---- pivot reciprocal root to working precision, for the pivot chain: native seed + Newton steps written out so that the
+// dependent chain is known (v_rsq_f64 is good to 5.2e-8 relative on gfx950, scratch/ubench/lat64.hip: two steps; v_rsq_f32 to
+// one ulp: one step) ----
+__device__ __forceinline__ double pivot_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    double e = __builtin_fma(-(h * y), y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-(h * y), y, 0.5);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ float pivot_rsqrt(float d) {
+    float y = __builtin_amdgcn_rsqf(d);
+    const float e = __builtin_fmaf(-(0.5f * d * y), y, 0.5f);
+    return __builtin_fmaf(y, e, y);
+}
+
+// ---- the register panel of potrf_lds: DPP row broadcasts (row = 16 lanes) ------------------------------------------------
+// On gfx950 v_fmac_f64 with a row_newbcast source costs what a plain v_fma_f64 does (4.9 cycles of issue,
+// scratch/ubench/lat64b.hip) against 17 + 5 for a v_readlane pair into SGPRs + fma: the broadcast is free.  Rules this code
+// keeps: (1) a VALU write needs two wait states before a DPP read of the same register and the compiler's hazard recognizer
+// does not see into asm statements — the one place where a producer stands directly in front of its DPP consumer carries its
+// own s_nop; (2) the statements are volatile, so they stay in source order; (3) everything that belongs between two column
+// updates sits INSIDE one asm statement: around every separate asm statement the compiler puts a conservative s_nop
+// (125 per block column in the first version).
+// One column c > J of pivot J for this lane's two rows (a: its row below the tile, g: its copy of row lane & 15 of the
+// tile), preceded by operation N of the reciprocal chain of the NEXT pivot (PivotChain; N >= NOPS: none).
+#define DPGP_FMAC2_F64                                                                                          \
+    "v_fmac_f64_dpp %[a], -%[g], %[ta] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_fmac_f64_dpp %[g], -%[g], %[tg] row_newbcast:%[j] row_mask:0xf bank_mask:0xf"
+#define DPGP_FMAC2_F32                                                                                          \
+    "v_fmac_f32_dpp %[a], -%[g], %[ta] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"                        \
+    "v_fmac_f32_dpp %[g], -%[g], %[tg] row_newbcast:%[j] row_mask:0xf bank_mask:0xf"
+// The reciprocal of the next pivot, two Newton steps from v_rcp_f64 (good to 4.6e-8 relative, scratch/ubench/lat64.hip; one
+// step from v_rcp_f32), as single operations that ride in front of the column updates: the compiler does not move this
+// dependent chain in between them by itself (16 x ~30 cycles of exposed latency per block column).
+template <typename T> struct PivotChain {
+    T d, y, e, rcp;
+    static constexpr int NOPS = sizeof(T) == 8 ? 5 : 3;
+    __device__ __forceinline__ void finish_from(int n0) {     // operations n0 .. NOPS - 1 on their own (short columns)
+        if constexpr (sizeof(T) == 8) {
+            if (n0 <= 0) y = __builtin_amdgcn_rcp((double)d);
+            if (n0 <= 1) e = fma(-d, y, (T)1);
+            if (n0 <= 2) y = fma(y, e, y);
+            if (n0 <= 3) e = fma(-d, y, (T)1);
+            if (n0 <= 4) rcp = fma(y, e, y);
+        } else {
+            if (n0 <= 0) y = __builtin_amdgcn_rcpf((float)d);
+            if (n0 <= 1) e = fma(-d, y, (T)1);
+            if (n0 <= 2) rcp = fma(y, e, y);
+        }
+    }
+};
+template <typename T, int J, int N> struct PanelColumn {
+    static __device__ __forceinline__ void run(T &a, T &g, T ta, T tg, PivotChain<T> &nx) {
+        if constexpr (sizeof(T) == 8) {
+            if constexpr (N == 0)
+                asm volatile("v_rcp_f64 %[y], %[d]\n\t" DPGP_FMAC2_F64 : [a] "+v"(a), [g] "+v"(g), [y] "=&v"(nx.y) : [ta] "v"(ta), [tg] "v"(tg), [d] "v"(nx.d), [j] "n"(J));
+            else if constexpr (N == 1 || N == 3)
+                asm volatile("v_fma_f64 %[e], -%[d], %[y], 1.0\n\t" DPGP_FMAC2_F64 : [a] "+v"(a), [g] "+v"(g), [e] "=&v"(nx.e) : [ta] "v"(ta), [tg] "v"(tg), [d] "v"(nx.d), [y] "v"(nx.y), [j] "n"(J));
+            else if constexpr (N == 2)
+                asm volatile("v_fma_f64 %[y], %[y], %[e], %[y]\n\t" DPGP_FMAC2_F64 : [a] "+v"(a), [g] "+v"(g), [y] "+v"(nx.y) : [ta] "v"(ta), [tg] "v"(tg), [e] "v"(nx.e), [j] "n"(J));
+            else if constexpr (N == 4)
+                asm volatile("v_fma_f64 %[r], %[y], %[e], %[y]\n\t" DPGP_FMAC2_F64 : [a] "+v"(a), [g] "+v"(g), [r] "=&v"(nx.rcp) : [ta] "v"(ta), [tg] "v"(tg), [y] "v"(nx.y), [e] "v"(nx.e), [j] "n"(J));
+            else
+                asm volatile(DPGP_FMAC2_F64 : [a] "+v"(a), [g] "+v"(g) : [ta] "v"(ta), [tg] "v"(tg), [j] "n"(J));
+        } else {
+            if constexpr (N == 0)
+                asm volatile("v_rcp_f32 %[y], %[d]\n\t" DPGP_FMAC2_F32 : [a] "+v"(a), [g] "+v"(g), [y] "=&v"(nx.y) : [ta] "v"(ta), [tg] "v"(tg), [d] "v"(nx.d), [j] "n"(J));
+            else if constexpr (N == 1)
+                asm volatile("v_fma_f32 %[e], -%[d], %[y], 1.0\n\t" DPGP_FMAC2_F32 : [a] "+v"(a), [g] "+v"(g), [e] "=&v"(nx.e) : [ta] "v"(ta), [tg] "v"(tg), [d] "v"(nx.d), [y] "v"(nx.y), [j] "n"(J));
+            else if constexpr (N == 2)
+                asm volatile("v_fma_f32 %[r], %[y], %[e], %[y]\n\t" DPGP_FMAC2_F32 : [a] "+v"(a), [g] "+v"(g), [r] "=&v"(nx.rcp) : [ta] "v"(ta), [tg] "v"(tg), [y] "v"(nx.y), [e] "v"(nx.e), [j] "n"(J));
+            else
+                asm volatile(DPGP_FMAC2_F32 : [a] "+v"(a), [g] "+v"(g) : [ta] "v"(ta), [tg] "v"(tg), [j] "n"(J));
+        }
+    }
+};
+// column J + 1 of pivot J, then the next pivot d = (updated) g[J + 1] of lane J + 1, broadcast to the row of lanes
+template <typename T, int J> struct PanelNextPivot {
+    static __device__ __forceinline__ T run(T &a, T &g, T ta, T tg) {
+        T d;
+        if constexpr (sizeof(T) == 8)
+            asm volatile(DPGP_FMAC2_F64 "\n\ts_nop 1\n\tv_mov_b64_dpp %[d], %[g] row_newbcast:%[j1] row_mask:0xf bank_mask:0xf"
+                         : [a] "+v"(a), [g] "+v"(g), [d] "=&v"(d) : [ta] "v"(ta), [tg] "v"(tg), [j] "n"(J), [j1] "n"(J + 1));
+        else
+            asm volatile(DPGP_FMAC2_F32 "\n\ts_nop 1\n\tv_mov_b32_dpp %[d], %[g] row_newbcast:%[j1] row_mask:0xf bank_mask:0xf"
+                         : [a] "+v"(a), [g] "+v"(g), [d] "=&v"(d) : [ta] "v"(ta), [tg] "v"(tg), [j] "n"(J), [j1] "n"(J + 1));
+        return d;
+    }
+};
+// lane J of the row of lanes -> all its lanes (NOP: wait states in front, for a source a VALU instruction has just written)
+template <typename T, int J, int NOP> __device__ __forceinline__ T row_bcast(T v) {
+    T r;
+    if constexpr (sizeof(T) == 8) {
+        if constexpr (NOP) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+        else asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+    } else {
+        if constexpr (NOP) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+        else asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+    }
+    return r;
+}
+
+// Pivots J .. 15 of one block column held one matrix row per lane, in the square-root-free (L D L^T) form: g = this lane's
+// copy of row (lane & 15) of the diagonal tile (full symmetric row; every row of 16 lanes holds the whole tile), a = the
+// lane's own row below the tile.  pc: the finished chain of pivot J.  dsel collects pivot (lane & 15) on each lane.  On exit
+// g[j] / a[j] hold column j of the Schur complement at pivot j: the entries of L are those times rsqrt(d_j) (the caller's).
+// Which chain operation rides in front of the q-th of the 14 - J columns behind the next pivot's: every other column while
+// there is room (an asm statement that reads what the statement directly before it wrote gets a conservative s_nop from the
+// compiler), every column otherwise; 99 = none.
+template <typename T> constexpr int panel_chain_op(int J, int q) {
+    const int ncols = 14 - J, nops = PivotChain<T>::NOPS;
+    if (ncols >= 2 * nops - 1) return (q % 2 == 0 && q / 2 < nops) ? q / 2 : 99;
+    return q < nops ? q : 99;
+}
+template <typename T> constexpr int panel_chain_placed(int J) {
+    const int ncols = 14 - J, nops = PivotChain<T>::NOPS;
+    return ncols >= 2 * nops - 1 ? nops : (ncols < nops ? (ncols < 0 ? 0 : ncols) : nops);
+}
+template <typename T, int J, int C> struct PanelColumns {       // columns C .. 15 of pivot J
+    static __device__ __forceinline__ void run(T (&g)[16], T (&a)[16], T ta, T tg, PivotChain<T> &nx) {
+        if constexpr (C < 16) {
+            PanelColumn<T, J, panel_chain_op<T>(J, C - J - 2)>::run(a[C], g[C], ta, tg, nx);   // (reads row J of the tile before changing its own)
+            PanelColumns<T, J, C + 1>::run(g, a, ta, tg, nx);
+        }
+    }
+};
+template <typename T, int J> struct PanelStep {
+    static __device__ __forceinline__ void run(T (&g)[16], T (&a)[16], const PivotChain<T> &pc, T &dsel, int li) {
+        if constexpr (J < 15) {
+            const T tg = g[J] * pc.rcp, ta = a[J] * pc.rcp;   // multipliers a_iJ / d_J of the two rows
+            // the next pivot's column first, so that its reciprocal is under way while the other columns are updated
+            PivotChain<T> nx;
+            nx.d = PanelNextPivot<T, J>::run(a[J + 1], g[J + 1], ta, tg);
+            dsel = (li == J + 1) ? nx.d : dsel;
+            PanelColumns<T, J, J + 2>::run(g, a, ta, tg, nx);
+            nx.finish_from(panel_chain_placed<T>(J));         // what the remaining columns had no room for
+            PanelStep<T, J + 1>::run(g, a, nx, dsel, li);
+        }
+    }
+};
+// g[j], a[j] *= r[lane j of the row]   (r = rsqrt of the pivots, one per lane)
+template <typename T, int J> struct PanelScale {
+    static __device__ __forceinline__ void run(T (&g)[16], T (&a)[16], T r) {
+        const T rj = row_bcast<T, J, J == 0>(r);
+        g[J] *= rj;
+        a[J] *= rj;
+        if constexpr (J < 15) PanelScale<T, J + 1>::run(g, a, r);
+    }
+};
+
+// Trailing update of potrf_lds.  Work items of step k: the m (m + 1) / 2 lower tiles (m = tiles below the diagonal one) in
+// row-major order, then the border vectors' m tile columns each; item t belongs to wave t & 3.
+// UpdPlan: the tile offsets of a wave's items, decoded ONCE per step with one item per lane (vector integer work, ~40
+// instructions) and handed to the item loop by v_readlane — decoding per item on the scalar unit (triangular index ->
+// row / column, three tile offsets) cost ~120 scalar instructions with a dozen branches, 700-900 cycles per item against 260
+// for the item's four MFMAs (stamps of the first version).
+template <typename T> struct UpdPlan {
+    int oa, ob, oc, isb;     // per lane: element offsets from `tiles` of the A / B operand tiles and the C tile; border flag
+    __device__ __forceinline__ void build(int wv, int lane, int border_ofs, int nbf, int k, int m, int ntri) {
+        const int t = wv + 4 * lane;
+        const int tt = min(t, max(ntri - 1, 0));
+        int r = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+        r += ((r + 1) * (r + 2) / 2 <= tt) ? 1 : 0;
+        r -= (r * (r + 1) / 2 > tt) ? 1 : 0;
+        const int tb = max(t - ntri, 0);
+        const int bi = (int)(((float)tb + 0.5f) * (1.0f / (float)max(m, 1))), qb = tb - bi * m;
+        isb = t >= ntri ? 1 : 0;
+        const int I = k + 1 + r, J = k + 1 + (isb ? qb : tt - r * (r + 1) / 2);
+        oa = isb ? border_ofs + (bi * nbf + k) * LDT : lds_tile_index(I, k, nbf) * TSZ;
+        ob = lds_tile_index(J, k, nbf) * TSZ;
+        oc = isb ? border_ofs + (bi * nbf + J) * LDT : lds_tile_index(I, J, nbf) * TSZ;
+    }
+};
+#ifdef UPD_DIAG_NO_MFMA       // scratch/ubench/chol_phases.hip only: the item loop without its matrix instructions
+#define UPD_MMA(x, y, z) (z)
+#else
+#define UPD_MMA(x, y, z) Mfma<T>::mma(x, y, z)
+#endif
+// One item: C -= A B^T on 16 x 16 LDS tiles, or (border) the one row c -= a B^T as row 0 of such a product.  No branch and no
+// mask anywhere: row i of an MFMA result depends on row i of A only, so a border item lets every lane row read the border
+// vector and sends the result elements it does not own to a dummy LDS tile (`dummy`: TSZ elements nobody reads for data).
+// fetch() of the wave's next item stands in the same basic block as run() of the current one; interleave() then tells the
+// scheduler to put the loads and the address arithmetic into the issue gaps of the four dependent MFMAs (64 cycles each on
+// gfx950, ~8 of them busy issuing) instead of clustering the MFMAs, which left the wave stalled in between (first version:
+// 1200 cycles per item, of which 260 MFMA).
+template <typename T> struct UpdItem {
     typedef typename Mfma<T>::acc_t acc_t;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
+    T a[4], b[4];
+    acc_t c;
+    T *pc0, *pc1;            // this lane's C elements: pc0[0] and pc1[(v - 1) * cs1], v = 1..3
+    int cs1;
+    static constexpr int cst = (sizeof(T) == 8 ? 4 : 1) * LDT;     // rows of a lane's C elements: Mfma<T>::row(lane, v)
+    __device__ __forceinline__ void fetch(T *tiles, T *dummy, const UpdPlan<T> &pl, int i, int lane) {
+        const int li = lane & 15, kk = lane >> 4;
+        const int oa = __builtin_amdgcn_readlane(pl.oa, i), ob = __builtin_amdgcn_readlane(pl.ob, i),
+                  oc = __builtin_amdgcn_readlane(pl.oc, i), isb = __builtin_amdgcn_readlane(pl.isb, i);
+        const T *pa = tiles + oa + (isb ? kk : li * LDT + kk);
+        const T *pb = tiles + ob + li * LDT + kk;
+        T *creg = tiles + oc + Mfma<T>::row(lane, 0) * LDT + li;
+        T *cbrd = Mfma<T>::row(lane, 0) == 0 ? tiles + oc + li : dummy + lane;
+        pc0 = isb ? cbrd : creg;
+        pc1 = isb ? dummy + lane : creg + cst;
+        cs1 = isb ? 0 : cst;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a[ks] = pa[4 * ks];
+            b[ks] = pb[4 * ks];
+        }
+        c[0] = pc0[0];
+#pragma unroll
+        for (int v = 1; v < 4; ++v) c[v] = pc1[(v - 1) * cs1];
+    }
+    // the same, split into the pieces that step() places between the MFMAs of the item before
+    const T *pa_, *pb_;
+    __device__ __forceinline__ void locate(T *tiles, T *dummy, const UpdPlan<T> &pl, int i, int lane) {
+        const int li = lane & 15, kk = lane >> 4;
+        const int oa = __builtin_amdgcn_readlane(pl.oa, i), ob = __builtin_amdgcn_readlane(pl.ob, i),
+                  oc = __builtin_amdgcn_readlane(pl.oc, i), isb = __builtin_amdgcn_readlane(pl.isb, i);
+        pa_ = tiles + oa + (isb ? kk : li * LDT + kk);
+        pb_ = tiles + ob + li * LDT + kk;
+        T *creg = tiles + oc + Mfma<T>::row(lane, 0) * LDT + li;
+        T *cbrd = Mfma<T>::row(lane, 0) == 0 ? tiles + oc + li : dummy + lane;
+        pc0 = isb ? cbrd : creg;
+        pc1 = isb ? dummy + lane : creg + cst;
+        cs1 = isb ? 0 : cst;
+    }
+    __device__ __forceinline__ void load_ab() {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a[ks] = pa_[4 * ks];
+            b[ks] = pb_[4 * ks];
+        }
+    }
+    __device__ __forceinline__ void load_c() {
+        c[0] = pc0[0];
+#pragma unroll
+        for (int v = 1; v < 4; ++v) c[v] = pc1[(v - 1) * cs1];
+    }
+    __device__ __forceinline__ void store_c() {
+        pc0[0] = c[0];
+#pragma unroll
+        for (int v = 1; v < 4; ++v) pc1[(v - 1) * cs1] = c[v];
+    }
+    // run this item while fetching the wave's item `inext` into nx.  The compiler clusters the four dependent MFMAs (64
+    // cycles each on gfx950, ~8 of them busy issuing) and the wave sits out the rest of each in front of the next one; the
+    // scheduling barriers keep the next item's address arithmetic and LDS reads in those gaps, in source order.
+    __device__ __forceinline__ void step(UpdItem &nx, T *tiles, T *dummy, const UpdPlan<T> &pl, int inext, int lane) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a[ks] = -a[ks];
+        __builtin_amdgcn_sched_barrier(0);
+        c = UPD_MMA(a[0], b[0], c);
+        __builtin_amdgcn_sched_barrier(0);
+        nx.locate(tiles, dummy, pl, inext, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        c = UPD_MMA(a[1], b[1], c);
+        __builtin_amdgcn_sched_barrier(0);
+        nx.load_ab();
+        __builtin_amdgcn_sched_barrier(0);
+        c = UPD_MMA(a[2], b[2], c);
+        __builtin_amdgcn_sched_barrier(0);
+        nx.load_c();
+        __builtin_amdgcn_sched_barrier(0);
+        c = UPD_MMA(a[3], b[3], c);
+        __builtin_amdgcn_sched_barrier(0);
+        store_c();
+    }
+};
+
+// tiles: LDS array of TSZ-element tiles followed by the border vectors.  On exit the tiles hold L and the border vectors
+// L^-1 v.  dinv_glob (optional): [nbf][256] global array that receives the inverted diagonal tiles (computed after the
+// factorisation, off its critical path, one tile per wave at a time).  `dinv`: one LDS tile of scratch (UpdItem's dummy).
+// OCC only separates instantiations: a kernel bounded to 2 workgroups per CU (256 VGPRs) must not share this function's
+// register allocation with an unbounded one.
+//
+// Right-looking over block columns of 16.  Step k has two phases and two barriers:
+//   PANEL (registers, one matrix row per lane): every row of 16 lanes holds the 16 rows of the diagonal tile (full symmetric
+//     rows, redundantly) and every lane one row below it (64 per wave; the border vectors are rows like any other).  Pivot j:
+//     each lane scales its own entries of column j by 1/d and updates its two rows with one v_fmac_f64 per column whose
+//     second factor — the entry of row j of the tile — comes from lane j of its own row of lanes by DPP (RowBcast).  The rows
+//     come out as L_kk and A_Ik L_kk^-T: no inverse of the diagonal tile, no panel product, no cross-wave traffic.
+//     (Round 2 factored + inverted the diagonal tile on one wave with v_readlane broadcasts — 3.7 us of the 5-6 us per
+//     step — and formed the panel with that inverse on the matrix pipe.)
+//   UPDATE (matrix pipe): A_IJ -= P_I P_J^T for k < J <= I, tiles dealt round-robin to the four waves.
+// PANEL phase of step k (see potrf_lds): on exit the rows below the diagonal tile are stored; g holds row (lane & 15) of L_kk,
+// which the caller stores after its barrier.  Returns the first non-positive pivot of the tile (1-based) or 0.
+template <typename T>
+__device__ __forceinline__ int potrf_lds_panel(T *tiles, T *border, int nbf, int nborder, int k, int wv, int lane, T (&g)[16]) {
+    const int li = lane & 15;
+    const T *tkk = tiles + lds_tile_index(k, k, nbf) * TSZ;
+    const int ntile_below = nbf - 1 - k, nrows_below = 16 * ntile_below + nborder;
+    int bad = 0;
+    if (64 * wv < nrows_below || wv == 0) {                   // (nrows_below <= 256: nbf <= 16)
+        const int p = 64 * wv + lane;                         // this lane's row below the diagonal tile
+        T *rowp = nullptr;
+        if (p < 16 * ntile_below) rowp = tiles + lds_tile_index(k + 1 + (p >> 4), k, nbf) * TSZ + li * LDT;
+        else if (p < nrows_below) rowp = border + ((p - 16 * ntile_below) * nbf + k) * LDT;
+        T a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            g[c] = tkk[li * LDT + c];                         // full symmetric row (potrf_lds mirrors the diagonal tiles)
+            a[c] = rowp ? rowp[c] : (T)0;
+        }
+        asm volatile("s_nop 4");                              // (EXEC restored by the predicated loads -> DPP)
+        PivotChain<T> pc;
+        pc.d = row_bcast<T, 0, 0>(g[0]);
+        T dsel = pc.d;                                        // lane li ends up with pivot li
+        pc.finish_from(0);
+        PanelStep<T, 0>::run(g, a, pc, dsel, li);
+        // non-positive (or NaN) pivots: found once per tile from the 16 collected pivots; the factorisation runs on (its
+        // numbers mean nothing from there on; the callers report info and poison the results)
+        const unsigned long long nonpos = __builtin_amdgcn_ballot_w64(!(dsel > (T)0)) & 0xffffull;
+        bad = nonpos ? __builtin_ctzll(nonpos) + 1 : 0;
+        PanelScale<T, 0>::run(g, a, pivot_rsqrt(dsel));
+        if (rowp) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) rowp[c] = a[c];
+        }
+    }
+    return bad;
+}
+// UPDATE phase of step k
+template <typename T>
+__device__ __forceinline__ void potrf_lds_update(T *tiles, T *dummy, int nbf, int nborder, int k, int wv, int lane) {
+    const int m = nbf - 1 - k, ntri = m * (m + 1) / 2, ntot = ntri + nborder * m;
+    const int nit = wv < ntot ? (ntot - wv + 3) >> 2 : 0;              // this wave's items: t = wv, wv + 4, ...  (<= 64)
+    UpdPlan<T> plan;
+    plan.build(wv, lane, (nbf * (nbf + 1) / 2) * TSZ, nbf, k, m, ntri);
+    UpdItem<T> X, Y;
+    if (nit > 0) X.fetch(tiles, dummy, plan, 0, lane);
+    for (int i = 0; i < nit; i += 2) {
+        X.step(Y, tiles, dummy, plan, min(i + 1, nit - 1), lane);      // (past the end: the last item once more, never run)
+        if (i + 1 >= nit) break;
+        Y.step(X, tiles, dummy, plan, min(i + 2, nit - 1), lane);
+    }
+}
+
+template <typename T, int OCC = 1>
+__device__ __forceinline__ void potrf_lds(T *tiles, T *dinv, int nbf_, int nbr_, int *fail, T *dinv_glob = nullptr) {
+    const int lane = threadIdx.x & 63, li = lane & 15, kk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Inlined into its kernels on purpose: as a called function it received its arguments in vector registers (every loop bound
+    // and tile offset treated as divergent, control flow on the vector unit under exec masks) and, the LDS pointers being
+    // propagated into it as constants, re-read the dynamic-LDS base from the compiler's per-kernel offset table in memory.
+    const int nbf = __builtin_amdgcn_readfirstlane(nbf_), nbr = __builtin_amdgcn_readfirstlane(nbr_);
     T *border = tiles + (size_t)(nbf * (nbf + 1) / 2) * TSZ;
-    if (wv == 0) diag_tile<T, true, true>(tiles, LDT, dinv, dinv_glob, fail, 0);
+    const int nborder = nbr - nbf;
+    int failed = 0;                                           // first non-positive pivot, 1-based
+    // the panel phase reads full symmetric rows of the diagonal tiles: mirror their lower triangles once (the updates
+    // A_II -= P_I P_I^T keep them symmetric bit for bit: the same products in the same order on both sides)
+    for (int e = threadIdx.x; e < nbf * 256; e += 256) {
+        const int I = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        T *t = tiles + lds_tile_index(I, I, nbf) * TSZ;
+        if (c > r) t[r * LDT + c] = t[c * LDT + r];
+    }
     __syncthreads();
     for (int k = 0; k < nbf; ++k) {
-        // panel: P_I = A_Ik * Linv_kk^T, in place
+        T g[16];                                              // row li of the diagonal tile -> of L_kk
         { ACC_BEGIN();
-        for (int I = k + 1 + wv; I < nbr; I += 4) {
-            acc_t c = {0, 0, 0, 0};
-            if (I < nbf) {
-                T *tile = tiles + lds_tile_index(I, k, nbf) * TSZ;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) c = Mfma<T>::mma(tile[li * LDT + 4 * ks + kk], dinv[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
-            } else {
-                T *bk = border + ((I - nbf) * nbf + k) * LDT;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    c = Mfma<T>::mma(li == 0 ? bk[4 * ks + kk] : (T)0, dinv[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (Mfma<T>::row(lane, v) == 0) bk[li] = c[v];
-            }
-        }
-        ACC_END(5); }
+        const int bad = potrf_lds_panel<T>(tiles, border, nbf, nborder, k, wv, lane, g);
+        failed = (bad && failed == 0) ? 16 * k + bad : failed;
+        ACC_END(4); }
         __syncthreads();
-        // trailing update A_IJ -= P_I P_J^T (k < J < nbf, J <= I < nbr).  Wave 0 takes the next diagonal tile first and
-        // factors it right away; waves 1-3 share the rest of the update.
-        if (wv == 0) {
-            if (k + 1 < nbf) {
-                T *tile = tiles + lds_tile_index(k + 1, k + 1, nbf) * TSZ;
-                const T *pI = tiles + lds_tile_index(k + 1, k, nbf) * TSZ;
-                acc_t c;
+        // L_kk goes back only now: every wave read the unfactored diagonal tile during the panel phase
+        if (wv == 0 && kk == 0) {
+            T *tkk = tiles + lds_tile_index(k, k, nbf) * TSZ;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) c[v] = tile[Mfma<T>::row(lane, v) * LDT + li];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) c = Mfma<T>::mma(-pI[li * LDT + 4 * ks + kk], pI[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                ACC_BEGIN();
-                diag_tile<T, true, true>(tile, LDT, dinv, dinv_glob ? dinv_glob + (k + 1) * 256 : (T *)nullptr, fail,
-                                         16 * (k + 1));
-                ACC_END(4);
-            }
-        } else {
-            ACC_BEGIN();
-            int cnt = 0;
-            for (int I = k + 1; I < nbr; ++I) {
-                const int jmax = min(I, nbf - 1);
-                for (int J = k + 1; J <= jmax; ++J) {
-                    if (I == k + 1 && J == k + 1) continue;
-                    if ((cnt++ % 3) != wv - 1) continue;
-                    const T *pJ = tiles + lds_tile_index(J, k, nbf) * TSZ;
-                    acc_t c;
-                    if (I < nbf) {
-                        T *tile = tiles + lds_tile_index(I, J, nbf) * TSZ;
-                        const T *pI = tiles + lds_tile_index(I, k, nbf) * TSZ;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) c[v] = tile[Mfma<T>::row(lane, v) * LDT + li];
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
-                            c = Mfma<T>::mma(-pI[li * LDT + 4 * ks + kk], pJ[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) tile[Mfma<T>::row(lane, v) * LDT + li] = c[v];
-                    } else {
-                        T *bJ = border + ((I - nbf) * nbf + J) * LDT;
-                        const T *bk = border + ((I - nbf) * nbf + k) * LDT;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) c[v] = (Mfma<T>::row(lane, v) == 0) ? bJ[li] : (T)0;
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
-                            c = Mfma<T>::mma(li == 0 ? -bk[4 * ks + kk] : (T)0, pJ[li * LDT + 4 * ks + kk], c);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            if (Mfma<T>::row(lane, v) == 0) bJ[li] = c[v];
-                    }
-                }
-            }
-            ACC_END(6);
+            for (int c = 0; c < 16; ++c) tkk[li * LDT + c] = (c <= li) ? g[c] : (T)0;
         }
+        { ACC_BEGIN();
+        potrf_lds_update<T>(tiles, dinv, nbf, nborder, k, wv, lane);
+        ACC_END(6); }
         __syncthreads();
+    }
+    if (threadIdx.x == 0 && failed && *fail == 0) *fail = failed;
+    if (dinv_glob) {                       // inverted diagonal tiles for the callers that go on to L^-1 (trtri_lds / potri_lds)
+        for (int k = wv; k < nbf; k += 4)
+            diag_tile<T, false, true>(tiles + lds_tile_index(k, k, nbf) * TSZ, LDT, (T *)nullptr, dinv_glob + k * 256, (int *)nullptr, 0);
     }
 }
 
@@ -398,7 +689,7 @@ __device__ void potrf_lds(T *tiles, T *dinv, int nbf, int nbr, int *fail, T *din
 //   2. out_ij = sum_{k >= i} W_ki^T W_kj row by row (row i of W is not read again by later rows).
 // Every product is the tile primitive C += X Y^T of Mfma<T>::mma on 16x16 LDS tiles (Y read transposed where needed).
 template <typename T>
-__device__ void trtri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {       // step 1 alone: tiles <- L^-1
+__device__ __forceinline__ void trtri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {       // step 1 alone: tiles <- L^-1
     typedef typename Mfma<T>::acc_t acc_t;
     constexpr int MAXT = 3;                                   // tiles of one row per wave: nb <= 12
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
@@ -446,7 +737,7 @@ __device__ void trtri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {      
     }
 }
 template <typename T>
-__device__ void potri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {
+__device__ __forceinline__ void potri_lds(T *tiles, T *dinv, const T *dinv_glob, int nb) {
     typedef typename Mfma<T>::acc_t acc_t;
     constexpr int MAXT = 3;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;

@@ -10,9 +10,13 @@ init = dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']
 model = dp_gp_lvm(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=t, alpha_prior_params=np.array([p['s1'], p['s2']]), device='cuda:0', initial_values=init, precision='mixed')
 for _ in range(5): float(model.objective)
 torch.cuda.synchronize()
-out = (ctypes.c_longlong * 16)()
+out = (ctypes.c_longlong * 64)()
 l = ctypes.CDLL(_lib.LIB_PATH)
 l.dpgp_debug_stamps(out)
 s = list(out)
 print('stamps (10 ns units):', s[:8])
 print('assemble %.1f us, factorisation %.1f us, sums %.1f us' % ((s[1] - s[0]) * 0.01, (s[2] - s[1]) * 0.01, (s[3] - s[2]) * 0.01))
+print('shader cycles per step k, panel (wave 0):', s[16:24])
+print('shader cycles per step k, update (wave 1):', s[32:40])
+print('   of which inside run() (summed over all evaluations / 5):', [x // 5 for x in s[48:56]])
+print('shader clock during the factorisation: %.0f MHz (s_memtime ticks / wall clock)' % ((s[10] - s[9]) / ((s[2] - s[1]) * 0.01)))
