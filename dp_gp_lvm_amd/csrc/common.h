@@ -87,7 +87,7 @@ __device__ __forceinline__ double dpgp_exp2(double x) {
 // |r| <= 1/128.  k and j come out of ONE addition of 1.5 * 2^46 (the sum's ulp is 1/64, so its low dword is round(64 x) in
 // two's complement), T[j] = 2^(j/64) from a 64-entry table that the workgroup keeps in LDS (512 B; lanes reading the same
 // entry broadcast), 2^r by the degree-5 Taylor polynomial of exp(r ln 2) (truncation (ln2/128)^6/720 = 3.5e-17 relative),
-// 2^k by v_ldexp_f64, which also gives 0 / inf for arguments far outside the exponent range and keeps NaN a NaN.
+// 2^k by v_ldexp_f64, which also gives 0 / inf for arguments far outside the exponent range; NaN in gives NaN out.
 // 12 fp64 + 3 integer instructions + one ds_read_b64 per value against ~24 fp64 instructions of dpgp_exp2(double)
 // (measured on gfx950, scratch/ubench/f64exp.hip: 70 vs 170 issue cycles per wave-instruction-equivalent; worst relative
 // error 2.5e-16 on [-1100, 50]).  Valid for x < 2^25 (larger arguments mean an infinite result anyway).
@@ -115,9 +115,9 @@ __device__ __forceinline__ void dpgp_exp2_tab_init(double *tab) {
 }
 __device__ __forceinline__ double dpgp_exp2_tab(double x, const double *tab) {
     const double MAGIC = 105553116266496.0;                       // 1.5 * 2^46
-    const double xc = __builtin_fmax(x, -1100.0);                 // 2^-1100 = 0; keeps round(64 x) inside 32 bits (a NaN
-                                                                  // argument gives 0 here: callers exponentiate sums of
-                                                                  // finite log-densities, NaN inputs surface elsewhere)
+    const double xc = x < -1100.0 ? -1100.0 : x;                  // 2^-1100 = 0; keeps round(64 x) inside 32 bits.  A select,
+                                                                  // not fmax: a NaN argument stays NaN through every step below
+                                                                  // (fmax would turn it into 2^-1100 = 0)
     const double t = xc + MAGIC;
     const int lo = (int)__builtin_bit_cast(long long, t);         // round(64 x)
     const double r = xc - (t - MAGIC);

@@ -243,7 +243,7 @@ extern "C" int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, in
     if (!beta) return -12;
     if (!(jitter >= 0.0)) return -13;
     if (prec < 0 || prec > 2) return -14;
-    if (algo < 0 || algo > DPGP_ALGO_MFMA_F32) return -15;
+    if (algo < 0 || algo > DPGP_ALGO_PATCH_F16) return -15;
     if (!terms) return -16;
     if (!sums) return -17;
     if (!info) return -18;

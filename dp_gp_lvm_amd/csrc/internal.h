@@ -71,6 +71,9 @@ int launch_sum_terms(int D, const double *terms, const double *kl_part, double *
 // a[B][M][M] in/out (lower, zeros above), info[B], ws: potrf_big_ws_elems(B, M) elements of T
 size_t potrf_big_ws_elems(int B, int M);
 template <typename T> int launch_potrf_big(int B, int M, T *a, int *info, T *ws, hipStream_t st);
+// ---- potrf_persist.hip: fp64, one persistent workgroup per matrix (Mw a multiple of 128, w[B][Mw][Mw] in place, lower + zeros)
+bool potrf_persist_applicable(int B, int M, int elem_size);
+int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st);
 // ---- grad.hip: backward pass (first version) ---------------------------------------------------------------------
 // adjoints of the per-output dense algebra, after a forward evaluation on the same chain workspace ws:
 //   GP[D][Mp][Mp] = df/dPsi2 (lower), WK[D][Mp][Mp] = (df/dK_uu) * (K_uu - jitter I) (lower), Gv[D][Mp] = df/d(Psi1^T y),

@@ -452,27 +452,79 @@ template <typename T, int J> struct PanelScale {
     }
 };
 
-// Trailing update of potrf_lds.  Work items of step k: the m (m + 1) / 2 lower tiles (m = tiles below the diagonal one) in
-// row-major order, then the border vectors' m tile columns each; item t belongs to wave t & 3.
-// UpdPlan: the tile offsets of a wave's items, decoded ONCE per step with one item per lane (vector integer work, ~40
-// instructions) and handed to the item loop by v_readlane — decoding per item on the scalar unit (triangular index ->
-// row / column, three tile offsets) cost ~120 scalar instructions with a dozen branches, 700-900 cycles per item against 260
-// for the item's four MFMAs (stamps of the first version).
+// ---- inverse of a lower-triangular 16 x 16 LDS tile with DPP row broadcasts: one tile per ROW of 16 lanes (four tiles per
+// wave at a time), lane = row.  X = L^-1 by forward substitution on rows: x_i = (e_i - sum_{j<i} L_ij x_j) / L_ii, kept
+// unscaled (x'_i = x_i L_ii) until the end so that a finished row needs no write of its own before it is broadcast.
+// x -= x[lane J of the row] * t.  The s_nop rides INSIDE the statement: x may have been written by a compiler-scheduled vector
+// instruction (its initialisation lands wherever the scheduler likes, e.g. directly in front of this statement), and a DPP
+// read needs two wait states behind such a write — found on the GPU as a first column of the inverse scaled by 1 / L_00.
+template <typename T, int J> __device__ __forceinline__ void dpp_fnma_self(T &x, T t) {
+    if constexpr (sizeof(T) == 8) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(t), "n"(J));
+    else asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(t), "n"(J));
+}
+template <typename T, int J, int C> struct TriInvCols {         // columns C .. J of step J
+    static __device__ __forceinline__ void run(T (&x)[16], T t) {
+        if constexpr (C <= J) {
+            dpp_fnma_self<T, J>(x[C], t);
+            TriInvCols<T, J, C + 1>::run(x, t);
+        }
+    }
+};
+template <typename T, int J> struct TriInvStep {
+    static __device__ __forceinline__ void run(T (&x)[16], const T (&gz)[16], T rown) {
+        if constexpr (J < 15) {                               // (row 15 is nobody's source)
+            const T t = gz[J] * row_bcast<T, J, 1>(rown);         // L_iJ / L_JJ for rows i > J, 0 for the others
+            TriInvCols<T, J, 0>::run(x, t);
+            TriInvStep<T, J + 1>::run(x, gz, rown);
+        }
+    }
+};
+// tile: this lane row's lower-triangular tile (row stride LDT, zeros above the diagonal); out: row stride ldo
+template <typename T> __device__ __forceinline__ void tri_inverse_dpp(const T *tile, T *out, int ldo, int lane) {
+    const int li = lane & 15;
+    T gz[16], x[16], d = (T)1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const T v = tile[li * LDT + c];
+        d = (c == li) ? v : d;
+        gz[c] = (c == li) ? (T)0 : v;                         // the row's own multiplier must be 0
+        x[c] = (c == li) ? (T)1 : (T)0;
+    }
+    const T rown = (T)1 / d;
+    asm volatile("s_nop 4");                                  // (EXEC / VALU writes settled in front of the first DPP read)
+    TriInvStep<T, 0>::run(x, gz, rown);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) out[li * ldo + c] = x[c] * rown;
+}
+
+// ---- trailing update of potrf_lds -------------------------------------------------------------------------------------
+// Step k updates the tiles behind block column k in two phases (see potrf_lds): COLUMN = block column k + 1 alone (what the
+// next panel needs), REST = the lower triangle from tile column k + 2 on.  Work items of a phase: its tiles (I, J) in
+// row-major order, then the border vectors' tile columns; a wave is handed a contiguous range of that list.
+// UpdPlan: the tile offsets of a wave's items, decoded ONCE per phase with one item per lane (vector integer work) and handed
+// to the item loop by v_readlane — decoding per item on the scalar unit (triangular index -> row / column, three tile
+// offsets) cost ~120 scalar instructions with a dozen branches, 700-900 cycles per item against 260 for the item's four
+// MFMAs (stamps of the first version).
 template <typename T> struct UpdPlan {
-    int oa, ob, oc, isb;     // per lane: element offsets from `tiles` of the A / B operand tiles and the C tile; border flag
-    __device__ __forceinline__ void build(int wv, int lane, int border_ofs, int nbf, int k, int m, int ntri) {
-        const int t = wv + 4 * lane;
-        const int tt = min(t, max(ntri - 1, 0));
+    int oa, ob, oc;          // per lane: element offsets from `tiles` of the A / B operands' and the C tile (or border entries)
+    // rest != 0: item t of the lower triangle from tile index k + 2 on; rest == 0: item t of block column k + 1
+    __device__ __forceinline__ void regular(int rest, int t, int nbf, int k) {
+        const int tt = max(t, 0);
         int r = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
         r += ((r + 1) * (r + 2) / 2 <= tt) ? 1 : 0;
         r -= (r * (r + 1) / 2 > tt) ? 1 : 0;
-        const int tb = max(t - ntri, 0);
-        const int bi = (int)(((float)tb + 0.5f) * (1.0f / (float)max(m, 1))), qb = tb - bi * m;
-        isb = t >= ntri ? 1 : 0;
-        const int I = k + 1 + r, J = k + 1 + (isb ? qb : tt - r * (r + 1) / 2);
-        oa = isb ? border_ofs + (bi * nbf + k) * LDT : lds_tile_index(I, k, nbf) * TSZ;
+        const int I = rest ? k + 2 + r : k + 1 + tt, J = rest ? k + 2 + (tt - r * (r + 1) / 2) : k + 1;
+        oa = lds_tile_index(I, k, nbf) * TSZ;
         ob = lds_tile_index(J, k, nbf) * TSZ;
-        oc = isb ? border_ofs + (bi * nbf + J) * LDT : lds_tile_index(I, J, nbf) * TSZ;
+        oc = lds_tile_index(I, J, nbf) * TSZ;
+    }
+    // border item t: vector t / ncol, tile column (rest ? k + 2 : k + 1) + t % ncol   (ncol = 1 for the column phase)
+    __device__ __forceinline__ void border(int rest, int t, int nbf, int k, int ncol, int border_ofs) {
+        const int tt = max(t, 0), nc = max(ncol, 1);
+        const int bi = (int)(((float)tt + 0.5f) * (1.0f / (float)nc)), J = (rest ? k + 2 : k + 1) + (tt - bi * nc);
+        oa = border_ofs + (bi * nbf + k) * LDT;
+        ob = lds_tile_index(J, k, nbf) * TSZ;
+        oc = border_ofs + (bi * nbf + J) * LDT;
     }
 };
 #ifdef UPD_DIAG_NO_MFMA       // scratch/ubench/chol_phases.hip only: the item loop without its matrix instructions
@@ -480,74 +532,57 @@ template <typename T> struct UpdPlan {
 #else
 #define UPD_MMA(x, y, z) Mfma<T>::mma(x, y, z)
 #endif
-// One item: C -= A B^T on 16 x 16 LDS tiles, or (border) the one row c -= a B^T as row 0 of such a product.  No branch and no
-// mask anywhere: row i of an MFMA result depends on row i of A only, so a border item lets every lane row read the border
-// vector and sends the result elements it does not own to a dummy LDS tile (`dummy`: TSZ elements nobody reads for data).
-// fetch() of the wave's next item stands in the same basic block as run() of the current one; interleave() then tells the
-// scheduler to put the loads and the address arithmetic into the issue gaps of the four dependent MFMAs (64 cycles each on
-// gfx950, ~8 of them busy issuing) instead of clustering the MFMAs, which left the wave stalled in between (first version:
-// 1200 cycles per item, of which 260 MFMA).
-template <typename T> struct UpdItem {
+// One item: C -= A B^T on 16 x 16 LDS tiles (BORDER = false), or the one row c -= a B^T as row 0 of such a product (BORDER:
+// row i of an MFMA result depends on row i of A only, so every lane row simply reads the border vector; the lanes that own no
+// result element aim their one store at the dummy tile).  No branch anywhere, constant strides (ds_read2 / ds_write2 with
+// immediate offsets).  step() runs an item while fetching the wave's next one: the compiler clusters the four dependent
+// MFMAs (64 cycles each on gfx950) and the wave sits out each in front of the next; scheduling barriers keep the next item's
+// address arithmetic and LDS reads in those gaps, in source order.  (fp64 MFMA and vector instructions of the same wave do
+// not overlap — what the gaps hide is LDS latency, not issue.)
+template <typename T, bool BORDER> struct UpdItem {
     typedef typename Mfma<T>::acc_t acc_t;
     T a[4], b[4];
     acc_t c;
-    T *pc0, *pc1;            // this lane's C elements: pc0[0] and pc1[(v - 1) * cs1], v = 1..3
-    int cs1;
+    const T *pa, *pb;
+    T *pc;                   // this lane's first C element; its four are pc[v * cst]   (BORDER: its one)
     static constexpr int cst = (sizeof(T) == 8 ? 4 : 1) * LDT;     // rows of a lane's C elements: Mfma<T>::row(lane, v)
-    __device__ __forceinline__ void fetch(T *tiles, T *dummy, const UpdPlan<T> &pl, int i, int lane) {
+    __device__ __forceinline__ void locate(T *tiles, T *dummy, const UpdPlan<T> &pl, int i, int lane) {
         const int li = lane & 15, kk = lane >> 4;
         const int oa = __builtin_amdgcn_readlane(pl.oa, i), ob = __builtin_amdgcn_readlane(pl.ob, i),
-                  oc = __builtin_amdgcn_readlane(pl.oc, i), isb = __builtin_amdgcn_readlane(pl.isb, i);
-        const T *pa = tiles + oa + (isb ? kk : li * LDT + kk);
-        const T *pb = tiles + ob + li * LDT + kk;
-        T *creg = tiles + oc + Mfma<T>::row(lane, 0) * LDT + li;
-        T *cbrd = Mfma<T>::row(lane, 0) == 0 ? tiles + oc + li : dummy + lane;
-        pc0 = isb ? cbrd : creg;
-        pc1 = isb ? dummy + lane : creg + cst;
-        cs1 = isb ? 0 : cst;
+                  oc = __builtin_amdgcn_readlane(pl.oc, i);
+        pb = tiles + ob + li * LDT + kk;
+        if constexpr (BORDER) {
+            pa = tiles + oa + kk;
+            pc = Mfma<T>::row(lane, 0) == 0 ? tiles + oc + li : dummy + lane;
+        } else {
+            pa = tiles + oa + li * LDT + kk;
+            pc = tiles + oc + Mfma<T>::row(lane, 0) * LDT + li;
+        }
+    }
+    __device__ __forceinline__ void load_ab() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             a[ks] = pa[4 * ks];
             b[ks] = pb[4 * ks];
         }
-        c[0] = pc0[0];
-#pragma unroll
-        for (int v = 1; v < 4; ++v) c[v] = pc1[(v - 1) * cs1];
-    }
-    // the same, split into the pieces that step() places between the MFMAs of the item before
-    const T *pa_, *pb_;
-    __device__ __forceinline__ void locate(T *tiles, T *dummy, const UpdPlan<T> &pl, int i, int lane) {
-        const int li = lane & 15, kk = lane >> 4;
-        const int oa = __builtin_amdgcn_readlane(pl.oa, i), ob = __builtin_amdgcn_readlane(pl.ob, i),
-                  oc = __builtin_amdgcn_readlane(pl.oc, i), isb = __builtin_amdgcn_readlane(pl.isb, i);
-        pa_ = tiles + oa + (isb ? kk : li * LDT + kk);
-        pb_ = tiles + ob + li * LDT + kk;
-        T *creg = tiles + oc + Mfma<T>::row(lane, 0) * LDT + li;
-        T *cbrd = Mfma<T>::row(lane, 0) == 0 ? tiles + oc + li : dummy + lane;
-        pc0 = isb ? cbrd : creg;
-        pc1 = isb ? dummy + lane : creg + cst;
-        cs1 = isb ? 0 : cst;
-    }
-    __device__ __forceinline__ void load_ab() {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            a[ks] = pa_[4 * ks];
-            b[ks] = pb_[4 * ks];
-        }
     }
     __device__ __forceinline__ void load_c() {
-        c[0] = pc0[0];
+        c[0] = pc[0];
 #pragma unroll
-        for (int v = 1; v < 4; ++v) c[v] = pc1[(v - 1) * cs1];
+        for (int v = 1; v < 4; ++v) c[v] = BORDER ? (T)0 : pc[v * cst];
     }
     __device__ __forceinline__ void store_c() {
-        pc0[0] = c[0];
+        pc[0] = c[0];
+        if constexpr (!BORDER) {
 #pragma unroll
-        for (int v = 1; v < 4; ++v) pc1[(v - 1) * cs1] = c[v];
+            for (int v = 1; v < 4; ++v) pc[v * cst] = c[v];
+        }
     }
-    // run this item while fetching the wave's item `inext` into nx.  The compiler clusters the four dependent MFMAs (64
-    // cycles each on gfx950, ~8 of them busy issuing) and the wave sits out the rest of each in front of the next one; the
-    // scheduling barriers keep the next item's address arithmetic and LDS reads in those gaps, in source order.
+    __device__ __forceinline__ void fetch(T *tiles, T *dummy, const UpdPlan<T> &pl, int i, int lane) {
+        locate(tiles, dummy, pl, i, lane);
+        load_ab();
+        load_c();
+    }
     __device__ __forceinline__ void step(UpdItem &nx, T *tiles, T *dummy, const UpdPlan<T> &pl, int inext, int lane) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a[ks] = -a[ks];
@@ -569,6 +604,42 @@ template <typename T> struct UpdItem {
         store_c();
     }
 };
+// items 0 .. n - 1 of a plan (n <= 64), two register sets
+template <typename T, bool BORDER>
+__device__ __forceinline__ void upd_run_items(T *tiles, T *dummy, const UpdPlan<T> &plan, int n, int lane) {
+    UpdItem<T, BORDER> X, Y;
+    if (n > 0) X.fetch(tiles, dummy, plan, 0, lane);
+    for (int i = 0; i < n; i += 2) {
+        X.step(Y, tiles, dummy, plan, min(i + 1, n - 1), lane);        // (past the end: the last item once more, never run)
+        if (i + 1 >= n) break;
+        Y.step(X, tiles, dummy, plan, min(i + 2, n - 1), lane);
+    }
+}
+// number of items of a phase of step k (rest: see UpdPlan)
+static __device__ __forceinline__ int potrf_lds_items(int nbf, int nborder, int k, int rest) {
+    const int m = nbf - 1 - k;                                          // tiles below the diagonal one
+    if (m <= 0) return 0;
+    return rest ? (m - 1) * m / 2 + nborder * (m - 1) : m + nborder;
+}
+// This wave's share [start, start + cnt) of the item list of a phase of step k
+template <typename T>
+__device__ __forceinline__ void potrf_lds_update(T *tiles, T *dummy, int nbf, int nborder, int k, int rest, int start, int cnt,
+                                                 int lane) {
+    const int m = nbf - 1 - k;
+    const int ncol = rest ? m - 1 : 1, nreg = rest ? (m - 1) * m / 2 : m;
+    const int r0 = min(start, nreg), r1 = min(start + cnt, nreg);
+    const int b0 = max(start, nreg) - nreg, b1 = max(start + cnt, nreg) - nreg;
+    if (r1 > r0) {
+        UpdPlan<T> plan;
+        plan.regular(rest, r0 + lane, nbf, k);
+        upd_run_items<T, false>(tiles, dummy, plan, r1 - r0, lane);
+    }
+    if (b1 > b0) {
+        UpdPlan<T> plan;
+        plan.border(rest, b0 + lane, nbf, k, ncol, (nbf * (nbf + 1) / 2) * TSZ);
+        upd_run_items<T, true>(tiles, dummy, plan, b1 - b0, lane);
+    }
+}
 
 // tiles: LDS array of TSZ-element tiles followed by the border vectors.  On exit the tiles hold L and the border vectors
 // L^-1 v.  dinv_glob (optional): [nbf][256] global array that receives the inverted diagonal tiles (computed after the
@@ -576,15 +647,18 @@ template <typename T> struct UpdItem {
 // OCC only separates instantiations: a kernel bounded to 2 workgroups per CU (256 VGPRs) must not share this function's
 // register allocation with an unbounded one.
 //
-// Right-looking over block columns of 16.  Step k has two phases and two barriers:
-//   PANEL (registers, one matrix row per lane): every row of 16 lanes holds the 16 rows of the diagonal tile (full symmetric
+// Right-looking over block columns of 16, with a look-ahead of one block column:
+//   PANEL k (registers, one matrix row per lane): every row of 16 lanes holds the 16 rows of the diagonal tile (full symmetric
 //     rows, redundantly) and every lane one row below it (64 per wave; the border vectors are rows like any other).  Pivot j:
 //     each lane scales its own entries of column j by 1/d and updates its two rows with one v_fmac_f64 per column whose
-//     second factor — the entry of row j of the tile — comes from lane j of its own row of lanes by DPP (RowBcast).  The rows
-//     come out as L_kk and A_Ik L_kk^-T: no inverse of the diagonal tile, no panel product, no cross-wave traffic.
+//     second factor — the entry of row j of the tile — comes from lane j of its own row of lanes by DPP.  The rows come out
+//     as L_kk and A_Ik L_kk^-T: no inverse of the diagonal tile, no panel product, no cross-wave traffic.
 //     (Round 2 factored + inverted the diagonal tile on one wave with v_readlane broadcasts — 3.7 us of the 5-6 us per
 //     step — and formed the panel with that inverse on the matrix pipe.)
-//   UPDATE (matrix pipe): A_IJ -= P_I P_J^T for k < J <= I, tiles dealt round-robin to the four waves.
+//   UPDATE k (matrix pipe): A_IJ -= P_I P_J^T for k < J <= I, in two parts: block column k + 1 by all four waves, then — at
+//     the same time — panel k + 1 on the wave(s) holding its rows and the rest (J >= k + 2) on the others.  The panel is a
+//     chain of 16 dependent pivots (~3100 cycles) that nothing shortens; the look-ahead takes the bulk of the matrix-pipe
+//     work out from between two panels.
 // PANEL phase of step k (see potrf_lds): on exit the rows below the diagonal tile are stored; g holds row (lane & 15) of L_kk,
 // which the caller stores after its barrier.  Returns the first non-positive pivot of the tile (1-based) or 0.
 template <typename T>
@@ -622,22 +696,7 @@ __device__ __forceinline__ int potrf_lds_panel(T *tiles, T *border, int nbf, int
     }
     return bad;
 }
-// UPDATE phase of step k
-template <typename T>
-__device__ __forceinline__ void potrf_lds_update(T *tiles, T *dummy, int nbf, int nborder, int k, int wv, int lane) {
-    const int m = nbf - 1 - k, ntri = m * (m + 1) / 2, ntot = ntri + nborder * m;
-    const int nit = wv < ntot ? (ntot - wv + 3) >> 2 : 0;              // this wave's items: t = wv, wv + 4, ...  (<= 64)
-    UpdPlan<T> plan;
-    plan.build(wv, lane, (nbf * (nbf + 1) / 2) * TSZ, nbf, k, m, ntri);
-    UpdItem<T> X, Y;
-    if (nit > 0) X.fetch(tiles, dummy, plan, 0, lane);
-    for (int i = 0; i < nit; i += 2) {
-        X.step(Y, tiles, dummy, plan, min(i + 1, nit - 1), lane);      // (past the end: the last item once more, never run)
-        if (i + 1 >= nit) break;
-        Y.step(X, tiles, dummy, plan, min(i + 2, nit - 1), lane);
-    }
-}
-
+#define LA_PANEL_CREDIT 5     // one block column's panel phase ~ this many update items of wave time (3100 vs ~450-700 cycles)
 template <typename T, int OCC = 1>
 __device__ __forceinline__ void potrf_lds(T *tiles, T *dinv, int nbf_, int nbr_, int *fail, T *dinv_glob = nullptr) {
     const int lane = threadIdx.x & 63, li = lane & 15, kk = lane >> 4;
@@ -657,26 +716,53 @@ __device__ __forceinline__ void potrf_lds(T *tiles, T *dinv, int nbf_, int nbr_,
         if (c > r) t[r * LDT + c] = t[c * LDT + r];
     }
     __syncthreads();
+    T g[16];                                                  // row li of the diagonal tile -> of L_kk (panel waves)
+    {
+        const int k = 0;
+        (void)k;
+        ACC_BEGIN();
+        failed = potrf_lds_panel<T>(tiles, border, nbf, nborder, 0, wv, lane, g);
+        ACC_END(4);
+    }
+    __syncthreads();
     for (int k = 0; k < nbf; ++k) {
-        T g[16];                                              // row li of the diagonal tile -> of L_kk
-        { ACC_BEGIN();
-        const int bad = potrf_lds_panel<T>(tiles, border, nbf, nborder, k, wv, lane, g);
-        failed = (bad && failed == 0) ? 16 * k + bad : failed;
-        ACC_END(4); }
-        __syncthreads();
-        // L_kk goes back only now: every wave read the unfactored diagonal tile during the panel phase
+        // L_kk goes back only now: every panel wave read the unfactored diagonal tile during the panel phase
         if (wv == 0 && kk == 0) {
             T *tkk = tiles + lds_tile_index(k, k, nbf) * TSZ;
 #pragma unroll
             for (int c = 0; c < 16; ++c) tkk[li * LDT + c] = (c <= li) ? g[c] : (T)0;
         }
-        { ACC_BEGIN();
-        potrf_lds_update<T>(tiles, dinv, nbf, nborder, k, wv, lane);
-        ACC_END(6); }
+        if (k + 1 == nbf) break;
+        // COLUMN phase: block column k + 1, dealt evenly to the four waves
+        {
+            ACC_BEGIN();
+            const int nc = potrf_lds_items(nbf, nborder, k, 0), per = (nc + 3) >> 2;
+            potrf_lds_update<T>(tiles, dinv, nbf, nborder, k, 0, min(wv * per, nc), min(per, max(nc - wv * per, 0)), lane);
+            ACC_END(5);
+        }
+        __syncthreads();
+        // REST phase: the waves that hold rows of block column k + 1 factor it first (panel k + 1) and take LA_PANEL_CREDIT
+        // items fewer of the rest of update k, which touches neither that block column nor anything the panel reads
+        {
+            ACC_BEGIN();
+            const int nrows_next = 16 * (nbf - 2 - k) + nborder;
+            const int np = min(max((nrows_next + 63) >> 6, 1), 4);         // panel waves: 0 .. np - 1
+            const int nr = potrf_lds_items(nbf, nborder, k, 1);
+            const int share = (nr + np * LA_PANEL_CREDIT + 3) >> 2, pshare = max(share - LA_PANEL_CREDIT, 0);
+            const int mine = wv < np ? pshare : share;
+            const int before = wv < np ? wv * pshare : np * pshare + (wv - np) * share;
+            if (wv < np) {
+                const int bad = potrf_lds_panel<T>(tiles, border, nbf, nborder, k + 1, wv, lane, g);
+                failed = (bad && failed == 0) ? 16 * (k + 1) + bad : failed;
+            }
+            potrf_lds_update<T>(tiles, dinv, nbf, nborder, k, 1, min(before, nr), min(mine, max(nr - before, 0)), lane);
+            ACC_END(6);
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0 && failed && *fail == 0) *fail = failed;
     if (dinv_glob) {                       // inverted diagonal tiles for the callers that go on to L^-1 (trtri_lds / potri_lds)
+        __syncthreads();
         for (int k = wv; k < nbf; k += 4)
             diag_tile<T, false, true>(tiles + lds_tile_index(k, k, nbf) * TSZ, LDT, (T *)nullptr, dinv_glob + k * 256, (int *)nullptr, 0);
     }

@@ -242,6 +242,26 @@ int launch_potrf_big(int B, int M, T *a, int *info, T *ws, hipStream_t st) {
     const int lookahead = (nl_ && nl_[0] == '1') ? 0 : 1;
     T *w = in_place ? a : ws, *winv = ws + (size_t)B * Mw * Mw, *dinv_g = winv + (size_t)B * PW * PW,
       *pbuf = dinv_g + (size_t)B * (PW / 16) * 256;
+    // enough fp64 matrices to give every compute unit its own: one persistent workgroup per matrix (potrf_persist.hip).
+    // DPGP_POTRF_PERSISTENT=0 / 1 (tests, profiling): never / whenever the element type allows it
+    if constexpr (sizeof(T) == 8) {
+        const char *pe_ = getenv("DPGP_POTRF_PERSISTENT");
+        const bool use = pe_ ? pe_[0] == '1' : potrf_persist_applicable(B, M, (int)sizeof(T));
+        if (use) {
+            const int cp0 = dpgp_ceil_div(Mw * Mw, 256 * 8);
+            if (!in_place) {
+                DPGP_PRELAUNCH(); hipLaunchKernelGGL((pbig_copy_in<T>), dim3(cp0, B), dim3(256), 0, st, M, Mw, (const T *)a, w);
+                DPGP_LAUNCH_CHECK();
+            }
+            const int rc = launch_potrf_persist(B, Mw, reinterpret_cast<double *>(w), info, st);
+            if (rc != DPGP_OK) return rc;
+            if (!in_place) {
+                DPGP_PRELAUNCH(); hipLaunchKernelGGL((pbig_copy_out<T>), dim3(cp0, B), dim3(256), 0, st, M, Mw, a, (const T *)w);
+                DPGP_LAUNCH_CHECK();
+            }
+            return DPGP_OK;
+        }
+    }
     const size_t lds_diag = LA_LDS_HDR + sizeof(T) * (size_t)TSZ * (1 + (PW / 16) * (PW / 16 + 1) / 2);
     const size_t lds_blk = sizeof(T) * (size_t)2 * RB * RB_LD, lds_u = sizeof(T) * (size_t)2 * UB * KQ_LD;
     const size_t lds_upd = lds_u > lds_diag ? lds_u : lds_diag;        // the look-ahead workgroup reuses it for the diagonal block

@@ -1,0 +1,274 @@
+// Batched fp64 Cholesky for M > 128 when there are enough matrices to give every compute unit one of its own (config 4:
+// B = D = 256 matrices of 512 x 512 on 256 CUs; reference: tf.cholesky on [D, M, M], dp_gp_lvm.py:116,127): ONE persistent
+// workgroup (4 waves, the CU's whole LDS and register file) factors a matrix from start to end — no kernel boundaries, no
+// panel buffer, no explicit inverse of a diagonal block.  Right-looking over 128-wide block columns; per block column k:
+//   (a) DIAGONAL BLOCK  L_kk = chol(A_kk), LDS-resident (potrf_lds: register panels with DPP row broadcasts + MFMA updates);
+//       the zeros of block row k to the right of it are stored first and drain while the block is factored.
+//   (b) its eight 16 x 16 diagonal tiles inverted, one tile per row of 16 lanes (tri_inverse_dpp).
+//   (c) PANEL  P_I = A_Ik L_kk^-T for the 16-row tiles I below, as a chain of 16 x 16 MFMA products that never leaves the
+//       registers: with X = P_I^T held in the accumulator layout, register v of a result tile IS the B operand of K-step v of
+//       the next product (fp64 16x16x4: C/D row = (lane >> 4) + 4 v), so forward substitution over the eight tile columns
+//       X_c = Linv_cc (A_Ic^T - sum_{c' < c} L_cc' X_c') needs only the L tiles (A operands, from LDS).  144 MFMAs per row
+//       tile instead of the 256 of a product with an explicit 128 x 128 inverse, and no trtri.  Rows travel between
+//       global memory and the transposed register layout through a per-wave LDS staging tile (coalesced 1 KB rows).
+//   (d) UPDATE  A_IJ -= P_I P_J^T on 128 x 128 blocks, K = 128 in four chunks of 32 staged in LDS with two buffers: the next
+//       chunk's global loads are in flight during the current chunk's 72-128 MFMAs per wave.  A wave owns row tiles w and
+//       7 - w of a block, so that a diagonal block (lower tiles only) costs every wave the same 9 of 16 tiles.  The block's
+//       old values are fetched during its last chunk and added at the end (the accumulation starts from zero).
+// The multi-workgroup routine (potrf_big.hip) remains for few matrices (B < 128), fp32 and as cross-check.
+#include <cstdlib>
+#include "internal.h"
+#include "linalg_dev.h"
+
+#define PP_PW 128                 // block column width
+#define PP_NT (PP_PW / 16)        // tiles per block edge
+#define PP_SLD (PP_PW + 2)        // row stride of a wave's staging tile [16][PP_SLD] (16-byte aligned rows)
+#define PP_KQ 32                  // K staged per chunk of the update
+#define PP_KLD (PP_KQ + 2)        // row stride of a staged chunk [128][PP_KLD]
+
+typedef double pp_f2 __attribute__((ext_vector_type(2)));
+
+static size_t pp_lds_bytes() {
+    const size_t fact = LA_LDS_HDR + sizeof(double) * ((size_t)TSZ * (PP_NT * (PP_NT + 1) / 2 + PP_NT) + (size_t)4 * 16 * PP_SLD);
+    const size_t upd = LA_LDS_HDR + sizeof(double) * (size_t)2 * 2 * PP_PW * PP_KLD;
+    return fact > upd ? fact : upd;
+}
+
+// ---- (c) one wave, one 16-row tile I below the diagonal block: S (staging, [16][PP_SLD]) holds A_Ik on entry and P_I on exit
+__device__ __forceinline__ void pp_trsm_tile(double *S, const double *tiles, const double *linv, int lane) {
+    typedef f64x4 acc_t;
+    const int li = lane & 15, kk = lane >> 4;
+    acc_t X[PP_NT];
+#pragma unroll
+    for (int c = 0; c < PP_NT; ++c) {
+        acc_t a;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a[v] = S[li * PP_SLD + 16 * c + 4 * v + kk];          // (A_Ic)^T in the accumulator layout
+#pragma unroll
+        for (int cp = 0; cp < c; ++cp) {
+            const double *lt = tiles + lds_tile_index(c, cp, PP_NT) * TSZ + li * LDT + kk;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-lt[4 * ks], X[cp][ks], a, 0, 0, 0);
+        }
+        const double *iv = linv + c * TSZ + li * LDT + kk;
+#ifdef PP_DEBUG_NOPS
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+        acc_t x = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[4 * ks], a[ks], x, 0, 0, 0);
+        X[c] = x;
+#ifdef PP_DEBUG_NOPS
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+    }
+#pragma unroll
+    for (int c = 0; c < PP_NT; ++c)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) S[li * PP_SLD + 16 * c + 4 * v + kk] = X[c][v];
+}
+
+__global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__restrict__ w, int *__restrict__ info) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    int &fail = *reinterpret_cast<int *>(smem_raw + 64);
+    double *base = reinterpret_cast<double *>(smem_raw + LA_LDS_HDR);
+    double *tiles = base;                                              // factorisation phases: 36 lower tiles of the diagonal block,
+    double *linv = tiles + (size_t)TSZ * (PP_NT * (PP_NT + 1) / 2);   //   its 8 inverted diagonal tiles,
+    double *stage = linv + (size_t)TSZ * PP_NT;                        //   4 staging tiles [16][PP_SLD]
+    const int t = threadIdx.x, lane = t & 63, li = lane & 15, kk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = blockIdx.x, nblk = Mw / PP_PW;
+    double *A = w + (size_t)b * Mw * Mw;
+    constexpr int nlow = PP_NT * (PP_NT + 1) / 2;
+    int first_fail = 0;
+    for (int k = 0; k < nblk; ++k) {
+        double *Akk = A + (size_t)(PP_PW * k) * Mw + PP_PW * k;
+        const int nbelow = Mw - PP_PW * (k + 1);                       // rows below / columns to the right of the block
+        // ---- (a) zeros to the right of the diagonal block (stores drain during the factorisation), block -> LDS tiles ----
+        for (int e = t; e < PP_PW * (nbelow / 2); e += 256) {
+            const int r = e / (nbelow / 2), c2 = (e - r * (nbelow / 2)) * 2;
+            *reinterpret_cast<pp_f2 *>(Akk + (size_t)r * Mw + PP_PW + c2) = (pp_f2){0.0, 0.0};
+        }
+        if (t == 0) fail = 0;
+        for (int e = t; e < nlow * 128; e += 256) {                    // (tile, row, column pair)
+            const int tt = e >> 7, r = (e >> 3) & 15, c2 = (e & 7) * 2;
+            int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+            while (I * (I + 1) / 2 > tt) --I;
+            const int J = tt - I * (I + 1) / 2;
+            const pp_f2 v = *reinterpret_cast<const pp_f2 *>(Akk + (size_t)(16 * I + r) * Mw + 16 * J + c2);
+            tiles[tt * TSZ + r * LDT + c2] = v[0];
+            tiles[tt * TSZ + r * LDT + c2 + 1] = v[1];
+        }
+        __syncthreads();
+        potrf_lds<double, 1>(tiles, linv, PP_NT, PP_NT, &fail);        // (no border: `linv` is only nominally its scratch tile)
+        __syncthreads();
+        if (fail && first_fail == 0) first_fail = PP_PW * k + fail;
+        for (int e = t; e < PP_PW * PP_PW / 2; e += 256) {             // L_kk back, zeros above its diagonal
+            const int i = e >> 6, j = (e & 63) * 2;
+            pp_f2 v;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                v[u] = (j + u <= i) ? tiles[lds_tile_index(i >> 4, (j + u) >> 4, PP_NT) * TSZ + (i & 15) * LDT + ((j + u) & 15)] : 0.0;
+            *reinterpret_cast<pp_f2 *>(Akk + (size_t)i * Mw + j) = v;
+        }
+        if (k + 1 == nblk) break;
+        // ---- (b) inverted diagonal tiles: waves 0 and 1, one tile per row of 16 lanes ----
+        if (wv < 2) {
+            const int c = 4 * wv + kk;
+            tri_inverse_dpp<double>(tiles + lds_tile_index(c, c, PP_NT) * TSZ, linv + c * TSZ, LDT, lane);
+        }
+        __syncthreads();
+        // ---- (c) panel: row tiles I = wv, wv + 4, ... below the block; the next tile's rows are fetched while this one runs ----
+        {
+            const int nrt = nbelow / 16;
+            double *S = stage + (size_t)wv * 16 * PP_SLD;
+            double *Pk = A + (size_t)(PP_PW * (k + 1)) * Mw + PP_PW * k;          // first row below the block, block column k
+            pp_f2 pre[16];
+            if (wv < nrt) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const pp_f2 *>(Pk + (size_t)(16 * wv + q) * Mw + 2 * lane);
+            }
+            for (int I = wv; I < nrt; I += 4) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {                       // (LDS is only ever accessed as double: a vector-typed store
+                    S[q * PP_SLD + 2 * lane] = pre[q][0];             //  next to scalar loads of the same bytes invites
+                    S[q * PP_SLD + 2 * lane + 1] = pre[q][1];         //  type-based reordering)
+                }
+                if (I + 4 < nrt) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        pre[q] = *reinterpret_cast<const pp_f2 *>(Pk + (size_t)(16 * (I + 4) + q) * Mw + 2 * lane);
+                }
+                pp_trsm_tile(S, tiles, linv, lane);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const pp_f2 v = {S[q * PP_SLD + 2 * lane], S[q * PP_SLD + 2 * lane + 1]};
+                    *reinterpret_cast<pp_f2 *>(Pk + (size_t)(16 * I + q) * Mw + 2 * lane) = v;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();                                               // P complete in memory; the LDS tiles are free
+        // ---- (d) update: 128 x 128 blocks (I, J), J <= I, of the trailing matrix; stream of (block, chunk) steps ----
+#ifndef PP_DEBUG_NO_UPDATE
+        {
+            typedef f64x4 acc_t;
+            const int nub = nbelow / PP_PW, nblocks = nub * (nub + 1) / 2, nsteps = nblocks * (PP_PW / PP_KQ);
+            double *T = A + (size_t)(PP_PW * (k + 1)) * Mw + PP_PW * (k + 1);     // trailing matrix
+            const double *P = A + (size_t)(PP_PW * (k + 1)) * Mw + PP_PW * k;     // panel: row r at P + r * Mw, 128 columns
+            const int rt0 = wv, rt1 = PP_NT - 1 - wv;                             // this wave's two row tiles of a block
+            acc_t acc[2][PP_NT];
+            pp_f2 px[8], py[8];                                                    // this thread's share of a staged chunk pair
+            // thread -> (row, column pair) of a [128][32] chunk: 16 threads per row
+            const int srow = t >> 4, sc2 = (t & 15) * 2;
+            int bI = 0, bJ = 0;                                                    // block of the step being FETCHED
+            auto fetch = [&](int step) {
+                const int h = step & 3;
+                const double *pi = P + (size_t)(PP_PW * bI) * Mw + PP_KQ * h, *pj = P + (size_t)(PP_PW * bJ) * Mw + PP_KQ * h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) px[q] = *reinterpret_cast<const pp_f2 *>(pi + (size_t)(srow + 16 * q) * Mw + sc2);
+                if (bI != bJ) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) py[q] = *reinterpret_cast<const pp_f2 *>(pj + (size_t)(srow + 16 * q) * Mw + sc2);
+                }
+                if (h == 3) {                                                      // advance to the next block (row-major lower)
+                    if (bJ < bI) ++bJ;
+                    else { ++bI; bJ = 0; }
+                }
+            };
+            auto stash = [&](int step, bool diag) {                                // registers -> LDS buffer (step & 1): -P_I, P_J
+                double *xs = base + (size_t)(step & 1) * 2 * PP_PW * PP_KLD, *ys = xs + (size_t)PP_PW * PP_KLD;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const pp_f2 vx = px[q], vy = diag ? px[q] : py[q];
+                    double *dx = xs + (srow + 16 * q) * PP_KLD + sc2, *dy = ys + (srow + 16 * q) * PP_KLD + sc2;
+                    dx[0] = -vx[0]; dx[1] = -vx[1];
+                    dy[0] = vy[0]; dy[1] = vy[1];
+                }
+            };
+            int cI = 0, cJ = 0;                                                    // block of the step being COMPUTED
+            int fI = 0, fJ = 0;                                                    // block whose chunk sits in px / py
+            if (nsteps > 0) {
+                fI = bI; fJ = bJ;
+                fetch(0);
+                stash(0, fI == fJ);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int Jt = 0; Jt < PP_NT; ++Jt) acc[i][Jt] = (acc_t){0, 0, 0, 0};
+            for (int step = 0; step < nsteps; ++step) {
+                const int h = step & 3;
+                const bool diag = (cI == cJ);
+                if (step + 1 < nsteps) {
+                    fI = bI; fJ = bJ;
+                    fetch(step + 1);
+                }
+                double *Cb = T + (size_t)(PP_PW * cI) * Mw + PP_PW * cJ;
+                acc_t cold[2][PP_NT];
+                if (h == 3) {                                                      // the block's old values, needed after this chunk
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int rt = i ? rt1 : rt0;
+#pragma unroll
+                        for (int Jt = 0; Jt < PP_NT; ++Jt)
+                            if (!diag || Jt <= rt) {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) cold[i][Jt][v] = Cb[(size_t)(16 * rt + kk + 4 * v) * Mw + 16 * Jt + li];
+                            }
+                    }
+                }
+                const double *xs = base + (size_t)(step & 1) * 2 * PP_PW * PP_KLD, *ys = xs + (size_t)PP_PW * PP_KLD;
+#pragma unroll 2
+                for (int ks = 0; ks < PP_KQ / 4; ++ks) {
+                    const double x0 = xs[(16 * rt0 + li) * PP_KLD + 4 * ks + kk], x1 = xs[(16 * rt1 + li) * PP_KLD + 4 * ks + kk];
+#pragma unroll
+                    for (int Jt = 0; Jt < PP_NT; ++Jt) {
+                        if (diag && Jt > rt1) continue;                            // (rt0 <= rt1: nothing of this column for the wave)
+                        const double yv = ys[(16 * Jt + li) * PP_KLD + 4 * ks + kk];
+                        if (!diag || Jt <= rt0) acc[0][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, yv, acc[0][Jt], 0, 0, 0);
+                        acc[1][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, yv, acc[1][Jt], 0, 0, 0);
+                    }
+                }
+                if (h == 3) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int rt = i ? rt1 : rt0;
+#pragma unroll
+                        for (int Jt = 0; Jt < PP_NT; ++Jt) {
+                            if (!diag || Jt <= rt) {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                    Cb[(size_t)(16 * rt + kk + 4 * v) * Mw + 16 * Jt + li] = cold[i][Jt][v] + acc[i][Jt][v];
+                            }
+                            acc[i][Jt] = (acc_t){0, 0, 0, 0};
+                        }
+                    }
+                    if (cJ < cI) ++cJ;
+                    else { ++cI; cJ = 0; }
+                }
+                if (step + 1 < nsteps) stash(step + 1, fI == fJ);
+                __syncthreads();
+            }
+        }
+#endif
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (t == 0) info[b] = first_fail;
+}
+
+bool potrf_persist_applicable(int B, int M, int elem_size) { return elem_size == 8 && M > 128 && B >= 128; }
+
+int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st) {
+    const size_t lds = pp_lds_bytes();
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pbig_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return DPGP_ERR_LAUNCH;
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(pbig_persistent_kernel, dim3(B), dim3(256), lds, st, Mw, w, info);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}

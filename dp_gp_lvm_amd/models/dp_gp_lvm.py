@@ -41,7 +41,7 @@ def dp_gp_lvm(y_train,
               truncation_level=DP_DEFAULT_TRUNCATION_LEVEL,
               alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
               mask_size=1,
-              device=None, precision='mixed', process_group=None, initial_values=None, backward_precision=None,
+              device=None, precision=None, process_group=None, initial_values=None, backward_precision=None,
               psi_algo='auto', _shard_of=None):
     """
     :param y_train: [N x D] numpy array, columns normalised to zero mean / unit variance (dp_gp_lvm.py:30-32).
@@ -68,7 +68,12 @@ def dp_gp_lvm(y_train,
     assert 0 < truncation_level <= min(num_samples, num_dimensions), \
         'The truncation level must be positive and less than the dimensionality of the observed data and ' \
         'less than the number of observations.'
-    assert precision in _lib.PREC, 'precision must be one of %s' % sorted(_lib.PREC)
+    if precision is None:
+        # the default-constructed model is the one that trains like the reference (fp64 arithmetic, src/utils/types.py:13-14):
+        # fp64 forward pass and dense adjoints, the streaming stage of the backward pass on the matrix pipe.
+        # precision='mixed' (fp32 psi-statistics) is the fast scoring mode: its conditioning guard stops a long Adam run.
+        precision, backward_precision = 'f64', (backward_precision or 'mixed')
+    assert precision in ('f32', 'mixed', 'f64'), "precision must be one of 'f32', 'mixed', 'f64'"
     assert backward_precision in (None, 'mixed', 'f64'), "backward_precision must be None, 'mixed' or 'f64'"
     # stage B behind an fp64 forward pass (the training configuration): the patch form of the Psi2 term, which keeps its accuracy
     # where the adjoints cancel (include/dpgp.h, DPGP_PREC_MIXED_PATCH); behind a mixed forward pass the faster pair-tile form
@@ -534,7 +539,7 @@ def dp_gp_lvm_t(y_train,
                 alpha_prior_params=DP_DEFAULT_ALPHA_PRIOR_PARAMS,
                 mask_size=1,
                 seed=0,
-                device=None, precision='mixed', initial_values=None, _view_of_many=False, process_group=None):
+                device=None, precision=None, initial_values=None, _view_of_many=False, process_group=None):
     """
     Over-T formulation — mirror of the reference's ``dp_gp_lvm_t`` factory (src/models/dp_gp_lvm.py:513-676), SURVEY.md
     §8(f) row 3: the kernel batch is the T atoms, the mixture weights phi [T x D] enter outside the kernel, so an evaluation
@@ -565,6 +570,7 @@ def dp_gp_lvm_t(y_train,
         'The truncation level must be positive and less than or equal to the dimensionality of the observed data and ' \
         'less than or equal to the number of observations.'
     assert isinstance(seed, int) and seed >= 0, 'Seed must be a 32-bit unsigned integer, i.e., 0 <= seed <= 2^32 - 1.'
+    precision = 'f64' if precision is None else precision     # (default: the reference's arithmetic, as in dp_gp_lvm)
     assert precision in ('mixed', 'f64'), "precision must be 'mixed' or 'f64'"
     np.random.seed(seed=seed)
     device = default_device() if device is None else torch.device(device)
@@ -674,7 +680,8 @@ def dp_gp_lvm_t(y_train,
             pad2 = (0, mp_ - m_, 0, mp_ - m_)
             dmu, ds, dz, dgam = ops.elbo_grad_psi(None, x_u_, x_mean_, s_, gat, aat,
                                                   torch.nn.functional.pad(gp, pad2).contiguous(),
-                                                  torch.nn.functional.pad(wk, pad2).contiguous(), None, prec='mixed',
+                                                  torch.nn.functional.pad(wk, pad2).contiguous(), None,
+                                                  prec='mixed_patch' if precision == 'f64' else 'mixed',
                                                   g_psi1=torch.nn.functional.pad(g1, (0, mp_ - m_)).contiguous())
             s_k, s_p = wk.sum(dim=(1, 2)), (gp * p2).sum(dim=(1, 2))
             s_gbp = (gb * p2).sum(dim=(1, 2))

@@ -22,7 +22,7 @@ from .interfaces.trainable import Trainable
 
 def bayesian_gp_lvm(y_train, kernel=None, num_latent_dims=GP_LVM_DEFAULT_LATENT_DIMENSIONS,
                     num_inducing_points=GP_LVM_DEFAULT_NUM_INDUCING_POINTS, num_latent_samples=0,
-                    device=None, precision='mixed', initial_values=None):
+                    device=None, precision=None, initial_values=None):
     """
     :param y_train: [N x D] numpy array.  :param kernel: optional k_ard_rbf with batch size 1 whose hyper-parameter VALUES
     initialise the model's own trainable ones.  :param num_latent_dims: Q.  :param num_inducing_points: M (< N).
@@ -116,7 +116,7 @@ def bayesian_gp_lvm(y_train, kernel=None, num_latent_dims=GP_LVM_DEFAULT_LATENT_
 
 def manifold_relevance_determination(views_train, num_latent_dims=GP_LVM_DEFAULT_LATENT_DIMENSIONS,
                                      num_inducing_points=GP_LVM_DEFAULT_NUM_INDUCING_POINTS,
-                                     device=None, precision='mixed', initial_values=None):
+                                     device=None, precision=None, initial_values=None):
     """
     Manifold relevance determination — mirror of the reference's factory (src/models/gaussian_process.py:551-664): V views
     [N x D_v] share q(X); every view has its own B = 1 ARD-RBF kernel and its own M inducing inputs, and

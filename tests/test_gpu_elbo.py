@@ -38,7 +38,7 @@ def check_terms(terms, ref_terms, prec, what):
 @pytest.mark.parametrize('fixture', ['dpgplvm_50_10_25_3_T8', 'dpgplvm_T1_d5', 'dpgplvm_d2', 'plumbing_100_12_20_4',
                                      'script_100_20_25_10'])
 @pytest.mark.parametrize('prec', ['f64', 'mixed', 'f32'])
-@pytest.mark.parametrize('algo', ['auto', 'plain'])
+@pytest.mark.parametrize('algo', ['auto', 'plain', 'patch_f16'])
 def test_fhat_terms_golden(dev, fixture, prec, algo):
     g = golden(fixture)
     if 'y' not in g:

@@ -147,6 +147,17 @@ def test_psi_statistics_outside_the_f16_range_are_poisoned_not_wrong(dev):
     np.testing.assert_allclose(terms64.cpu().numpy(), want, rtol=1e-8, atol=1e-8 * np.abs(want).max())
 
 
+def test_fp64_psi_kernels_propagate_nan(dev):
+    """NaN in gives NaN out for the fp64 streaming kernels (their table-based exp2 once clamped a NaN argument to 2^-1100 = 0;
+    ADVICE r2): the reference (TensorFlow) propagates NaN."""
+    g = golden('kernel_b7')
+    mu = np.array(g['x_mean'], dtype=np.float64, copy=True)
+    mu[3, 1] = np.nan
+    args = [T(a, torch.float64, dev) for a in (g['x_u'], mu, g['x_var'], g['gamma'], g['alpha'])]
+    p2 = ops.psi2(*args).cpu().numpy()
+    assert np.isnan(p2).any(), 'psi2 (fp64) swallowed a NaN latent mean'
+
+
 @pytest.mark.parametrize('m', [1, 7, 16, 20, 25, 64, 100, 128, 130])
 @pytest.mark.parametrize('dt', [torch.float64, torch.float32])
 @pytest.mark.parametrize('algo', ['auto', 'plain'])
