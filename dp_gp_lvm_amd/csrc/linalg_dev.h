@@ -17,6 +17,10 @@
 #define LA_LDS_HDR 128  // bytes at the start of the dynamic LDS region: 8 doubles of reduction scratch + fail flag
 #define LA_LDS_LIMIT (150 * 1024)
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its global loads and
+// stores (__syncthreads() drains both; potrf_persist.hip lets 393 KB of zero stores drain behind the LDS-resident
+// factorisation, which has eight of these per block column).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float dpgp_rsqrt(float x) { return rsqrtf(x); }
 __device__ __forceinline__ double dpgp_rsqrt(double x) { return rsqrt(x); }
 
@@ -715,7 +719,7 @@ __device__ __forceinline__ void potrf_lds(T *tiles, T *dinv, int nbf_, int nbr_,
         T *t = tiles + lds_tile_index(I, I, nbf) * TSZ;
         if (c > r) t[r * LDT + c] = t[c * LDT + r];
     }
-    __syncthreads();
+    lds_barrier();
     T g[16];                                                  // row li of the diagonal tile -> of L_kk (panel waves)
     {
         const int k = 0;
@@ -724,7 +728,7 @@ __device__ __forceinline__ void potrf_lds(T *tiles, T *dinv, int nbf_, int nbr_,
         failed = potrf_lds_panel<T>(tiles, border, nbf, nborder, 0, wv, lane, g);
         ACC_END(4);
     }
-    __syncthreads();
+    lds_barrier();
     for (int k = 0; k < nbf; ++k) {
         // L_kk goes back only now: every panel wave read the unfactored diagonal tile during the panel phase
         if (wv == 0 && kk == 0) {
@@ -740,7 +744,7 @@ __device__ __forceinline__ void potrf_lds(T *tiles, T *dinv, int nbf_, int nbr_,
             potrf_lds_update<T>(tiles, dinv, nbf, nborder, k, 0, min(wv * per, nc), min(per, max(nc - wv * per, 0)), lane);
             ACC_END(5);
         }
-        __syncthreads();
+        lds_barrier();
         // REST phase: the waves that hold rows of block column k + 1 factor it first (panel k + 1) and take LA_PANEL_CREDIT
         // items fewer of the rest of update k, which touches neither that block column nor anything the panel reads
         {
@@ -758,11 +762,11 @@ __device__ __forceinline__ void potrf_lds(T *tiles, T *dinv, int nbf_, int nbr_,
             potrf_lds_update<T>(tiles, dinv, nbf, nborder, k, 1, min(before, nr), min(mine, max(nr - before, 0)), lane);
             ACC_END(6);
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (threadIdx.x == 0 && failed && *fail == 0) *fail = failed;
     if (dinv_glob) {                       // inverted diagonal tiles for the callers that go on to L^-1 (trtri_lds / potri_lds)
-        __syncthreads();
+        lds_barrier();
         for (int k = wv; k < nbf; k += 4)
             diag_tile<T, false, true>(tiles + lds_tile_index(k, k, nbf) * TSZ, LDT, (T *)nullptr, dinv_glob + k * 256, (int *)nullptr, 0);
     }

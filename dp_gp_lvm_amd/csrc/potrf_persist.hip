@@ -27,6 +27,13 @@
 #define PP_KLD (PP_KQ + 2)        // row stride of a staged chunk [128][PP_KLD]
 
 typedef double pp_f2 __attribute__((ext_vector_type(2)));
+#ifdef PP_STAMPS              // diagnostic build (scratch/build_persist_variant.sh stamps2 -DPP_STAMPS): phase clocks of workgroup 0
+__device__ long long g_pp_stamps[64];
+extern "C" void dpgp_debug_persist_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(long long) * 64); }
+#define PP_STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_pp_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_STAMP(i)
+#endif
 
 static size_t pp_lds_bytes() {
     const size_t fact = LA_LDS_HDR + sizeof(double) * ((size_t)TSZ * (PP_NT * (PP_NT + 1) / 2 + PP_NT) + (size_t)4 * 16 * PP_SLD);
@@ -84,11 +91,9 @@ __global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__
     for (int k = 0; k < nblk; ++k) {
         double *Akk = A + (size_t)(PP_PW * k) * Mw + PP_PW * k;
         const int nbelow = Mw - PP_PW * (k + 1);                       // rows below / columns to the right of the block
-        // ---- (a) zeros to the right of the diagonal block (stores drain during the factorisation), block -> LDS tiles ----
-        for (int e = t; e < PP_PW * (nbelow / 2); e += 256) {
-            const int r = e / (nbelow / 2), c2 = (e - r * (nbelow / 2)) * 2;
-            *reinterpret_cast<pp_f2 *>(Akk + (size_t)r * Mw + PP_PW + c2) = (pp_f2){0.0, 0.0};
-        }
+        PP_STAMP(8 * k + 0);
+        // ---- (a) block -> LDS tiles; then the zeros to the right of the diagonal block: fire-and-forget stores that drain
+        //      during the factorisation (issued in front of the loads they made the loads queue behind 393 KB of stores) ----
         if (t == 0) fail = 0;
         for (int e = t; e < nlow * 128; e += 256) {                    // (tile, row, column pair)
             const int tt = e >> 7, r = (e >> 3) & 15, c2 = (e & 7) * 2;
@@ -100,9 +105,15 @@ __global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__
             tiles[tt * TSZ + r * LDT + c2] = v[0];
             tiles[tt * TSZ + r * LDT + c2 + 1] = v[1];
         }
-        __syncthreads();
+        for (int e = t; e < PP_PW * (nbelow / 2); e += 256) {
+            const int r = e / (nbelow / 2), c2 = (e - r * (nbelow / 2)) * 2;
+            *reinterpret_cast<pp_f2 *>(Akk + (size_t)r * Mw + PP_PW + c2) = (pp_f2){0.0, 0.0};
+        }
+        lds_barrier();                                                 // (not __syncthreads(): the zero stores keep draining)
+        PP_STAMP(8 * k + 1);
         potrf_lds<double, 1>(tiles, linv, PP_NT, PP_NT, &fail);        // (no border: `linv` is only nominally its scratch tile)
-        __syncthreads();
+        lds_barrier();
+        PP_STAMP(8 * k + 2);
         if (fail && first_fail == 0) first_fail = PP_PW * k + fail;
         for (int e = t; e < PP_PW * PP_PW / 2; e += 256) {             // L_kk back, zeros above its diagonal
             const int i = e >> 6, j = (e & 63) * 2;
@@ -113,12 +124,14 @@ __global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__
             *reinterpret_cast<pp_f2 *>(Akk + (size_t)i * Mw + j) = v;
         }
         if (k + 1 == nblk) break;
+        PP_STAMP(8 * k + 3);
         // ---- (b) inverted diagonal tiles: waves 0 and 1, one tile per row of 16 lanes ----
         if (wv < 2) {
             const int c = 4 * wv + kk;
             tri_inverse_dpp<double>(tiles + lds_tile_index(c, c, PP_NT) * TSZ, linv + c * TSZ, LDT, lane);
         }
         __syncthreads();
+        PP_STAMP(8 * k + 4);
         // ---- (c) panel: row tiles I = wv, wv + 4, ... below the block; the next tile's rows are fetched while this one runs ----
         {
             const int nrt = nbelow / 16;
@@ -150,6 +163,7 @@ __global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__
         }
         __threadfence_block();
         __syncthreads();                                               // P complete in memory; the LDS tiles are free
+        PP_STAMP(8 * k + 5);
         // ---- (d) update: 128 x 128 blocks (I, J), J <= I, of the trailing matrix; stream of (block, chunk) steps ----
 #ifndef PP_DEBUG_NO_UPDATE
         {
@@ -256,7 +270,9 @@ __global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__
 #endif
         __threadfence_block();
         __syncthreads();
+        PP_STAMP(8 * k + 6);
     }
+    PP_STAMP(63);
     if (t == 0) info[b] = first_fail;
 }
 

@@ -1,0 +1,21 @@
+# phase cycles of the persistent Cholesky (workgroup 0) from the stamped build: DPGP_LIBRARY=scratch/libdpgp_hip_stamps2.so
+import os, sys, ctypes
+os.environ['DPGP_POTRF_PERSISTENT'] = '1'
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dp_gp_lvm_amd import ops, _lib
+dev = torch.device('cuda', 0)
+b, m = 256, 512
+g = torch.Generator(device='cpu').manual_seed(1)
+a0 = torch.randn((b, m, m), generator=g, dtype=torch.float64).to(dev)
+spd = a0 @ a0.transpose(1, 2) + m * torch.eye(m, dtype=torch.float64, device=dev)
+for _ in range(4): l, info = ops.potrf_batched(spd)
+torch.cuda.synchronize()
+out = (ctypes.c_longlong * 64)()
+ctypes.CDLL(_lib.LIB_PATH).dpgp_debug_persist_stamps(out)
+s = list(out)
+names = ['load block + zeros', 'potrf_lds', 'L_kk write-back', 'tile inverses', 'panel (trsm)', 'update']
+for k in range(4):
+    row = [s[8 * k + i + 1] - s[8 * k + i] for i in range(6)] if k < 3 else [s[8 * k + 1] - s[8 * k], s[8 * k + 2] - s[8 * k + 1], s[63] - s[8 * k + 2]]
+    print('k %d: ' % k + ', '.join('%s %d' % (n, v) for n, v in zip(names, row)))
+print('total cycles %d' % (s[63] - s[0]))
