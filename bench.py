@@ -169,8 +169,10 @@ def git_sha():
 def profiled_traffic(cfg, prec, world):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): read from
-    profiles/r02/traffic.json, which records the build it was measured on; null when this configuration was not profiled."""
-    path = os.path.join(REPO, 'profiles', 'r02', 'traffic.json')
+    profiles/r03/traffic.json (r02 as fall-back), which records the build it was measured on; null when this configuration was not profiled."""
+    path = os.path.join(REPO, 'profiles', 'r03', 'traffic.json')
+    if not os.path.exists(path):
+        path = os.path.join(REPO, 'profiles', 'r02', 'traffic.json')
     if world != 1 or not os.path.exists(path):
         return None, None
     try:
@@ -314,15 +316,22 @@ def main():
             # the matrix pipe the kernel runs on (f16 operands, fp32 accumulate; fp64 MFMA for --prec f64).  The matrix pipe
             # is not what limits it: every exponent costs one v_exp_f32 (8 issue cycles per wave) + one accumulate, see
             # `exp_frac` (vs the v_exp_f32 rate alone) and DESIGN.md section 4.
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_rec,
-                         'kernel': 'psi2_pairs_kernel (+ K_uu task slice)' if f16_path else 'psi2_mfma_kernel (+ K_uu task slice)', 'kernel_ms': psi2_ms,
-                         'limiter': ('VALU issue: one v_exp_f32 (8 cycles) + one v_add_f32 (4) per exponent; the matrix pipe runs beneath' if f16_path else
-                                     'fp64 issue: v_mfma_f64 and fp64 VALU (table exp2) share the pipe and do not overlap'),
-                         'vs_fp32_matrix_peak': achieved / MFMA_F32_PEAK_TFLOPS,
-                         'exp_per_s': exps / (psi2_ms * 1e-3), 'exp_peak_per_s': exp_peak if f16_path else None,
-                         'exp_frac': (exps / (psi2_ms * 1e-3) / exp_peak) if f16_path else None},
+            # `bound` names the pipe that limits the kernel: for the f16-split kernels that is the vector unit's
+            # transcendental issue (one v_exp_f32 = 8 issue cycles per wave-instruction -> 256 CUs x 4 SIMDs x 64 / 8 x 2.4 GHz =
+            # 1.966e13 exp/s), so `achieved` / `peak` / `frac` are in exponentials per second; the matrix-pipe figure of the
+            # same launch (algorithmic flops / dense f16 peak) is kept under `mfma`.  --prec f64: the fp64 matrix pipe.
+            'roofline': ({'bound': 'valu-transcendental', 'achieved': exps / (psi2_ms * 1e-3) / 1e9, 'peak': exp_peak / 1e9,
+                          'unit': 'Gexp/s', 'frac': exps / (psi2_ms * 1e-3) / exp_peak,
+                          'mfma': {'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                                   'vs_fp32_matrix_peak': achieved / MFMA_F32_PEAK_TFLOPS},
+                          'limiter': 'VALU issue: one v_exp_f32 (8 cycles) + one v_add_f32 (4) per exponent; the matrix pipe runs beneath'}
+                         if f16_path else
+                         {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                          'limiter': 'fp64 issue: v_mfma_f64 and fp64 VALU (table exp2) share the pipe and do not overlap'}),
         }
+        res['roofline'].update({'traffic': traffic, 'traffic_source': traffic_rec, 'kernel_ms': psi2_ms,
+                                'kernel': 'psi2_pairs_kernel (+ K_uu task slice)' if f16_path else 'psi2_mfma_kernel (+ K_uu task slice)',
+                                'algorithmic_exps': exps, 'algorithmic_flops': flops})
         if world == 1 and not a.no_secondary:
             res['secondary'] = secondary(dev, shape, p)
         if world == 1 and not a.no_side and a.prec == 'mixed':

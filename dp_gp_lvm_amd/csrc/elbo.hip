@@ -5,8 +5,8 @@
 //   3. Psi1_d^T y_d partial slabs                             (psi1T_y_f16_kernel)
 //   4. Psi2_d partial slabs on the matrix cores, with the K_uu branch (chol(K_uu), log-det, K_uu^-1: D latency-bound
 //      workgroups) as an extra task slice of the SAME dispatch  (psi2_f16_kernel + chain_k_body)
-//   5. B = K + beta Psi2, bordered Cholesky, f_hat terms      (chain_b_kernel)
-//   6. f_hat = sum of terms, KL = sum of partials [+ model-level tail]  (sum_terms_kernel)
+//   5. B = K + beta Psi2, bordered Cholesky, f_hat terms; in the workgroup that finishes last: f_hat = sum of terms,
+//      KL = sum of partials [+ model-level tail]                (chain_b_kernel)
 #include "internal.h"
 #include "psi2_consts.h"
 
@@ -25,7 +25,7 @@ static ElboLayout elbo_layout(int D, int N, int M, int Q, int prec) {
     L.off_yy = o; o += dpgp_align256(sizeof(double) * DPGP_YY_NCH * D);
     L.off_ld = o; o += dpgp_align256(sizeof(double) * D);
     L.off_ik = o; o += dpgp_align256(sizeof(int) * D);
-    L.off_kl = o; o += dpgp_align256(sizeof(double) * DPGP_KL_NBLK);
+    L.off_kl = o; o += dpgp_align256(sizeof(double) * DPGP_KL_NBLK + sizeof(int));   // + chain_b's arrival counter
     L.off_guard = o; o += dpgp_align256(sizeof(double) * D);
     L.off_pc = o; o += dpgp_align256(psi2_consts_bytes(M, Q));
     L.off_sc = o; o += (prec == DPGP_PREC_F64) ? 0 : psi2_pairs_scale_bytes(D, M);
@@ -93,12 +93,12 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
                                               pairs_psi2 ? 2 : 1, pscale)))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
-    if ((rc = launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
-                                     reinterpret_cast<double *>(ws + L.off_guard), la, algo, st)))
-        return rc;
-    // f_hat and KL; with the model-level pointers of exec also the packed pair / the finished objective, in the same launch
-    return launch_sum_terms(D, terms, klp, sums, ex ? (const double *)ex->model_scal : nullptr,
-                            ex ? (double *)ex->model_pack : nullptr, ex ? (double *)ex->model_out : nullptr, st);
+    // ... and, in the workgroup that finishes last, f_hat and KL; with the model-level pointers of exec also the packed pair /
+    // the finished objective (round 2: a launch of its own, sum_terms_kernel)
+    return launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
+                                  reinterpret_cast<double *>(ws + L.off_guard), la, algo, st, klp, sums,
+                                  ex ? (const double *)ex->model_scal : nullptr, ex ? (double *)ex->model_pack : nullptr,
+                                  ex ? (double *)ex->model_out : nullptr);
 }
 
 // Backward pass, stage A (grad.hip): adjoints of the per-output dense algebra from the workspace of a finished forward

@@ -540,6 +540,8 @@ __device__ __forceinline__ void kl_yy_block(int blk, int N, int Q, const TIN *__
         }
         const double a = block_sum(a0, &scratch[0][0]);
         if (t == 0) kl_out[blk] = 0.5 * a;     // sum over blocks = 1/2 (sum mu^2 + sum (s - log s) - N Q)
+        // the arrival counter of chain_b_kernel's final reduction (linalg.hip) sits behind the partials: reset per evaluation
+        if (t == 0 && blk == 0) *reinterpret_cast<int *>(kl_out + DPGP_KL_NBLK) = 0;
         return;
     }
     const int bid = blk - DPGP_KL_NBLK, dblk = bid / YY_NCH, ch = bid - dblk * YY_NCH;

@@ -61,7 +61,11 @@ int launch_chain_k(int D, int M, TL *ws, double *logdet_k, int *info_k, int algo
 template <typename TP, typename TL>
 int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1,
                    const double *alpha, const double *beta, const double *yy_part, const double *logdet_k,
-                   const int *info_k, double *terms, int *info, double *guard, TL *ws, int algo, hipStream_t st);
+                   const int *info_k, double *terms, int *info, double *guard, TL *ws, int algo, hipStream_t st,
+                   const double *kl_part = nullptr, double *sums = nullptr, const double *model_scal = nullptr,
+                   double *model_pack = nullptr, double *model_out = nullptr);
+// sums != nullptr: the workgroup that finishes last also runs the reduction of launch_sum_terms (same arguments; the arrival
+// counter is the int behind kl_part[DPGP_KL_NBLK], zeroed by launch_elbo_front / launch_kl_yy on the same stream)
 // sums[0] = sum of terms (f_hat); sums[1] = KL from the DPGP_KL_NBLK partials (kl_part may be null: sums[1] untouched)
 //   model_scal (optional, see dpgp_model_prepare): also pack[0..1] = {f_hat, this GPU's DP-objective share} and, if out is
 //   given, out[0..4] = {objective, f_hat, KL, DP objective, hyper-prior} (single-GPU finalisation) in the same launch

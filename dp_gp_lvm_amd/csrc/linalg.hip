@@ -54,6 +54,40 @@ __global__ __launch_bounds__(256) void chain_k_kernel(int M, int Mp, TL *__restr
     chain_k_body<TL, 1>(blockIdx.x, M, Mp, ws, ws_stride, logdet_k, info_k, plain, smem_raw);
 }
 
+// f_hat = sum of the per-output terms, KL from its partials, the model-level tail: one 256-thread workgroup, fixed order.
+__device__ __forceinline__ void sum_terms_body(int D, const double *terms, const double *kl_part, double *sums,
+                                               const double *model_scal, double *model_pack, double *model_out, double *scratch) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < D * 5; i += 256) a += terms[i];
+    a = block_sum(a, scratch);
+    if (threadIdx.x == 0) {
+        sums[0] = a;
+        double kl = sums[1];
+        if (kl_part) {
+            kl = 0.0;
+            for (int i = 0; i < DPGP_KL_NBLK; ++i) kl += kl_part[i];
+            sums[1] = kl;
+        }
+        if (model_scal) {    // dp_gp_lvm.py:151-154 (see dpgp_model_pack / dpgp_model_finalize)
+            double dp = model_scal[0];
+            const int nrb = (D + DPGP_PREP_ROWS - 1) / DPGP_PREP_ROWS;
+            for (int i = 0; i < nrb; ++i) dp += model_scal[2 + i];
+            dp = -dp;
+            if (model_pack) {
+                model_pack[0] = a;
+                model_pack[1] = dp;
+            }
+            if (model_out) {
+                const double hyper = model_scal[1];
+                model_out[0] = dp - (a - kl) - hyper;
+                model_out[1] = a;
+                model_out[2] = kl;
+                model_out[3] = dp;
+                model_out[4] = hyper;
+            }
+        }
+    }
+}
 // ---- chain_b: everything after Psi2 (dp_gp_lvm.py:118-145 in the B = K + beta Psi2 form) -----------------------------
 // mode 0: B lives in LDS (potrf_lds); mode 1: B in global memory (Wb), blocked MFMA; mode 2: plain VALU cross-check.
 // OCC = 2: bounded to 256 VGPRs so that two workgroups share a compute unit (D = 512: one round instead of two, 135 -> 71 us);
@@ -69,7 +103,9 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
                                                       const double *__restrict__ logdet_k,
                                                       const int *__restrict__ info_k, double *__restrict__ terms,
                                                       int *__restrict__ info, double *__restrict__ guard,
-                                                      TL *__restrict__ ws, size_t ws_stride, int mode) {
+                                                      TL *__restrict__ ws, size_t ws_stride, int mode,
+                                                      const double *kl_part, double *sums, const double *model_scal,
+                                                      double *model_pack, double *model_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *scratch = reinterpret_cast<double *>(smem_raw);
     int &fail = *reinterpret_cast<int *>(smem_raw + 64);
@@ -214,6 +250,23 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
         o[3] = -0.5 * b_ * yy;
         o[4] = f ? nan_ : 0.5 * b_ * b_ * cc;
     }
+    // ---- the final reduction, by the workgroup that finishes last (sums != nullptr: the fused ELBO; round 2 launched
+    // sum_terms_kernel for it: 5-7 us of launch + latency on the critical path of every evaluation).  The counter sits behind
+    // the KL partials and is zeroed by the front launch; the sum runs in the fixed order of sum_terms_body either way, so the
+    // result does not depend on which workgroup is last. ----
+    if (sums) {
+        int *counter = reinterpret_cast<int *>(const_cast<double *>(kl_part) + DPGP_KL_NBLK);
+        int &last = *reinterpret_cast<int *>(smem_raw + 68);
+        if (t == 0) {
+            __threadfence();                                   // this workgroup's terms / info are visible device-wide
+            last = (atomicAdd(counter, 1) == D - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (last) {
+            __threadfence();                                   // (acquire: the other workgroups' terms, not this CU's stale L1 lines)
+            sum_terms_body(D, terms, kl_part, sums, model_scal, model_pack, model_out, scratch);
+        }
+    }
 }
 
 static size_t chain_b_lds_bytes(int Mp, size_t elem) {   // LDS-resident B: dinv + lower triangle + border row
@@ -241,7 +294,8 @@ template int launch_chain_k<double>(int, int, double *, double *, int *, int, hi
 template <typename TP, typename TL>
 int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1,
                    const double *alpha, const double *beta, const double *yy_part, const double *logdet_k,
-                   const int *info_k, double *terms, int *info, double *guard, TL *ws, int algo, hipStream_t st) {
+                   const int *info_k, double *terms, int *info, double *guard, TL *ws, int algo, hipStream_t st,
+                   const double *kl_part, double *sums, const double *model_scal, double *model_pack, double *model_out) {
     const int Mp = dpgp_round_up(M, 16);
     int mode = 2;
     size_t lds = la_lds_bytes(Mp, sizeof(TL));
@@ -257,7 +311,8 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
             hipSuccess)
         return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(D), dim3(256), lds, st, D, N, M, Mp, psi2_part, ns2, v_part, ns1, alpha, beta, yy_part,
-                       logdet_k, info_k, terms, info, guard, ws, la_chain_ws_elems(M), mode);
+                       logdet_k, info_k, terms, info, guard, ws, la_chain_ws_elems(M), mode, kl_part, sums, model_scal, model_pack,
+                       model_out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -274,7 +329,8 @@ extern "C" int dpgp_debug_chain_b_occupancy(int Mp, int extra) {
 #define INST_CHAIN_B(TP, TL)                                                                                        \
     template int launch_chain_b<TP, TL>(int, int, int, const TP *, int, const double *, int, const double *,      \
                                         const double *, const double *, const double *, const int *, double *, int *, \
-                                        double *, TL *, int, hipStream_t);
+                                        double *, TL *, int, hipStream_t, const double *, double *, const double *, double *, \
+                                        double *);
 INST_CHAIN_B(float, float)
 INST_CHAIN_B(float, double)
 INST_CHAIN_B(double, double)
@@ -286,36 +342,7 @@ __global__ __launch_bounds__(256) void sum_terms_kernel(int D, const double *__r
                                                         double *__restrict__ model_pack,
                                                         double *__restrict__ model_out) {
     __shared__ double scratch[8];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < D * 5; i += 256) a += terms[i];
-    a = block_sum(a, scratch);
-    if (threadIdx.x == 0) {
-        sums[0] = a;
-        double kl = sums[1];
-        if (kl_part) {
-            kl = 0.0;
-            for (int i = 0; i < DPGP_KL_NBLK; ++i) kl += kl_part[i];
-            sums[1] = kl;
-        }
-        if (model_scal) {    // dp_gp_lvm.py:151-154 (see dpgp_model_pack / dpgp_model_finalize)
-            double dp = model_scal[0];
-            const int nrb = (D + DPGP_PREP_ROWS - 1) / DPGP_PREP_ROWS;
-            for (int i = 0; i < nrb; ++i) dp += model_scal[2 + i];
-            dp = -dp;
-            if (model_pack) {
-                model_pack[0] = a;
-                model_pack[1] = dp;
-            }
-            if (model_out) {
-                const double hyper = model_scal[1];
-                model_out[0] = dp - (a - kl) - hyper;
-                model_out[1] = a;
-                model_out[2] = kl;
-                model_out[3] = dp;
-                model_out[4] = hyper;
-            }
-        }
-    }
+    sum_terms_body(D, terms, kl_part, sums, model_scal, model_pack, model_out, scratch);
 }
 int launch_sum_terms(int D, const double *terms, const double *kl_part, double *sums, const double *model_scal,
                      double *model_pack, double *model_out, hipStream_t st) {
