@@ -4,7 +4,7 @@ assertions and accessors; ``.objective`` is evaluated by the HIP library (libdpg
 
     dpgp_model_prepare  ->  dpgp_elbo_fhat  ->  [one packed all-reduce when D is sharded]  ->  dpgp_model_finalize
 
-i.e. eight kernel launches and at most one collective per evaluation, with no host arithmetic in between.
+i.e. five kernel launches and at most one collective per evaluation, with no host arithmetic in between.
 Where the reference returns lazy TensorFlow nodes, accessors here return torch tensors computed from the current
 parameter values, and ``objective`` re-evaluates on every access.
 
@@ -182,7 +182,7 @@ def dp_gp_lvm(y_train,
     graph_state = {}
 
     def _evaluate_graph(out=None):
-        """evaluate() replayed from a HIP graph (captured on first use): one hipGraphLaunch instead of eight kernel launches
+        """evaluate() replayed from a HIP graph (captured on first use): one hipGraphLaunch instead of five kernel launches
         and their argument marshalling on the host — at small per-GPU shares (D / 8 output dims) the host side of the eager
         path is as long as the kernels.  The graph reads the raw variables in place, so optimiser updates are seen.  With a
         process group the graph holds this rank's part (prepare ... pack); the 2-scalar all-reduce and the finalising kernel
