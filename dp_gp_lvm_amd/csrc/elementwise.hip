@@ -1,5 +1,6 @@
 // ARD-RBF gram / diag / psi0 / psi1 / Psi1^T y / KL kernels (HBM- or exp-bound, no matrix cores needed).
 // Reference semantics: /root/reference/src/kernels/rbf_kernel.py:58-161, src/models/expressions/gp_expressions.py:10-24.
+#include <cstdlib>
 #include "internal.h"
 #include "psi2_consts.h"
 
@@ -16,15 +17,22 @@ __device__ __forceinline__ void gram_tile(int b, int i0, int j0, int N0, int N1,
                                           const TIN *__restrict__ alpha, const TIN *__restrict__ beta, int flags, T jitter,
                                           T *__restrict__ out, int ld_out, size_t batch_stride, int symmetric,
                                           unsigned char *smem_raw) {
-    T *xs = reinterpret_cast<T *>(smem_raw);          // [64][Q+1]
-    T *zs = xs + GRAM_T * (Q + 1);                     // [64][Q+1]
+    // both input tiles in LDS, pre-scaled by sqrt(gamma_b), TRANSPOSED: [Q][64], so that a thread's four rows / columns of
+    // one latent dim are ONE 16-byte (fp32) read instead of four 4-byte ones (round 2: [64][Q + 1], eight ds_read_b32 per 32
+    // vector instructions — the LDS pipe, not the vector unit or HBM, held the 1 GB gram at 4.1 TB/s)
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    T *xs = reinterpret_cast<T *>(smem_raw);          // [Q][64]
+    T *zs = xs + GRAM_T * Q;                           // [Q][64]
     const int t = threadIdx.x;
     const TIN *g = gamma + (size_t)b * Q;
-    for (int e = t; e < GRAM_T * Q; e += 256) {
-        int r = e / Q, q = e - r * Q;
-        T sg = sqrt((T)g[q]);
-        xs[r * (Q + 1) + q] = (i0 + r < N0) ? sg * (T)x0[(size_t)(i0 + r) * Q + q] : (T)0;
-        zs[r * (Q + 1) + q] = (j0 + r < N1) ? sg * (T)x1[(size_t)(j0 + r) * Q + q] : (T)0;
+    {   // fill: thread = (point r = t & 63, latent dims q = t >> 6, + 4, ...): no division, one square root per (thread, q)
+        const int r = t & 63;
+        const bool in0 = i0 + r < N0, in1 = j0 + r < N1;
+        for (int q = t >> 6; q < Q; q += 4) {
+            const T sg = sqrt((T)g[q]);
+            xs[q * GRAM_T + r] = in0 ? sg * (T)x0[(size_t)(i0 + r) * Q + q] : (T)0;
+            zs[q * GRAM_T + r] = in1 ? sg * (T)x1[(size_t)(j0 + r) * Q + q] : (T)0;
+        }
     }
     __syncthreads();
     const int ty = t >> 4, tx = t & 15;
@@ -34,11 +42,8 @@ __device__ __forceinline__ void gram_tile(int b, int i0, int j0, int N0, int N1,
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0;
     for (int q = 0; q < Q; ++q) {
-        T a[4], c_[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = xs[(ty * 4 + r) * (Q + 1) + q];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) c_[c] = zs[(tx * 4 + c) * (Q + 1) + q];
+        const vec4 a = *reinterpret_cast<const vec4 *>(xs + q * GRAM_T + ty * 4);
+        const vec4 c_ = *reinterpret_cast<const vec4 *>(zs + q * GRAM_T + tx * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -49,7 +54,7 @@ __device__ __forceinline__ void gram_tile(int b, int i0, int j0, int N0, int N1,
     }
     const T al = (T)alpha[b];
     T diag_add = 0;
-    if (symmetric) {
+    if (symmetric & 1) {
         if (flags & DPGP_FLAG_NOISE) diag_add += (T)1 / (T)beta[b];
         if (flags & DPGP_FLAG_JITTER) diag_add += jitter;
     }
@@ -64,14 +69,14 @@ __device__ __forceinline__ void gram_tile(int b, int i0, int j0, int N0, int N1,
         for (int c = 0; c < 4; ++c) {
             int j = j0 + tx * 4 + c;
             v[c] = al * dpgp_exp2(scale * acc[r][c]);
-            if (symmetric && i == j) v[c] += diag_add;
+            if ((symmetric & 1) && i == j) v[c] += diag_add;
         }
         int j = j0 + tx * 4;
         T *p = ob + (size_t)i * ld_out + j;
         if (j + 3 < N1 && ((ld_out & 3) == 0)) {
-            typedef T vec4 __attribute__((ext_vector_type(4)));
             vec4 vv = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<vec4 *>(p) = vv;
+            if (symmetric & 2) __builtin_nontemporal_store(vv, reinterpret_cast<vec4 *>(p));   // (bit 1: the output is not re-read soon)
+            else *reinterpret_cast<vec4 *>(p) = vv;
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -93,10 +98,13 @@ __global__ __launch_bounds__(256) void gram_kernel(int N0, int N1, int Q, const 
 template <typename TIN, typename T>
 int launch_gram(int B, int N0, int N1, int Q, const TIN *x0, const TIN *x1, const TIN *gamma, const TIN *alpha,
                 const TIN *beta, int flags, double jitter, T *out, int ld_out, size_t batch_stride, hipStream_t st) {
-    const int sym = (x1 == nullptr);
+    int sym = (x1 == nullptr) ? 1 : 0;
     if (sym) { x1 = x0; N1 = N0; }
+    // outputs beyond the L2 + MALL working set are streamed with non-temporal stores (DPGP_GRAM_NT=0 / 1 overrides: profiling)
+    const char *nt_ = getenv("DPGP_GRAM_NT");
+    if (nt_ ? nt_[0] == '1' : (size_t)B * N0 * N1 * sizeof(T) > ((size_t)256 << 20)) sym |= 2;
     dim3 grid(dpgp_ceil_div(N1, GRAM_T), dpgp_ceil_div(N0, GRAM_T), B);
-    size_t lds = sizeof(T) * 2 * GRAM_T * (Q + 1);
+    size_t lds = sizeof(T) * 2 * GRAM_T * Q;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((gram_kernel<TIN, T>), grid, dim3(256), lds, st, N0, N1, Q, x0, x1, gamma, alpha, beta, flags,
                        (T)jitter, out, ld_out, batch_stride, sym);
     DPGP_LAUNCH_CHECK();
