@@ -8,12 +8,13 @@ def P(*a):
     s = ' '.join(str(x) for x in a); print(s); out.write(s + '\n')
 dur = {}
 for tag in ('trace_c3', 'trace_c2', 'trace_c4', 'trace_c5', 'trace_c3_f64', 'trace_linalg'):
-    for f in glob.glob(O + '/' + tag + '/*/*kernel_stats.csv'):
+    for f in glob.glob(O + '/' + tag + '/*/*kernel_stats.csv') + glob.glob(O + '/' + tag + '_kernel_stats.csv'):
         P('==', tag, '(rocprofv3 --kernel-trace --stats)')
         for r in list(csv.DictReader(open(f)))[:12]:
             P('  %-70s calls %4s avg %10.1f us  %6s%%' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
             dur[(tag, r['Name'].split('(')[0][:60])] = float(r['AverageNs']) / 1e3
-        os.replace(f, os.path.join(O, tag + '_kernel_stats.csv'))
+        if os.path.abspath(f) != os.path.abspath(os.path.join(O, tag + '_kernel_stats.csv')):
+            os.replace(f, os.path.join(O, tag + '_kernel_stats.csv'))
 def agg_pmc(tag, want):
     res = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(O + '/' + tag + '/*/*counter_collection.csv'):
