@@ -120,18 +120,18 @@ def secondary(dev, shape, p):
     out = {}
 
     def timed(fn, reps, setup=None):
+        """ms per call: events around `reps` back-to-back calls (the queue stays full, so this is device time, not the
+        host-side cost of one operator call — round 2 timed single calls and reported the 0.2 ms gram kernel as 0.33 ms)."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tot = 0.0
-        for i in range(reps + 2):
-            if setup:
-                setup()
-            e0.record()
+        for _ in range(2):
             fn()
-            e1.record()
-            e1.synchronize()
-            if i >= 2:
-                tot += e0.elapsed_time(e1)
-        return tot / reps
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
 
     t64 = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev)
     z, g, al, be = t64(p['z']), t64(p['gamma']), t64(p['alpha']), t64(p['beta'])
@@ -155,6 +155,18 @@ def secondary(dev, shape, p):
         fl = bb * mm ** 3 / 3.0
         out[key] = {'kernel_ms': ms, 'flops': fl, 'tflops': fl / ms / 1e9, 'peak_tflops': 78.6, 'frac': fl / ms / 1e9 / 78.6,
                     'what': 'dpgp_potrf_batched_f64 B=%d M=%d (M^3/3 flops each), copy of the input subtracted' % (bb, mm)}
+    # counter-derived figures of the same workloads (scratch/prof_r03.sh: WRITE_SIZE / FETCH_SIZE in separate --pmc passes,
+    # SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops, kernel-trace durations), committed with the build they were taken on
+    try:
+        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03', 'linalg_pmc.json')))
+        sha = open(os.path.join(REPO, 'profiles', 'r03', 'GIT_SHA_OF_PROFILED_BUILD.txt')).read().strip()
+        pick = lambda k: {a: b for a, b in pmc[k].items() if a != 'counters'} if k in pmc else None
+        out['rocprof'] = {'source': 'profiles/r03/linalg_pmc.json @ ' + sha,
+                          'gram_kuu': pick('void gram_kernel<double, double>'), 'gram_large': pick('void gram_kernel<float, float>'),
+                          'cholesky_m128_b512': pick('void potrf_batched_lds_kernel<double>'),
+                          'cholesky_m512_b256': pick('pbig_persistent_kernel')}
+    except (OSError, ValueError, KeyError):
+        pass
     return out
 
 

@@ -55,10 +55,12 @@ __global__ __launch_bounds__(256) void chain_k_kernel(int M, int Mp, TL *__restr
 }
 
 // f_hat = sum of the per-output terms, KL from its partials, the model-level tail: one 256-thread workgroup, fixed order.
+template <bool COHERENT = false>    // COHERENT: the terms were written by other workgroups of the SAME launch (agent-scope loads)
 __device__ __forceinline__ void sum_terms_body(int D, const double *terms, const double *kl_part, double *sums,
                                                const double *model_scal, double *model_pack, double *model_out, double *scratch) {
     double a = 0.0;
-    for (int i = threadIdx.x; i < D * 5; i += 256) a += terms[i];
+    for (int i = threadIdx.x; i < D * 5; i += 256)
+        a += COHERENT ? __hip_atomic_load(terms + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : terms[i];
     a = block_sum(a, scratch);
     if (threadIdx.x == 0) {
         sums[0] = a;
@@ -244,11 +246,15 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
         info[d] = f;
         if (flagged_only) f = 0;                               // the terms below stay numbers
         const double nan_ = __longlong_as_double(0x7ff8000000000000LL);
-        o[0] = 0.5 * N * (log(b_) - DPGP_LOG_2PI);
-        o[1] = f ? nan_ : -(ld - logdet_k[d]);                 // -sum log diag L_A
-        o[2] = f ? nan_ : 0.5 * b_ * (ip - a_ * N);            // tr(L^-1 Psi2 L^-T) = <K^-1, Psi2>
-        o[3] = -0.5 * b_ * yy;
-        o[4] = f ? nan_ : 0.5 * b_ * b_ * cc;
+        const double o_[5] = {0.5 * N * (log(b_) - DPGP_LOG_2PI),
+                              f ? nan_ : -(ld - logdet_k[d]),                 // -sum log diag L_A
+                              f ? nan_ : 0.5 * b_ * (ip - a_ * N),            // tr(L^-1 Psi2 L^-T) = <K^-1, Psi2>
+                              -0.5 * b_ * yy,
+                              f ? nan_ : 0.5 * b_ * b_ * cc};
+        // agent-scope (sc1) stores: the workgroup that finishes last — possibly on another XCD, whose L2 is not coherent with
+        // this one's — reads them with agent-scope loads; a full release fence (L2 write-back) per workgroup cost 4-11 us
+#pragma unroll
+        for (int i = 0; i < 5; ++i) __hip_atomic_store(o + i, o_[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- the final reduction, by the workgroup that finishes last (sums != nullptr: the fused ELBO; round 2 launched
     // sum_terms_kernel for it: 5-7 us of launch + latency on the critical path of every evaluation).  The counter sits behind
@@ -258,14 +264,11 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
         int *counter = reinterpret_cast<int *>(const_cast<double *>(kl_part) + DPGP_KL_NBLK);
         int &last = *reinterpret_cast<int *>(smem_raw + 68);
         if (t == 0) {
-            __threadfence();                                   // this workgroup's terms / info are visible device-wide
-            last = (atomicAdd(counter, 1) == D - 1) ? 1 : 0;
+            __builtin_amdgcn_s_waitcnt(0);                     // the sc1 stores of the terms above have been acknowledged
+            last = (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == D - 1) ? 1 : 0;
         }
         __syncthreads();
-        if (last) {
-            __threadfence();                                   // (acquire: the other workgroups' terms, not this CU's stale L1 lines)
-            sum_terms_body(D, terms, kl_part, sums, model_scal, model_pack, model_out, scratch);
-        }
+        if (last) sum_terms_body<true>(D, terms, kl_part, sums, model_scal, model_pack, model_out, scratch);
     }
 }
 
