@@ -40,6 +40,8 @@ SIGNATURES = {
                                    _vp, _vp, _vp]),
     'dpgp_event_create': (_vp, []),
     'dpgp_event_destroy': (None, [_vp]),
+    'dpgp_stream_create': (_vp, []),
+    'dpgp_stream_destroy': (None, [_vp]),
     'dpgp_event_elapsed_ms': (ctypes.c_float, [_vp, _vp]),
     'dpgp_model_prepare': (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
@@ -67,7 +69,7 @@ for _t in ('f32', 'f64'):
 class ExecResources(ctypes.Structure):
     """dpgp_exec_t of include/dpgp.h: optional psi2 timing events and model-level tail pointers."""
     _fields_ = [('ev_psi2_begin', _vp), ('ev_psi2_end', _vp), ('model_scal', _vp), ('model_pack', _vp),
-                ('model_out', _vp)]
+                ('model_out', _vp), ('stream_aux', _vp), ('ev_fork', _vp), ('ev_join', _vp)]
 
 
 _lib = None

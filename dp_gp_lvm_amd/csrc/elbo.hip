@@ -77,8 +77,16 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     if ((rc = launch_elbo_front<TL>(N, Q, mu, s, klp, D, y, ldy, yy, z, M, pconst, gamma, alpha, beta, jitter, la, L.Mp,
                                     la_chain_ws_elems(M), pairs_psi2 ? pscale : nullptr, st)))
         return rc;
-    if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1, st)))
+    // Psi1^T y needs only the front launch and feeds only the chain: with a second stream in `exec` it runs beside the psi2
+    // launch instead of in front of it (12 us of the per-GPU share at D = 64)
+    hipStream_t aux = (ex && ex->stream_aux && ex->ev_fork && ex->ev_join) ? (hipStream_t)ex->stream_aux : nullptr;
+    if (aux) {
+        if (hipEventRecord((hipEvent_t)ex->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)ex->ev_fork, 0) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
+    }
+    if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1, aux ? aux : st)))
         return rc;
+    if (aux && hipEventRecord((hipEvent_t)ex->ev_join, aux) != hipSuccess) return DPGP_ERR_LAUNCH;
     // the K_uu branch rides in the psi2 dispatch when it is LDS-resident (or the exact-MFMA psi2 kernel runs, which carries
     // both forms); otherwise it is a launch of its own ahead of psi2
     const bool f16_psi2 = (sizeof(TP) == 4 && algo != DPGP_ALGO_MFMA_F32);
@@ -93,6 +101,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
                                               pairs_psi2 ? 2 : 1, pscale)))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
+    if (aux && hipStreamWaitEvent(st, (hipEvent_t)ex->ev_join, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
     // ... and, in the workgroup that finishes last, f_hat and KL; with the model-level pointers of exec also the packed pair /
     // the finished objective (round 2: a launch of its own, sum_terms_kernel)
     return launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
@@ -281,6 +290,13 @@ extern "C" void *dpgp_event_create(void) {
 extern "C" void dpgp_event_destroy(void *e) {
     if (e) (void)hipEventDestroy((hipEvent_t)e);
 }
+extern "C" void *dpgp_stream_create(void) {
+    hipStream_t s = nullptr;
+    return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? (void *)s : nullptr;
+}
+extern "C" void dpgp_stream_destroy(void *s) {
+    if (s) (void)hipStreamDestroy((hipStream_t)s);
+}
 extern "C" float dpgp_event_elapsed_ms(void *a, void *b) {
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.0f;
@@ -334,18 +350,34 @@ __global__ __launch_bounds__(256) void model_prepare_kernel(
             hyper += -lx - 0.5 * (DPGP_LOG_2PI + lx * lx);        // log_normal.log_pdf (log_normal.py:34-39)
         }
         const double w1 = softplus_d(w_raw[0]), w2 = softplus_d(w_raw[1]);
+        // The special functions of the stick parameters, ONE per thread (thread = (stick k, function f)): the fp64 lgamma /
+        // digamma of the device library are hundreds of instructions each; six of them back to back on the threads k < T - 1
+        // (plus three more on thread 0) were 10 of this launch's 16 us — the whole evaluation waits for this block.
+        __shared__ double sf[6][PREP_MAX_T], sx[3];
+        for (int i = t; i < 6 * (T - 1) + 3; i += 256) {
+            if (i < 6 * (T - 1)) {
+                const int k = i / 6, f = i - 6 * k;
+                const double g1 = softplus_d(g1_raw[k]), g2 = softplus_d(g2_raw[k]);
+                const double x = (f % 3 == 0) ? g1 : ((f % 3 == 1) ? g2 : g1 + g2);
+                sf[f][k] = f < 3 ? lgamma(x) : digamma_d(x);
+            } else {
+                const int f = i - 6 * (T - 1);
+                sx[f] = f == 0 ? digamma_d(w1) : (f == 1 ? lgamma(s1) : lgamma(w1));
+            }
+        }
+        __syncthreads();
         if (t < T - 1) {
             const double g1 = softplus_d(g1_raw[t]), g2 = softplus_d(g2_raw[t]);
-            const double p1 = digamma_d(g1), p2 = digamma_d(g2), p12 = digamma_d(g1 + g2);
+            const double p1 = sf[3][t], p2 = sf[4][t], p12 = sf[5][t];
             // per stick t: part of E[log p(V|alpha)] and the Beta entropy
             consts += (w1 / w2 - 1.0) * (p2 - p12) +
-                      (lgamma(g1) + lgamma(g2) - lgamma(g1 + g2) - (g1 - 1.0) * p1 - (g2 - 1.0) * p2 + (g1 + g2 - 2.0) * p12);
+                      (sf[0][t] + sf[1][t] - sf[2][t] - (g1 - 1.0) * p1 - (g2 - 1.0) * p2 + (g1 + g2 - 2.0) * p12);
         }
         if (t == 0) {
-            const double pw = digamma_d(w1), lw2 = log(w2);
+            const double pw = sx[0], lw2 = log(w2);
             consts += (T - 1.0) * (pw - lw2)                                                   // rest of E[log p(V|alpha)]
-                      + s1 * log(s2) - lgamma(s1) + (s1 - 1.0) * (pw - lw2) - s2 * (w1 / w2)   // E[log p(alpha)]
-                      + w1 - lw2 + lgamma(w1) + (1.0 - w1) * pw;                               // Gamma entropy
+                      + s1 * log(s2) - sx[1] + (s1 - 1.0) * (pw - lw2) - s2 * (w1 / w2)        // E[log p(alpha)]
+                      + w1 - lw2 + sx[2] + (1.0 - w1) * pw;                                     // Gamma entropy
         }
         hyper = block_sum(hyper, scratch);
         consts = block_sum(consts, scratch);

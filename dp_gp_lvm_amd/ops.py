@@ -237,6 +237,13 @@ class ElboWorkspace:
         self.sums = torch.full((2,), float('nan'), dtype=torch.float64, device=device)
         self.info = torch.zeros(d, dtype=torch.int32, device=device)
         self.exec = _lib.ExecResources()
+        # second stream + fork / join events: Psi1^T y beside the psi2 launch (include/dpgp.h, dpgp_exec_t.stream_aux).
+        # Opt-in (DPGP_PARALLEL_BRANCH=1): measured on MI355X it is SLOWER than one stream — config 2: 0.263 vs 0.253 ms per
+        # evaluation, config 3: 1.371 vs 1.298, replayed from a HIP graph 0.345 — the two event hand-offs cost more than the
+        # 12 us (D = 64) the branch could hide, and the psi2 launch fills the chip on its own.
+        import os
+        if os.environ.get('DPGP_PARALLEL_BRANCH', '0') == '1':
+            self.exec.stream_aux, self.exec.ev_fork, self.exec.ev_join = l.dpgp_stream_create(), l.dpgp_event_create(), l.dpgp_event_create()
         import ctypes
         lay = (ctypes.c_size_t * 10)()
         _lib.check(l.dpgp_elbo_workspace_layout(d, n, m, q, _lib.PREC[prec], ctypes.cast(lay, ctypes.c_void_p)),
@@ -245,6 +252,18 @@ class ElboWorkspace:
         # guard[d]: bound on what the rounding of an fp32 Psi2 can do to output dim d's terms (include/dpgp.h,
         # DPGP_INFO_ILL_CONDITIONED); a view into the workspace, valid after an evaluation
         self.guard = self.ws[self.layout[8]:self.layout[8] + 8 * d].view(torch.float64)
+
+
+    def __del__(self):
+        try:
+            l = _lib.lib()
+            if self.exec.stream_aux:
+                l.dpgp_stream_destroy(self.exec.stream_aux)
+                l.dpgp_event_destroy(self.exec.ev_fork)
+                l.dpgp_event_destroy(self.exec.ev_join)
+                self.exec.stream_aux = None
+        except Exception:                                        # (interpreter shutdown)
+            pass
 
 
 def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='auto', workspace=None, events=None,

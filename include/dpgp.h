@@ -167,6 +167,12 @@ typedef struct dpgp_exec {
     const double *model_scal;
     double *model_pack;
     double *model_out;
+    /* parallel branch (all three set, or none): the Psi1^T y launch — independent of the psi2 launch, both feed the chain —
+     * goes to `stream_aux` between `ev_fork` (recorded on `stream` after the front launch) and `ev_join` (waited for by
+     * `stream` before the chain launch).  Caller-created: dpgp_stream_create / dpgp_event_create.  Graph-capturable. */
+    void *stream_aux;
+    void *ev_fork;
+    void *ev_join;
 } dpgp_exec_t;
 int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
@@ -211,6 +217,8 @@ int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, 
 /* hipEvent helpers for hosts without their own HIP binding */
 void *dpgp_event_create(void);
 void dpgp_event_destroy(void *event);
+void *dpgp_stream_create(void);          /* a non-blocking hipStream_t (dpgp_exec_t.stream_aux) */
+void dpgp_stream_destroy(void *stream);
 float dpgp_event_elapsed_ms(void *begin, void *end);
 
 /* ---- model-level glue of dp_gp_lvm(...).objective that is O(D T + N Q) (all fp64):
