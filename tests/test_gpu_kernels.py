@@ -210,6 +210,38 @@ def test_potrf_large_multi_workgroup(dev, m, dt):
     assert info.tolist() == [0, 151]
 
 
+@pytest.mark.parametrize('m', [200, 256, 300, 384, 512, 640])
+def test_potrf_large_persistent_workgroup(dev, m, monkeypatch):
+    """M beyond one workgroup's LDS, the path taken when there are enough matrices to give every compute unit its own
+    (B >= 128, fp64): ONE persistent workgroup per matrix (potrf_persist.hip) — forced here for a small batch through
+    DPGP_POTRF_PERSISTENT=1, and once at B = 130 where the library picks it by itself."""
+    monkeypatch.setenv('DPGP_POTRF_PERSISTENT', '1')
+    rng = np.random.default_rng(m + 1)
+    b = 3
+    a = rng.standard_normal((b, m, m + 3))
+    a = a @ a.transpose(0, 2, 1) + 0.5 * m * np.eye(m)
+    l_ref = np.linalg.cholesky(a)
+    l, info = ops.potrf_batched(T(a, torch.float64, dev))
+    assert int(info.abs().max()) == 0
+    close(l, l_ref, dict(rtol=1e-11, atol_rel=1e-13), 'potrf (persistent workgroup)')
+    assert float(torch.triu(l, 1).abs().max()) == 0.0, 'zeros above the diagonal'
+    bad = np.eye(m)[None].repeat(2, axis=0)
+    bad[1, 150, 150] = -1.0
+    _, info = ops.potrf_batched(T(bad, torch.float64, dev))
+    assert info.tolist() == [0, 151]
+
+
+def test_potrf_many_large_matrices_pick_the_persistent_path(dev, monkeypatch):
+    monkeypatch.delenv('DPGP_POTRF_PERSISTENT', raising=False)
+    rng = np.random.default_rng(5)
+    b, m = 130, 256
+    a0 = rng.standard_normal((b, m, m))
+    a = a0 @ a0.transpose(0, 2, 1) + m * np.eye(m)
+    l, info = ops.potrf_batched(T(a, torch.float64, dev))
+    assert int(info.abs().max()) == 0
+    close(l, np.linalg.cholesky(a), dict(rtol=1e-11, atol_rel=1e-13), 'potrf (B = 130)')
+
+
 @pytest.mark.parametrize('algo', ['auto', 'plain'])
 def test_potrf_reports_non_positive_definite(dev, algo):
     a = np.eye(40)[None].repeat(2, axis=0)
