@@ -92,18 +92,31 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     const bool f16_psi2 = (sizeof(TP) == 4 && algo != DPGP_ALGO_MFMA_F32);
     const bool fused_k = (algo != DPGP_ALGO_PLAIN) && (!f16_psi2 || la_chain_k_resident(M, (int)sizeof(TL))) &&
                          !getenv("DPGP_UNFUSED_K");      // (experiments only)
-    if (!fused_k && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, st))) return rc;
+    // M > 128 in fp64 with a matrix per compute unit: the persistent-workgroup chain (chain_big.hip); its K_uu side runs here
+    bool big = false;
+    if constexpr (sizeof(TL) == 8) {
+        big = (algo != DPGP_ALGO_PLAIN) && chain_big_applicable(D, M, 8);
+        if (big && (rc = launch_chain_big_k(D, M, reinterpret_cast<double *>(la), ik, st))) return rc;
+    }
+    if (!big && !fused_k && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, st))) return rc;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     // psi2 on the matrix cores; the same dispatch carries, ahead of the psi2 workgroups, the D workgroups of the K_uu
     // branch (Cholesky, log-det, inverse of K_uu), which are latency-bound and overlap the psi2 work completely
     if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st,
-                                              fused_k ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst,
+                                              (fused_k && !big) ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst,
                                               pairs_psi2 ? 2 : 1, pscale)))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     if (aux && hipStreamWaitEvent(st, (hipEvent_t)ex->ev_join, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
     // ... and, in the workgroup that finishes last, f_hat and KL; with the model-level pointers of exec also the packed pair /
     // the finished objective (round 2: a launch of its own, sum_terms_kernel)
+    if constexpr (sizeof(TL) == 8) {
+        if (big)
+            return launch_chain_big_b<TP>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ik, terms, info,
+                                          reinterpret_cast<double *>(ws + L.off_guard), reinterpret_cast<double *>(la), st, klp,
+                                          sums, ex ? (const double *)ex->model_scal : nullptr,
+                                          ex ? (double *)ex->model_pack : nullptr, ex ? (double *)ex->model_out : nullptr);
+    }
     return launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
                                   reinterpret_cast<double *>(ws + L.off_guard), la, algo, st, klp, sums,
                                   ex ? (const double *)ex->model_scal : nullptr, ex ? (double *)ex->model_pack : nullptr,

@@ -77,7 +77,20 @@ size_t potrf_big_ws_elems(int B, int M);
 template <typename T> int launch_potrf_big(int B, int M, T *a, int *info, T *ws, hipStream_t st);
 // ---- potrf_persist.hip: fp64, one persistent workgroup per matrix (Mw a multiple of 128, w[B][Mw][Mw] in place, lower + zeros)
 bool potrf_persist_applicable(int B, int M, int elem_size);
-int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st);
+int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st, size_t wstride = 0);   // 0: Mw * Mw
+// X = L^-1 R in place for lower-triangular R (zeros above the diagonal), same scheme; only nrm2[b * nstride] = |X_b|_F^2 is a
+// result (X is scratch afterwards: its last 128 rows are not stored)
+int launch_ptrsm_persist(int B, int Mw, const double *l, size_t lstride, double *x, size_t xstride, double *nrm2,
+                         size_t nstride, hipStream_t st);
+// ---- chain_big.hip: the dense chain of the fused ELBO for M > 128 in fp64 (one persistent workgroup per output dim and step)
+bool chain_big_applicable(int D, int M, int elem);
+size_t chain_big_ws_elems(int M);                        // per output dim, doubles (layout: chain_big.hip)
+int launch_chain_big_k(int D, int M, double *ws, int *info_k, hipStream_t st);     // after the front launch: everything on K_uu
+template <typename TP>
+int launch_chain_big_b(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1, const double *alpha,
+                       const double *beta, const double *yy_part, const int *info_k, double *terms, int *info, double *guard,
+                       double *ws, hipStream_t st, const double *kl_part, double *sums, const double *model_scal,
+                       double *model_pack, double *model_out);
 // ---- grad.hip: backward pass (first version) ---------------------------------------------------------------------
 // adjoints of the per-output dense algebra, after a forward evaluation on the same chain workspace ws:
 //   GP[D][Mp][Mp] = df/dPsi2 (lower), WK[D][Mp][Mp] = (df/dK_uu) * (K_uu - jitter I) (lower), Gv[D][Mp] = df/d(Psi1^T y),

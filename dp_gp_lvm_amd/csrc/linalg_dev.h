@@ -884,9 +884,16 @@ template <typename T> __device__ void wtw_lower_blocked(const T *Wm, int ldw, T 
 
 
 // per-output workspace of the Cholesky chain in elements (layout: linalg.hip)
+// (M > 128: at least the layout of the persistent-workgroup chain, chain_big.hip: K0 | three Mw x Mw matrices | 128 scalars)
+static inline size_t chain_big_elems_inline(int M) {
+    const size_t Mp = (size_t)dpgp_round_up(M, 16), Mw = (size_t)dpgp_round_up(M, 128);
+    return Mp * Mp + 3 * Mw * Mw + 128;
+}
 static inline size_t la_chain_ws_elems_inline(int M) {
     const int Mp = dpgp_round_up(M, 16);
-    return (size_t)3 * Mp * Mp + (size_t)(Mp + 16) * Mp + (size_t)(Mp / 16) * 256;
+    const size_t plain = (size_t)3 * Mp * Mp + (size_t)(Mp + 16) * Mp + (size_t)(Mp / 16) * 256;
+    const size_t big = M > 128 ? chain_big_elems_inline(M) : 0;
+    return plain > big ? plain : big;
 }
 static inline size_t la_lds_bytes(int Mp, size_t elem) {     // global-memory blocked routines: dinv + one panel of nb+1 tiles
     return LA_LDS_HDR + elem * (size_t)TSZ * (size_t)(Mp / 16 + 2);

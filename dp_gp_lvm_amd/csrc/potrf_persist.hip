@@ -75,7 +75,8 @@ __device__ __forceinline__ void pp_trsm_tile(double *S, const double *tiles, con
         for (int v = 0; v < 4; ++v) S[li * PP_SLD + 16 * c + 4 * v + kk] = X[c][v];
 }
 
-__global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__restrict__ w, int *__restrict__ info) {
+__global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__restrict__ w, size_t wstride,
+                                                              int *__restrict__ info) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     int &fail = *reinterpret_cast<int *>(smem_raw + 64);
     double *base = reinterpret_cast<double *>(smem_raw + LA_LDS_HDR);
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__
     const int t = threadIdx.x, lane = t & 63, li = lane & 15, kk = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int b = blockIdx.x, nblk = Mw / PP_PW;
-    double *A = w + (size_t)b * Mw * Mw;
+    double *A = w + (size_t)b * wstride;
     constexpr int nlow = PP_NT * (PP_NT + 1) / 2;
     int first_fail = 0;
     for (int k = 0; k < nblk; ++k) {
@@ -276,15 +277,212 @@ __global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__
     if (t == 0) info[b] = first_fail;
 }
 
+// ---- X = L^-1 R in place, R lower triangular (zeros above the diagonal), same persistent scheme as the factorisation above:
+// right-looking over 128-row block rows; per block row k
+//   (a), (b) L_kk -> LDS tiles, its diagonal tiles inverted;
+//   (c) X_k. = L_kk^-1 G_k. for the 8 (k + 1) tiles of 16 columns of the block row: pp_trsm_tile solves L_kk X^T... exactly this
+//       left solve on a [16 columns][128 rows] staging tile (there it is the transposed panel tile);
+//   (d) X_IJ -= L_Ik X_kJ for the blocks I > k, J <= k: the update loop of the factorisation with the A operand chunk from L
+//       (negated) and the B operand chunk [32][128] from block row k of X (row-major in k: no transposition).
+// Used by the fused ELBO for M > 128 (chain_big.hip): only |X|_F^2 leaves the kernel (nrm2[b]); X itself is scratch (the
+// last block row is not even stored).  L[B][Mw][Mw] read-only (lower + zeros), X[B][Mw][Mw] in/out.
+#define PT_YLD 144                 // row stride of a staged [32][128] chunk of X: lanes (kk, li) of an operand read hit 64 banks
+static size_t pt_lds_bytes() {
+    const size_t fact = LA_LDS_HDR + sizeof(double) * ((size_t)TSZ * (PP_NT * (PP_NT + 1) / 2 + PP_NT) + (size_t)4 * 16 * PP_SLD);
+    const size_t upd = LA_LDS_HDR + sizeof(double) * (size_t)2 * (PP_PW * PP_KLD + PP_KQ * PT_YLD);
+    return fact > upd ? fact : upd;
+}
+
+__global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const double *__restrict__ Lall, size_t lstride,
+                                                               double *__restrict__ Xall, size_t xstride,
+                                                               double *__restrict__ nrm2, size_t nstride) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *scratch = reinterpret_cast<double *>(smem_raw);
+    double *base = reinterpret_cast<double *>(smem_raw + LA_LDS_HDR);
+    double *tiles = base;
+    double *linv = tiles + (size_t)TSZ * (PP_NT * (PP_NT + 1) / 2);
+    double *stage = linv + (size_t)TSZ * PP_NT;
+    const int t = threadIdx.x, lane = t & 63, li = lane & 15, kk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = blockIdx.x, nblk = Mw / PP_PW;
+    const double *L = Lall + (size_t)b * lstride;
+    double *X = Xall + (size_t)b * xstride;
+    constexpr int nlow = PP_NT * (PP_NT + 1) / 2;
+    double fro = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        const double *Lkk = L + (size_t)(PP_PW * k) * Mw + PP_PW * k;
+        // ---- (a) L_kk -> LDS tiles ----
+        for (int e = t; e < nlow * 128; e += 256) {
+            const int tt = e >> 7, r = (e >> 3) & 15, c2 = (e & 7) * 2;
+            int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+            while (I * (I + 1) / 2 > tt) --I;
+            const int J = tt - I * (I + 1) / 2;
+            const pp_f2 v = *reinterpret_cast<const pp_f2 *>(Lkk + (size_t)(16 * I + r) * Mw + 16 * J + c2);
+            tiles[tt * TSZ + r * LDT + c2] = v[0];
+            tiles[tt * TSZ + r * LDT + c2 + 1] = v[1];
+        }
+        __syncthreads();
+        // ---- (b) inverted diagonal tiles ----
+        if (wv < 2) {
+            const int c = 4 * wv + kk;
+            tri_inverse_dpp<double>(tiles + lds_tile_index(c, c, PP_NT) * TSZ, linv + c * TSZ, LDT, lane);
+        }
+        __syncthreads();
+        // ---- (c) block row k: column tiles ct = wv, wv + 4, ...; lane -> (row r0 + 8 q of the block, column pair c2 of the tile) ----
+        {
+            const int nct = PP_NT * (k + 1), r0 = lane >> 3, c2 = (lane & 7) * 2;
+            double *S = stage + (size_t)wv * 16 * PP_SLD;
+            double *Xk = X + (size_t)(PP_PW * k) * Mw;
+            const bool keep = (k + 1 < nblk);                  // the last block row is only summed
+            pp_f2 pre[16];
+            if (wv < nct) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const pp_f2 *>(Xk + (size_t)(r0 + 8 * q) * Mw + 16 * wv + c2);
+            }
+            for (int ct = wv; ct < nct; ct += 4) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    S[c2 * PP_SLD + r0 + 8 * q] = pre[q][0];
+                    S[(c2 + 1) * PP_SLD + r0 + 8 * q] = pre[q][1];
+                }
+                if (ct + 4 < nct) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        pre[q] = *reinterpret_cast<const pp_f2 *>(Xk + (size_t)(r0 + 8 * q) * Mw + 16 * (ct + 4) + c2);
+                }
+                pp_trsm_tile(S, tiles, linv, lane);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const pp_f2 v = {S[c2 * PP_SLD + r0 + 8 * q], S[(c2 + 1) * PP_SLD + r0 + 8 * q]};
+                    fro += v[0] * v[0] + v[1] * v[1];
+                    if (keep) *reinterpret_cast<pp_f2 *>(Xk + (size_t)(r0 + 8 * q) * Mw + 16 * ct + c2) = v;
+                }
+            }
+        }
+        if (k + 1 == nblk) break;
+        __threadfence_block();
+        __syncthreads();                                               // block row k complete in memory; the LDS tiles are free
+        // ---- (d) update of the blocks (I, J), I > k, J <= k ----
+        {
+            typedef f64x4 acc_t;
+            const int nI = nblk - 1 - k, nJ = k + 1, nsteps = nI * nJ * (PP_PW / PP_KQ);
+            const double *Lk = L + (size_t)(PP_PW * (k + 1)) * Mw + PP_PW * k;    // L_Ik: row r of block I at Lk + (128 I + r) Mw
+            const double *Xk = X + (size_t)(PP_PW * k) * Mw;                      // block row k of X
+            double *T = X + (size_t)(PP_PW * (k + 1)) * Mw;                       // the block rows below
+            const int rt0 = wv, rt1 = PP_NT - 1 - wv;
+            acc_t acc[2][PP_NT];
+            pp_f2 px[8], py[8];
+            const int srow = t >> 4, sc2 = (t & 15) * 2;                           // [128][32] chunk of L: 16 threads per row
+            const int yrow = t >> 6, yc2 = (t & 63) * 2;                           // [32][128] chunk of X: 64 threads per row
+            int bI = 0, bJ = 0;
+            auto fetch = [&](int step) {
+                const int h = step & 3;
+                const double *pi = Lk + (size_t)(PP_PW * bI) * Mw + PP_KQ * h;
+                const double *pj = Xk + (size_t)(PP_KQ * h) * Mw + PP_PW * bJ;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) px[q] = *reinterpret_cast<const pp_f2 *>(pi + (size_t)(srow + 16 * q) * Mw + sc2);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) py[q] = *reinterpret_cast<const pp_f2 *>(pj + (size_t)(yrow + 4 * q) * Mw + yc2);
+                if (h == 3) {
+                    if (bJ + 1 < nJ) ++bJ;
+                    else { ++bI; bJ = 0; }
+                }
+            };
+            auto stash = [&](int step) {
+                double *xs = base + (size_t)(step & 1) * (PP_PW * PP_KLD + PP_KQ * PT_YLD), *ys = xs + (size_t)PP_PW * PP_KLD;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    double *dx = xs + (srow + 16 * q) * PP_KLD + sc2, *dy = ys + (yrow + 4 * q) * PT_YLD + yc2;
+                    dx[0] = -px[q][0]; dx[1] = -px[q][1];
+                    dy[0] = py[q][0]; dy[1] = py[q][1];
+                }
+            };
+            int cI = 0, cJ = 0;
+            if (nsteps > 0) {
+                fetch(0);
+                stash(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int Jt = 0; Jt < PP_NT; ++Jt) acc[i][Jt] = (acc_t){0, 0, 0, 0};
+            for (int step = 0; step < nsteps; ++step) {
+                const int h = step & 3;
+                if (step + 1 < nsteps) fetch(step + 1);
+                double *Cb = T + (size_t)(PP_PW * cI) * Mw + PP_PW * cJ;
+                acc_t cold[2][PP_NT];
+                if (h == 3) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int rt = i ? rt1 : rt0;
+#pragma unroll
+                        for (int Jt = 0; Jt < PP_NT; ++Jt)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) cold[i][Jt][v] = Cb[(size_t)(16 * rt + kk + 4 * v) * Mw + 16 * Jt + li];
+                    }
+                }
+                const double *xs = base + (size_t)(step & 1) * (PP_PW * PP_KLD + PP_KQ * PT_YLD), *ys = xs + (size_t)PP_PW * PP_KLD;
+#pragma unroll 2
+                for (int ks = 0; ks < PP_KQ / 4; ++ks) {
+                    const double x0 = xs[(16 * rt0 + li) * PP_KLD + 4 * ks + kk], x1 = xs[(16 * rt1 + li) * PP_KLD + 4 * ks + kk];
+#pragma unroll
+                    for (int Jt = 0; Jt < PP_NT; ++Jt) {
+                        const double yv = ys[(4 * ks + kk) * PT_YLD + 16 * Jt + li];
+                        acc[0][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, yv, acc[0][Jt], 0, 0, 0);
+                        acc[1][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, yv, acc[1][Jt], 0, 0, 0);
+                    }
+                }
+                if (h == 3) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int rt = i ? rt1 : rt0;
+#pragma unroll
+                        for (int Jt = 0; Jt < PP_NT; ++Jt) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                Cb[(size_t)(16 * rt + kk + 4 * v) * Mw + 16 * Jt + li] = cold[i][Jt][v] + acc[i][Jt][v];
+                            acc[i][Jt] = (acc_t){0, 0, 0, 0};
+                        }
+                    }
+                    if (cJ + 1 < nJ) ++cJ;
+                    else { ++cI; cJ = 0; }
+                }
+                if (step + 1 < nsteps) stash(step + 1);
+                __syncthreads();
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    __syncthreads();
+    fro = block_sum(fro, scratch);
+    if (t == 0) nrm2[(size_t)b * nstride] = fro;
+}
+
+int launch_ptrsm_persist(int B, int Mw, const double *l, size_t lstride, double *x, size_t xstride, double *nrm2,
+                         size_t nstride, hipStream_t st) {
+    const size_t lds = pt_lds_bytes();
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ptrsm_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return DPGP_ERR_LAUNCH;
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(ptrsm_persistent_kernel, dim3(B), dim3(256), lds, st, Mw, l, lstride, x, xstride, nrm2, nstride);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
 bool potrf_persist_applicable(int B, int M, int elem_size) { return elem_size == 8 && M > 128 && B >= 128; }
 
-int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st) {
+int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st, size_t wstride) {
+    if (!wstride) wstride = (size_t)Mw * Mw;
     const size_t lds = pp_lds_bytes();
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pbig_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH();
-    hipLaunchKernelGGL(pbig_persistent_kernel, dim3(B), dim3(256), lds, st, Mw, w, info);
+    hipLaunchKernelGGL(pbig_persistent_kernel, dim3(B), dim3(256), lds, st, Mw, w, wstride, info);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }

@@ -142,6 +142,40 @@ def test_config4_shape_against_c_oracle(dev):
         check_terms(terms, ref, prec, 'config 4 ' + prec)
 
 
+@pytest.mark.parametrize('shape', [(300, 3, 200, 5), (400, 2, 384, 8), (150, 2, 129, 8)])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_persistent_chain_beyond_128_inducing_points(dev, shape, prec, monkeypatch):
+    """The persistent-workgroup chain (csrc/chain_big.hip: chol(K), chol(K + beta Psi2), L_A = L_K^-1 L_B as a triangular solve
+    with a triangular right-hand side) is chosen when D >= 128; forced here on few output dims so that the NumPy oracle stays
+    cheap.  M = 200 / 129: identity padding to 256 rows; M = 384: three block columns.  Also against the round-2 path."""
+    from oracle import dpgp_oracle as orc
+    p = make_problem(shape=shape, seed=31)
+    ref = orc.fhat_terms(p['y'], p['z'], p['mu'], p['s'], p['gamma'], p['alpha'], p['beta'])
+    monkeypatch.setenv('DPGP_CHAIN_BIG', '1')
+    terms, sums, info = run(p, dev, prec)
+    assert not info.any()
+    check_terms(terms, ref, prec, 'persistent chain %s %s' % (shape, prec))
+    np.testing.assert_allclose(sums[0], terms.sum(), rtol=1e-12)
+    monkeypatch.setenv('DPGP_CHAIN_BIG', '0')
+    old, _, info0 = run(p, dev, prec)
+    assert not info0.any()
+    np.testing.assert_allclose(terms, old, rtol=1e-9, atol=1e-9 * np.abs(old).max())
+
+
+def test_persistent_chain_reports_failures_per_output(dev, monkeypatch):
+    """as test_not_positive_definite_is_reported_not_fatal, through the persistent chain (M > 128)"""
+    monkeypatch.setenv('DPGP_CHAIN_BIG', '1')
+    p = make_problem(shape=(200, 4, 160, 3), seed=5)
+    ref, _, info = run(p, dev, 'f64')
+    assert not info.any()
+    p['beta'] = p['beta'].copy()
+    p['beta'][2] = -500.0
+    terms, sums, info = run(p, dev, 'f64')
+    assert info[2] > 160 and (np.delete(info, 2) == 0).all()
+    assert np.isnan(terms[2, [1, 2, 4]]).all()
+    np.testing.assert_array_equal(np.delete(terms, 2, axis=0), np.delete(ref, 2, axis=0))
+
+
 def test_sharded_model_single_rank_group(dev):
     """The D-sharded code path of the model object (pack -> all_reduce -> finalize) with a 1-rank process group on the GPU."""
     import os
