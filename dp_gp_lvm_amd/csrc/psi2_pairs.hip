@@ -46,6 +46,9 @@ typedef float pp_f16v __attribute__((ext_vector_type(16)));
 #endif
 template <int KS> struct PairsCfg { static constexpr int G = PP_G(KS); };
 
+#ifndef PP_NW8_MIN_TILES
+#define PP_NW8_MIN_TILES 512       // pair tiles from which the eight-wave workgroup is used (see psi2_pairs_kernel, pairs_geom)
+#endif
 #ifndef PP_DEEP_PREFETCH
 #define PP_DEEP_PREFETCH 1         // groups of two resident tiles fetch their row operands two row tiles ahead
 #endif
@@ -55,11 +58,11 @@ template <int KS> struct PairsCfg { static constexpr int G = PP_G(KS); };
 
 // the column operands of GG pair tiles tb, tb + 4, ...: operand order (psi2_consts.h), 64 lanes x 16 bytes contiguous per
 // (tile, K-step)
-template <int KS, int GG>
+template <int KS, int GG, int NW>
 __device__ __forceinline__ void pairs_load(pp_h8 (&bop)[GG][KS], int tb, const _Float16 *__restrict__ img, int l5, int half) {
 #pragma unroll
     for (int g = 0; g < GG; ++g) {
-        const pp_h8 *row = reinterpret_cast<const pp_h8 *>(img) + (size_t)(tb + 4 * g) * KS * 64 + 32 * half + l5;
+        const pp_h8 *row = reinterpret_cast<const pp_h8 *>(img) + (size_t)(tb + NW * g) * KS * 64 + 32 * half + l5;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bop[g][ks] = row[ks * 64];
     }
@@ -70,7 +73,7 @@ __device__ __forceinline__ void pairs_load(pp_h8 (&bop)[GG][KS], int tb, const _
 // issued before the exponentials of the current one are evaluated.  GG is even or 1.
 // bop: the operands of this group (pairs_load); tb_next >= 0: the operands of the group at tb_next are fetched into bop as soon
 // as the last MFMA of this group has been issued, i.e. beneath this group's epilogue.
-template <int KS, int GG>
+template <int KS, int GG, int NW>
 __device__ __forceinline__ void pairs_group(int tb, pp_h8 (&bop)[GG][KS], int tb_next, const _Float16 *__restrict__ aimg,
                                             const _Float16 *__restrict__ img,
                                             const unsigned *__restrict__ pmap, const float *__restrict__ scale, int ntile,
@@ -83,8 +86,8 @@ __device__ __forceinline__ void pairs_group(int tb, pp_h8 (&bop)[GG][KS], int tb
     float sc[GG], old[GG];
 #pragma unroll
     for (int g = 0; g < GG; ++g) {
-        pm[g] = pmap[32 * (tb + 4 * g) + l5];
-        sc[g] = scale[32 * (tb + 4 * g) + l5];
+        pm[g] = pmap[32 * (tb + NW * g) + l5];
+        sc[g] = scale[32 * (tb + NW * g) + l5];
     }
 #pragma unroll
     for (int g = 0; g < GG; ++g) {
@@ -191,7 +194,7 @@ __device__ __forceinline__ void pairs_group(int tb, pp_h8 (&bop)[GG][KS], int tb
             for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
         }
     }
-    if (tb_next >= 0) pairs_load<KS, GG>(bop, tb_next, img, l5, half);
+    if (tb_next >= 0) pairs_load<KS, GG, NW>(bop, tb_next, img, l5, half);
     // ---- column sums: add the lane halves, scale by alpha^2 exp2(beta_p), store (first chunk) or accumulate ----
 #pragma unroll
     for (int g = 0; g < GG; ++g) {
@@ -209,8 +212,12 @@ __global__ __launch_bounds__(256) void psi2_pair_scale_kernel(int M, int Q, cons
     psi2_pair_scale_block<TIN, TIN>((int)blockIdx.y, (int)blockIdx.x, M, Q, z, gamma, alpha, scale);
 }
 
-template <typename TIN, int KS>
-__global__ __launch_bounds__(256, PP_WAVES) void psi2_pairs_kernel(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
+// NW waves per workgroup: 4 (two workgroups per compute unit, 80 KB of LDS each) or 8 (one workgroup with the whole LDS: twice
+// the observations per chunk behind the same two waves per SIMD — the column operands of a group of G pair tiles are fetched once
+// per chunk, so at KS = 8 (288 rows per 80 KB, G = 2) their traffic and the group prologue/epilogue set the pace: measured at
+// config 4, 24.2 / 19.9 ms for 144 / 288 rows per chunk)
+template <typename TIN, int KS, int NW>
+__global__ __launch_bounds__(64 * NW, PP_WAVES) void psi2_pairs_kernel(int N, int M, int Q, int B, const unsigned char *__restrict__ consts,
                                                             const TIN *__restrict__ mu, const TIN *__restrict__ s,
                                                             const TIN *__restrict__ gamma, const float *__restrict__ scale,
                                                             float *__restrict__ part, int Mp, int n_per_split, int n_splits,
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256, PP_WAVES) void psi2_pairs_kernel(int N, int M,
     int item;
     if (psi2_task_1d(blockIdx.x, task.ws ? B : 0, task.last != 0, item)) {
 #ifndef PP_NO_CHAIN
-        if constexpr (std::is_same<TIN, double>::value) chain_k_task<2>(task, item, smem_raw);
+        if constexpr (std::is_same<TIN, double>::value && NW == 4) chain_k_task<2>(task, item, smem_raw);
 #endif
         return;
     }
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256, PP_WAVES) void psi2_pairs_kernel(int N, int M,
         const int rows = min(R, nend - n0), ntile = (rows + 31) >> 5;
         if (chunk) __syncthreads();                              // the previous chunk's image is no longer read
         // ---- phase A: the A image of this chunk, thread = observation ----
-        for (int r = t; r < 32 * ntile; r += 256) {
+        for (int r = t; r < 32 * ntile; r += 64 * NW) {
             const int n = n0 + r;
             unsigned *dst = reinterpret_cast<unsigned *>(aimg + (size_t)r * LDA);
             float cc = -60000.0f;                                // rows past the end: exp2(-60000) = 0
@@ -295,25 +302,25 @@ __global__ __launch_bounds__(256, PP_WAVES) void psi2_pairs_kernel(int N, int M,
 
         // ---- the wave's pair tiles: groups of G, the remainder in groups of 2 and 1 ----
         int tb = t0 + wv;
-        if (tb + 4 * (G - 1) < t1) {
+        if (tb + NW * (G - 1) < t1) {
             pp_h8 bop[G][KS];
-            pairs_load<KS, G>(bop, tb, img, l5, half);
-            for (; tb + 4 * (G - 1) < t1; tb += 4 * G) {
-                const int nx = tb + 4 * G;
-                pairs_group<KS, G>(tb, bop, nx + 4 * (G - 1) < t1 ? nx : -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out,
+            pairs_load<KS, G, NW>(bop, tb, img, l5, half);
+            for (; tb + NW * (G - 1) < t1; tb += NW * G) {
+                const int nx = tb + NW * G;
+                pairs_group<KS, G, NW>(tb, bop, nx + NW * (G - 1) < t1 ? nx : -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out,
                                    Mp, chunk);
             }
         }
         if constexpr (G > 2)
-            for (; tb + 4 < t1; tb += 8) {
+            for (; tb + NW < t1; tb += 2 * NW) {
                 pp_h8 bop[2][KS];
-                pairs_load<KS, 2>(bop, tb, img, l5, half);
-                pairs_group<KS, 2>(tb, bop, -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
+                pairs_load<KS, 2, NW>(bop, tb, img, l5, half);
+                pairs_group<KS, 2, NW>(tb, bop, -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
             }
-        for (; tb < t1; tb += 4) {
+        for (; tb < t1; tb += NW) {
             pp_h8 bop[1][KS];
-            pairs_load<KS, 1>(bop, tb, img, l5, half);
-            pairs_group<KS, 1>(tb, bop, -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
+            pairs_load<KS, 1, NW>(bop, tb, img, l5, half);
+            pairs_group<KS, 1, NW>(tb, bop, -1, aimg, img, pmap, sc_b, ntile, l5, half, poison, out, Mp, chunk);
         }
     }
 }
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256, PP_WAVES) void psi2_pairs_kernel(int N, int M,
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct PairsGeom {
-    int KS, R, n_ranges, tiles_per_range;
+    int KS, R, n_ranges, tiles_per_range, NW;
     size_t lds;
 };
 static PairsGeom pairs_geom(int B, int N, int M, int Q, int ns, size_t chain_lds) {
@@ -336,6 +343,19 @@ static PairsGeom pairs_geom(int B, int N, int M, int Q, int ns, size_t chain_lds
     if (chain_lds > budget) budget = chain_lds;
     int rmax = (int)((budget - PP_LDS_HDR) / row) & ~31;
     const int nper = dpgp_ceil_div(N, ns);
+    // eight waves on the whole LDS (psi2_pairs_kernel) when the observations of a workgroup do not fit one 80 KB chunk, no
+    // K_uu task rides in the dispatch (those are 256-thread workgroups) and every wave has enough pair tiles to pay for the
+    // image build of the larger chunk (operator alone, 4 against 8 waves: config 4 (4104 tiles, KS = 8) 19.96 -> 18.24 ms;
+    // config 3 (258 tiles, KS = 4) 1.467 -> 1.443 ms; config 5 (65 tiles, KS = 8) 0.79 -> 0.89 ms)
+    g.NW = (!chain_lds && nper > rmax && C.Ppad / 32 >= PP_NW8_MIN_TILES) ? 8 : 4;
+    if (const char *e = getenv("DPGP_PP_NW")) {                 // (experiments only)
+        const int v = atoi(e);
+        if ((v == 4 || v == 8) && !(v == 8 && chain_lds)) g.NW = v;
+    }
+    if (g.NW == 8) {
+        budget = 160 * 1024;
+        rmax = (int)((budget - PP_LDS_HDR) / row) & ~31;
+    }
     int r = dpgp_round_up(nper, 32);
     if (r > rmax) {                                             // several chunks per workgroup: equal ones
         const int chunks = dpgp_ceil_div(nper, rmax);
@@ -348,7 +368,7 @@ static PairsGeom pairs_geom(int B, int N, int M, int Q, int ns, size_t chain_lds
     const int tiles = C.Ppad / 32;
     // (with the K_uu tasks in the dispatch: one round of <= 512 workgroups, less the B slots the tasks hold from the start
     //  when there are few output dims — the rule psi2_nsplit chose ns by)
-    int nr = chain_lds ? (B < 128 ? 512 - B : 512) / (B * ns) : dpgp_ceil_div(512, B * ns);
+    int nr = chain_lds ? (B < 128 ? 512 - B : 512) / (B * ns) : dpgp_ceil_div(g.NW == 8 ? 256 : 512, B * ns);
     if (nr > dpgp_ceil_div(tiles, 32)) nr = dpgp_ceil_div(tiles, 32);   // >= 32 tiles (8 per wave) per range
     if (nr < 1) nr = 1;
     if (const char *e = getenv("DPGP_PP_RANGES")) {             // (experiments only)
@@ -360,7 +380,7 @@ static PairsGeom pairs_geom(int B, int N, int M, int Q, int ns, size_t chain_lds
     return g;
 }
 
-template <typename TIN, int KS>
+template <typename TIN, int KS, int NW>
 static int launch_pairs_ks(int B, int N, int M, int Q, const TIN *mu, const TIN *s, const TIN *gamma, const float *scale,
                            float *part, int ns, const ChainKTask &task, const unsigned char *consts, const PairsGeom &g,
                            hipStream_t st) {
@@ -368,12 +388,13 @@ static int launch_pairs_ks(int B, int N, int M, int Q, const TIN *mu, const TIN 
     const int nper = dpgp_ceil_div(N, ns);
     const long long nwg = (long long)B * ns * g.n_ranges + (task.ws ? B : 0);
     if (nwg > 0x7fffffffLL) return -1;
-    auto kern = psi2_pairs_kernel<TIN, KS>;
+    auto kern = psi2_pairs_kernel<TIN, KS, NW>;
+    if (NW == 8 && task.ws) return -16;
     if (g.lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) !=
             hipSuccess)
         return DPGP_ERR_LAUNCH;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), g.lds, st, N, M, Q, B, consts, mu, s, gamma, scale, part,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), g.lds, st, N, M, Q, B, consts, mu, s, gamma, scale, part,
                        Mp, nper, ns, g.n_ranges, g.tiles_per_range, g.R, task);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
@@ -404,7 +425,10 @@ int launch_psi2_pairs(int B, int N, int M, int Q, const TIN *z, const TIN *mu, c
     }
     const PairsGeom g = pairs_geom(B, N, M, Q, ns, chain_lds);
     switch (g.KS) {
-#define CASE(k) case k: return launch_pairs_ks<TIN, k>(B, N, M, Q, mu, s, gamma, scale, part, ns, task, consts, g, st);
+#define CASE(k)                                                                                                       \
+    case k:                                                                                                           \
+        return g.NW == 8 ? launch_pairs_ks<TIN, k, 8>(B, N, M, Q, mu, s, gamma, scale, part, ns, task, consts, g, st) \
+                         : launch_pairs_ks<TIN, k, 4>(B, N, M, Q, mu, s, gamma, scale, part, ns, task, consts, g, st);
         CASE(2) CASE(4) CASE(6) CASE(8)
 #undef CASE
     }

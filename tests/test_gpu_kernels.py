@@ -96,6 +96,27 @@ def test_psi_statistics_vs_oracle_ragged(dev, shape, dt):
     close(ops.psi1T_y(*args, T(y, dt, dev)), orc.psi1T_y(z, mu, s, gam, al, y), tol, 'psi1T_y')
 
 
+@pytest.mark.parametrize('shape', [(2, 1300, 100, 20), (3, 700, 70, 7), (1, 2500, 200, 12)])
+def test_psi2_eight_wave_workgroups(dev, shape, monkeypatch):
+    """The pair-tile kernel with eight waves on the whole LDS of a compute unit (psi2_pairs.hip, NW = 8: chosen for >= 512 pair
+    tiles when the observations of a workgroup need several chunks — config 4), forced here on shapes the oracle can follow:
+    several chunks per workgroup, ragged last chunk, tile counts that are not multiples of 8."""
+    b, n, m, q = shape
+    rng = np.random.default_rng(sum(shape))
+    z, mu = rng.standard_normal((m, q)), rng.standard_normal((n, q))
+    s = np.exp(0.5 * rng.standard_normal((n, q)))
+    gam, al = np.exp(0.3 * rng.standard_normal((b, q))), np.exp(0.3 * rng.standard_normal((b, 1)))
+    args = [T(a, torch.float32, dev) for a in (z, mu, s, gam, al)]
+    ref2 = orc.psi2(z, mu, s, gam, al)
+    monkeypatch.setenv('DPGP_PP_NW', '8')
+    monkeypatch.setenv('DPGP_PSI2_NS', '1')
+    p8 = ops.psi2(*args)
+    close(p8, ref2, TOL_PSI2[torch.float32], 'psi2, eight waves')
+    monkeypatch.setenv('DPGP_PP_NW', '4')
+    p4 = ops.psi2(*args)
+    torch.testing.assert_close(p8, p4, rtol=1e-5, atol=1e-5 * float(p4.max()))
+
+
 @pytest.mark.parametrize('dt', [torch.float64, torch.float32])
 def test_psi2_far_from_origin_is_translation_invariant(dev, dt):
     """q(X) and Z far from the origin: the kernel centres its coordinates, so fp32 accuracy must not degrade."""
