@@ -22,9 +22,9 @@
 #include "internal.h"
 #ifdef DPGP_PROFILE_CHAIN
 // diagnostic build only (scratch/): per-phase clock stamps of workgroup 0, read back with dpgp_debug_stamps()
-__device__ long long g_chain_stamps[64];
+__device__ long long g_chain_stamps[128];
 #define STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { g_chain_stamps[i] = wall_clock64(); g_chain_stamps[8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
-extern "C" void dpgp_debug_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * 64); }
+extern "C" void dpgp_debug_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * 128); }
 #define ACC_BEGIN() long long t__ = __builtin_amdgcn_s_memtime()
 // slots 16 + k / 32 + k: shader cycles of panel / update phase k of the last evaluation (wave 0 / wave 1 of workgroup 0)
 #define ACC_END(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == ((i) == 4 ? 0 : 1)) { const long long dt__ = __builtin_amdgcn_s_memtime() - t__; g_chain_stamps[i] += dt__; g_chain_stamps[((i) == 4 ? 16 : 32) + k] = dt__; } } while (0)
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void potrf_batched_lds_kernel(int M, int Mp
     const int b = blockIdx.x, t = threadIdx.x, nb = Mp / 16, nlow = nb * (nb + 1) / 2;
     T *A = a + (size_t)b * M * M;
     if (t == 0) fail = 0;
+    STAMP(60);
     for (int e = t; e < nlow * 256; e += 256) {               // (tile, row, column): consecutive threads along a row
         const int tt = e >> 8, r = (e >> 4) & 15, c = e & 15;
         int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
@@ -401,12 +402,15 @@ __global__ __launch_bounds__(256, 2) void potrf_batched_lds_kernel(int M, int Mp
         tiles[tt * TSZ + r * LDT + c] = (i < M && j < M) ? A[(size_t)i * M + j] : ((i == j) ? (T)1 : (T)0);
     }
     __syncthreads();
+    STAMP(61);
     potrf_lds<T, 2>(tiles, dinv, nb, nb, &fail);
     __syncthreads();
+    STAMP(62);
     for (int e = t; e < M * M; e += 256) {
         const int i = e / M, j = e - i * M;
         A[e] = (j <= i) ? tiles[lds_tile_index(i >> 4, j >> 4, nb) * TSZ + (i & 15) * LDT + (j & 15)] : (T)0;
     }
+    STAMP(63);
     if (t == 0) info[b] = fail;
 }
 

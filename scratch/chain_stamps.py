@@ -10,7 +10,7 @@ init = dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']
 model = dp_gp_lvm(p['y'], num_latent_dims=q, num_inducing_points=m, truncation_level=t, alpha_prior_params=np.array([p['s1'], p['s2']]), device='cuda:0', initial_values=init, precision='mixed')
 for _ in range(5): float(model.objective)
 torch.cuda.synchronize()
-out = (ctypes.c_longlong * 64)()
+out = (ctypes.c_longlong * 128)()
 l = ctypes.CDLL(_lib.LIB_PATH)
 l.dpgp_debug_stamps(out)
 s = list(out)
