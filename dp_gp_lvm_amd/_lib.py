@@ -32,6 +32,9 @@ SIGNATURES = {
                             _vp]),
     'dpgp_elbo_fhat_ex': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                _vp, _vp]),
+    'dpgp_elbo_fhat_t_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'dpgp_elbo_fhat_t': (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _d, _i, _vp, _vp,
+                              _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     'dpgp_elbo_grad_chain': (_i, [_i, _i, _i, _i, _vp, _vp, _d, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dpgp_elbo_grad_psi_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'dpgp_elbo_grad_psi': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp,
@@ -45,6 +48,8 @@ SIGNATURES = {
     'dpgp_event_elapsed_ms': (ctypes.c_float, [_vp, _vp]),
     'dpgp_model_prepare': (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
+    'dpgp_model_prepare_t': (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i, _vp, _vp, _vp,
+                                  _vp, _vp]),
     'dpgp_model_scal_count': (_i, [_i]),
     'dpgp_model_backward': (_i, [_i] * 8 + [_vp] * 10 + [_d, _d, _i] + [_vp] * 15 + [_vp]),
     'dpgp_model_pack': (_i, [_i, _vp, _vp, _vp, _vp]),

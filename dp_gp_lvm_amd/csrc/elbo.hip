@@ -59,7 +59,7 @@ template <typename TP, typename TL>
 static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                     const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                     int algo, double *terms, double *sums, int *info, unsigned char *ws, const ElboLayout &L,
-                    hipStream_t st, const dpgp_exec_t *ex) {
+                    hipStream_t st, const dpgp_exec_t *ex, TL *lb_out = nullptr) {
     double *yy = reinterpret_cast<double *>(ws + L.off_yy);
     double *ldk = reinterpret_cast<double *>(ws + L.off_ld);
     int *ik = reinterpret_cast<int *>(ws + L.off_ik);
@@ -110,6 +110,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     if (aux && hipStreamWaitEvent(st, (hipEvent_t)ex->ev_join, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
     // ... and, in the workgroup that finishes last, f_hat and KL; with the model-level pointers of exec also the packed pair /
     // the finished objective (round 2: a launch of its own, sum_terms_kernel)
+    if (big && lb_out) return -30;
     if constexpr (sizeof(TL) == 8) {
         if (big)
             return launch_chain_big_b<TP>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ik, terms, info,
@@ -120,7 +121,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     return launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
                                   reinterpret_cast<double *>(ws + L.off_guard), la, algo, st, klp, sums,
                                   ex ? (const double *)ex->model_scal : nullptr, ex ? (double *)ex->model_pack : nullptr,
-                                  ex ? (double *)ex->model_out : nullptr);
+                                  ex ? (double *)ex->model_out : nullptr, lb_out);
 }
 
 // Backward pass, stage A (grad.hip): adjoints of the per-output dense algebra from the workspace of a finished forward
@@ -295,6 +296,132 @@ extern "C" int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int l
                              ws_bytes, stream, nullptr);
 }
 
+// ---- f_hat of the over-T model (dp_gp_lvm_t, reference dp_gp_lvm.py:608-676): the T atoms play the part of the output dims in
+// the fused reduction above (terms 0-2 of atom t do not depend on y), and every atom is solved against ALL D columns:
+//      f_hat = -N D / 2 log 2pi + sum_td phi_td ( per_t + 1/2 beta_t^2 |L_B,t^-1 Psi1_t^T y_d|^2 - 1/2 beta_t y_d^T y_d ),
+//      per_t = N/2 log beta_t + beta_t / 2 (tr(L^-1 Psi2 L^-T) - alpha_t N) - sum log diag L_A,t
+// Launches: the five of dpgp_elbo_fhat on T "output dims" (chain_b also exports L_B,t), Psi1 [T,N,M] (fp64), the split-k product
+// Psi1_t^T Y (:657-658), the D-column solve + squared norms (potrf_persist.hip), one combining workgroup.  M <= 128.
+struct ElboTLayout {
+    ElboLayout L;
+    size_t off_fused, off_terms, off_sums, off_lb, off_p1, off_vp, total;
+    int ksplit, nlow;
+};
+static ElboTLayout elbo_t_layout(int T, int D, int N, int M, int Q, int prec) {
+    ElboTLayout E;
+    E.L = elbo_layout(T, N, M, Q, prec);
+    const int Mp = E.L.Mp, nb = Mp / 16;
+    E.nlow = nb * (nb + 1) / 2;
+    const int tiles = dpgp_ceil_div(D, 64) * dpgp_ceil_div(M, 64) * T;
+    int ks = 512 / (tiles > 0 ? tiles : 1);
+    if (ks > 8) ks = 8;
+    if (ks > N / 64) ks = N / 64;
+    if (ks < 1) ks = 1;
+    E.ksplit = ks;
+    size_t o = 0;
+    E.off_fused = o; o += dpgp_align256(E.L.total);
+    E.off_terms = o; o += dpgp_align256(sizeof(double) * 5 * T);
+    E.off_sums = o;  o += 256;
+    E.off_lb = o;    o += dpgp_align256(sizeof(double) * (size_t)T * E.nlow * DPGP_LB_TILE_ELEMS);
+    E.off_p1 = o;    o += dpgp_align256(sizeof(double) * (size_t)T * N * M);
+    E.off_vp = o;    o += dpgp_align256(sizeof(double) * (size_t)ks * T * M * D);
+    E.total = o;
+    return E;
+}
+extern "C" size_t dpgp_elbo_fhat_t_workspace_bytes(int T, int D, int N, int M, int Q, int prec) {
+    if (T <= 0 || D < T || N <= 0 || M <= 0 || Q <= 0 || prec < 1 || prec > 2) return 0;
+    return elbo_t_layout(T, D, N, M, Q, prec).total;
+}
+
+__global__ __launch_bounds__(256) void fhat_t_combine_kernel(int T, int D, int N, const double *__restrict__ terms,
+                                                             const double *__restrict__ phit, const double *__restrict__ quad,
+                                                             const double *__restrict__ yy, const double *__restrict__ beta,
+                                                             const double *__restrict__ sums_in, double *__restrict__ per_t,
+                                                             double *__restrict__ sums, long long phi_st, long long phi_sd,
+                                                             const double *__restrict__ model_scal,
+                                                             double *__restrict__ model_pack, double *__restrict__ model_out) {
+    __shared__ double scratch[8];
+    const int t = threadIdx.x;
+    double acc = 0.0;
+    for (int e = t; e < T * D; e += 256) {
+        const int a = e / D, d = e - a * D;
+        const double *o = terms + 5 * a;
+        const double pt = o[0] + 0.5 * N * DPGP_LOG_2PI + o[1] + o[2];
+        acc += phit[a * phi_st + d * phi_sd] * (pt + 0.5 * quad[e] - 0.5 * beta[a] * yy[d]);
+    }
+    acc = block_sum(acc, scratch);
+    if (t < T) {
+        const double *o = terms + 5 * t;
+        per_t[t] = o[0] + 0.5 * N * DPGP_LOG_2PI + o[1] + o[2];
+    }
+    if (t == 0) {
+        const double fhat = acc - 0.5 * (double)N * (double)D * DPGP_LOG_2PI, kl = sums_in[1];
+        sums[0] = fhat;
+        sums[1] = kl;
+        if (model_scal) {                                    // the model-level tail, as in sum_terms_body (linalg.hip)
+            double a = model_scal[0];
+            const int nrb = (D + DPGP_PREP_ROWS - 1) / DPGP_PREP_ROWS;
+            for (int i = 0; i < nrb; ++i) a += model_scal[2 + i];
+            if (model_pack) { model_pack[0] = fhat; model_pack[1] = -a; }
+            if (model_out) {
+                const double hyper = model_scal[1];
+                model_out[0] = -a - (fhat - kl) - hyper;
+                model_out[1] = fhat; model_out[2] = kl; model_out[3] = -a; model_out[4] = hyper;
+            }
+        }
+    }
+}
+
+extern "C" int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double *y, int ldy, const double *yy, const double *z,
+                                const double *mu, const double *s, const double *gamma, const double *alpha, const double *beta,
+                                const double *phit, long long phi_st, long long phi_sd, double jitter, int prec, double *per_t,
+                                double *quad, double *sums, int *info, void *ws, size_t ws_bytes, void *stream,
+                                const double *model_scal, double *model_pack, double *model_out) {
+    if (T <= 0) return -1;
+    if (D < T) return -2;                                   // (the model asserts truncation_level <= D, dp_gp_lvm.py:567)
+    if (N <= 0) return -3;
+    if (M <= 0) return -4;
+    if (Q <= 0 || Q > DPGP_MAX_Q) return -5;
+    if (!y) return -6;
+    if (ldy < D) return -7;
+    if (!yy) return -8;
+    if (!z || !mu || !s) return -9;
+    if (!gamma || !alpha || !beta) return -12;
+    if (!phit) return -15;
+    if (!(jitter >= 0.0)) return -16;
+    if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_F64) return -17;
+    if (!per_t || !quad || !sums || !info) return -18;
+    if (!ws) return -22;
+    if (dpgp_round_up(M, 16) > 128) return -30;            // first version: L_B,t comes out of the LDS-resident chain
+    const ElboTLayout E = elbo_t_layout(T, D, N, M, Q, prec);
+    if (ws_bytes < E.total) return -23;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char *w = (unsigned char *)ws;
+    double *terms = reinterpret_cast<double *>(w + E.off_terms), *sums2 = reinterpret_cast<double *>(w + E.off_sums);
+    double *lb = reinterpret_cast<double *>(w + E.off_lb), *p1 = reinterpret_cast<double *>(w + E.off_p1);
+    double *vp = reinterpret_cast<double *>(w + E.off_vp);
+    int rc;
+    // (the first T columns of y stand in for the per-output columns of the fused reduction: its terms 3 and 4 are not used)
+    if (prec == DPGP_PREC_MIXED)
+        rc = elbo_run<float, double>(T, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums2, info,
+                                     w + E.off_fused, E.L, st, nullptr, lb);
+    else
+        rc = elbo_run<double, double>(T, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums2, info,
+                                      w + E.off_fused, E.L, st, nullptr, lb);
+    if (rc) return rc;
+    if ((rc = dpgp_psi1_f64(T, N, M, Q, z, mu, s, gamma, alpha, p1, stream))) return rc - 100;
+    // V_t[m][d] = sum_n Psi1_t[n][m] y[n][d]
+    if ((rc = launch_gemm_splitk_f64(T, M, D, N, p1, (long long)N * M, 1, M, y, 0, ldy, 1, vp, (long long)M * D, D, 1, E.ksplit,
+                                     (long long)T * M * D, st)))
+        return rc - 200;
+    if ((rc = launch_tcols_quad(T, M, D, lb, vp, E.ksplit, (long long)T * M * D, beta, quad, st))) return rc;
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(fhat_t_combine_kernel, dim3(1), dim3(256), 0, st, T, D, N, terms, phit, quad, yy, beta, sums2, per_t, sums,
+                       phi_st, phi_sd, model_scal, model_pack, model_out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
 // HIP events for callers that have no HIP runtime binding of their own (bench.py times the psi2 kernel with these).
 extern "C" void *dpgp_event_create(void) {
     hipEvent_t e = nullptr;
@@ -345,7 +472,9 @@ __global__ __launch_bounds__(256) void model_prepare_kernel(
     const double *__restrict__ s_raw, const double *__restrict__ g1_raw, const double *__restrict__ g2_raw,
     const double *__restrict__ w_raw, double s1, double s2, int add_constants, double *__restrict__ gamma,
     double *__restrict__ alpha, double *__restrict__ beta, double *__restrict__ s_out, double *__restrict__ phi_out,
-    double *__restrict__ scal) {
+    double *__restrict__ scal, double *__restrict__ atoms_out) {
+    // (atoms_out, optional: softplus of the atoms, [T*Q gamma | T alpha | T beta] — the over-T model works on the atoms themselves
+    //  and passes gamma = alpha = beta = nullptr)
     const int t = threadIdx.x;
     __shared__ double scratch[8];
     if ((int)blockIdx.x > nrb) {   // q(X) variances: s = softplus(raw)   (dp_gp_lvm.py:67-69, utils/types.py:40-57)
@@ -359,7 +488,8 @@ __global__ __launch_bounds__(256) void model_prepare_kernel(
         double hyper = 0.0, consts = 0.0;
         for (int i = t; i < T * Q + 2 * T; i += 256) {
             const double raw = i < T * Q ? gat_raw[i] : (i < T * Q + T ? aat_raw[i - T * Q] : bat_raw[i - T * Q - T]);
-            const double lx = log(softplus_d(raw));
+            const double sp = softplus_d(raw), lx = log(sp);
+            if (atoms_out) atoms_out[i] = sp;
             hyper += -lx - 0.5 * (DPGP_LOG_2PI + lx * lx);        // log_normal.log_pdf (log_normal.py:34-39)
         }
         const double w1 = softplus_d(w_raw[0]), w2 = softplus_d(w_raw[1]);
@@ -429,6 +559,7 @@ __global__ __launch_bounds__(256) void model_prepare_kernel(
         const double lz = log(zsum);
         if (j < Q) {                                                     // mixing (dp_gp_lvm.py:100)
             double g = 0.0;
+            if (!gamma) continue;
             for (int k = 0; k < T; ++k) g += exp(lr[k] - mx - lz) * gat[k * Q + j];
             gamma[(size_t)d * Q + j] = g;
         } else {
@@ -442,8 +573,8 @@ __global__ __launch_bounds__(256) void model_prepare_kernel(
                 if (k < T - 1) ev += p * c1[k] + tail * c2[k];           // E[log p(Z|V)] (:64-66); tail = sum_{j>k} phi_dj
                 tail += p;
             }
-            alpha[d] = al;                                               // (dp_gp_lvm.py:101-102)
-            beta[d] = be;
+            if (alpha) alpha[d] = al;                                    // (dp_gp_lvm.py:101-102)
+            if (beta) beta[d] = be;
             dsum += ev + ent;
         }
     }
@@ -675,12 +806,11 @@ extern "C" int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offs
 
 extern "C" int dpgp_model_scal_count(int D) { return D > 0 ? 2 + dpgp_ceil_div(D, PREP_ROWS) : 0; }
 
-extern "C" int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
-                                  const double *gamma_atoms_raw, const double *alpha_atoms_raw,
-                                  const double *beta_atoms_raw, const double *s_raw, const double *g1_raw,
-                                  const double *g2_raw, const double *w_raw, double s1, double s2, int add_constants,
-                                  double *gamma, double *alpha, double *beta, double *s, double *phi, double *scal,
-                                  void *stream) {
+static int model_prepare_run(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
+                             const double *gamma_atoms_raw, const double *alpha_atoms_raw, const double *beta_atoms_raw,
+                             const double *s_raw, const double *g1_raw, const double *g2_raw, const double *w_raw, double s1,
+                             double s2, int add_constants, double *gamma, double *alpha, double *beta, double *s, double *phi,
+                             double *scal, double *atoms, void *stream) {
     if (D <= 0) return -1;
     if (T <= 0 || T > PREP_MAX_T) return -2;
     if (Q <= 0 || Q > DPGP_MAX_Q) return -3;
@@ -696,9 +826,6 @@ extern "C" int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int 
     if (!w_raw) return -14;
     if (!(s1 > 0.0)) return -15;
     if (!(s2 > 0.0)) return -16;
-    if (!gamma) return -18;
-    if (!alpha) return -19;
-    if (!beta) return -20;
     if (!s) return -21;
     if (!scal) return -23;
     const int nrb = dpgp_ceil_div(D, PREP_ROWS);
@@ -706,9 +833,32 @@ extern "C" int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int 
     if (sblocks > 512) sblocks = 512;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_prepare_kernel, dim3(1 + nrb + sblocks), dim3(256), 0, (hipStream_t)stream, D, T, Q, N,
                        d_offset, mask_size, nrb, logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw, g1_raw,
-                       g2_raw, w_raw, s1, s2, add_constants, gamma, alpha, beta, s, phi, scal);
+                       g2_raw, w_raw, s1, s2, add_constants, gamma, alpha, beta, s, phi, scal, atoms);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
+}
+extern "C" int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
+                                  const double *gamma_atoms_raw, const double *alpha_atoms_raw,
+                                  const double *beta_atoms_raw, const double *s_raw, const double *g1_raw,
+                                  const double *g2_raw, const double *w_raw, double s1, double s2, int add_constants,
+                                  double *gamma, double *alpha, double *beta, double *s, double *phi, double *scal,
+                                  void *stream) {
+    if (!gamma) return -18;
+    if (!alpha) return -19;
+    if (!beta) return -20;
+    return model_prepare_run(D, T, Q, N, d_offset, mask_size, logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw,
+                             g1_raw, g2_raw, w_raw, s1, s2, add_constants, gamma, alpha, beta, s, phi, scal, nullptr, stream);
+}
+// the same launch for the over-T model (dp_gp_lvm_t): no mixing; phi[D,T] and the softplus of the atoms are the outputs
+extern "C" int dpgp_model_prepare_t(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
+                                    const double *gamma_atoms_raw, const double *alpha_atoms_raw,
+                                    const double *beta_atoms_raw, const double *s_raw, const double *g1_raw,
+                                    const double *g2_raw, const double *w_raw, double s1, double s2, int add_constants,
+                                    double *s, double *phi, double *atoms, double *scal, void *stream) {
+    if (!phi) return -22;
+    if (!atoms) return -24;
+    return model_prepare_run(D, T, Q, N, d_offset, mask_size, logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw,
+                             g1_raw, g2_raw, w_raw, s1, s2, add_constants, nullptr, nullptr, nullptr, s, phi, scal, atoms, stream);
 }
 
 extern "C" int dpgp_model_pack(int D, const double *fhat, const double *scal, double *pack, void *stream) {

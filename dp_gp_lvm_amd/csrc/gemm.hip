@@ -38,23 +38,27 @@ __global__ __launch_bounds__(256, 2) void gemm_strided_f64_kernel(int batch, int
                                                                   long long a_sk, const double *__restrict__ b, long long b_sb,
                                                                   long long b_sk, long long b_sj, double beta,
                                                                   double *__restrict__ c, long long c_sb, long long c_si,
-                                                                  long long c_sj) {
+                                                                  long long c_sj, int ksplit, long long c_ss) {
     __shared__ __align__(16) double As[GM_T * GM_LD], Bs[GM_T * GM_LD];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
     const int i0 = GM_T * blockIdx.y, j0 = GM_T * blockIdx.x;
     const bool a_kfast = (a_sk == 1), b_kfast = (b_sk == 1);
-    for (int bi = blockIdx.z; bi < batch; bi += gridDim.z) {
+    // ksplit > 1 (internal callers only): the k range in ksplit pieces, piece ks of batch element bi into c + ks c_ss (beta = 0)
+    const int kchunk = ksplit > 1 ? GM_KC * ((k + ksplit * GM_KC - 1) / (ksplit * GM_KC)) : k;
+    for (int bz = blockIdx.z; bz < batch * ksplit; bz += gridDim.z) {
+        const int bi = bz / ksplit, ks_ = bz - bi * ksplit;
+        const int kbeg = ks_ * kchunk, kend = min(k, kbeg + kchunk);
         const double *ab = a + (long long)bi * a_sb, *bb = b + (long long)bi * b_sb;
-        double *cb = c + (long long)bi * c_sb;
+        double *cb = c + (long long)bi * c_sb + (long long)ks_ * c_ss;
         f64x4 acc[4];
 #pragma unroll
         for (int J = 0; J < 4; ++J) acc[J] = (f64x4){0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < k; k0 += GM_KC) {
+        for (int k0 = kbeg; k0 < kend; k0 += GM_KC) {
             __syncthreads();
-            if (a_kfast) gm_stage<true>(ab, a_si, a_sk, i0, m, k0, k, As);
-            else gm_stage<false>(ab, a_si, a_sk, i0, m, k0, k, As);
-            if (b_kfast) gm_stage<true>(bb, b_sj, b_sk, j0, n, k0, k, Bs);
-            else gm_stage<false>(bb, b_sj, b_sk, j0, n, k0, k, Bs);
+            if (a_kfast) gm_stage<true>(ab, a_si, a_sk, i0, m, k0, kend, As);
+            else gm_stage<false>(ab, a_si, a_sk, i0, m, k0, kend, As);
+            if (b_kfast) gm_stage<true>(bb, b_sj, b_sk, j0, n, k0, kend, Bs);
+            else gm_stage<false>(bb, b_sj, b_sk, j0, n, k0, kend, Bs);
             __syncthreads();
 #pragma unroll
             for (int ks = 0; ks < GM_KC / 4; ++ks) {
@@ -91,7 +95,21 @@ extern "C" int dpgp_gemm_strided_f64(int batch, int m, int n, int k, double alph
     CHECK_ARG(grid.y <= 65535u, 2);
     DPGP_PRELAUNCH();
     hipLaunchKernelGGL(gemm_strided_f64_kernel, grid, dim3(256), 0, (hipStream_t)stream, batch, m, n, k, alpha, a, a_sb, a_si,
-                       a_sk, b, b_sb, b_sk, b_sj, beta, c, c_sb, c_si, c_sj);
+                       a_sk, b, b_sb, b_sk, b_sj, beta, c, c_sb, c_si, c_sj, 1, 0LL);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
+// internal: the k range in ksplit pieces, each into its own slab c + ks c_ss (beta = 0; the consumer adds the slabs) — a product
+// with few output tiles and a long k (Psi1^T Y of the over-T model: 8 x 128 x 512 outputs, k = N = 2000) fills the GPU this way
+int launch_gemm_splitk_f64(int batch, int m, int n, int k, const double *a, long long a_sb, long long a_si, long long a_sk,
+                           const double *b, long long b_sb, long long b_sk, long long b_sj, double *c, long long c_sb,
+                           long long c_si, long long c_sj, int ksplit, long long c_ss, hipStream_t st) {
+    if (batch < 1 || m < 1 || n < 1 || k < 1 || ksplit < 1 || (long long)batch * ksplit > 65535) return -1;
+    const dim3 grid(dpgp_ceil_div(n, GM_T), dpgp_ceil_div(m, GM_T), batch * ksplit);
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(gemm_strided_f64_kernel, grid, dim3(256), 0, st, batch, m, n, k, 1.0, a, a_sb, a_si, a_sk, b, b_sb, b_sk,
+                       b_sj, 0.0, c, c_sb, c_si, c_sj, ksplit, c_ss);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }

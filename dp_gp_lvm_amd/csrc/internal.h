@@ -63,7 +63,9 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
                    const double *alpha, const double *beta, const double *yy_part, const double *logdet_k,
                    const int *info_k, double *terms, int *info, double *guard, TL *ws, int algo, hipStream_t st,
                    const double *kl_part = nullptr, double *sums = nullptr, const double *model_scal = nullptr,
-                   double *model_pack = nullptr, double *model_out = nullptr);
+                   double *model_pack = nullptr, double *model_out = nullptr, TL *lb_out = nullptr);
+// lb_out != nullptr (LDS-resident sizes only, -30 otherwise): also the factors L_B as the LDS image of their lower tiles,
+// lb_out[D][nb (nb + 1) / 2][16][17] (linalg_dev.h: TSZ, LDT)
 // sums != nullptr: the workgroup that finishes last also runs the reduction of launch_sum_terms (same arguments; the arrival
 // counter is the int behind kl_part[DPGP_KL_NBLK], zeroed by launch_elbo_front / launch_kl_yy on the same stream)
 // sums[0] = sum of terms (f_hat); sums[1] = KL from the DPGP_KL_NBLK partials (kl_part may be null: sums[1] untouched)
@@ -82,6 +84,14 @@ int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st, si
 // result (X is scratch afterwards: its last 128 rows are not stored)
 int launch_ptrsm_persist(int B, int Mw, const double *l, size_t lstride, double *x, size_t xstride, double *nrm2,
                          size_t nstride, hipStream_t st);
+// quad[t][d] = scale[t]^2 |L_t^-1 v_td|^2 for the D columns of V_t = sum of nsl slabs vp[ks v_ss + (t M + r) D + d]; M <= 128,
+// lb: the lb_out image of launch_chain_b
+int launch_tcols_quad(int T, int M, int D, const double *lb, const double *vp, int nsl, long long v_ss, const double *scale,
+                      double *quad, hipStream_t st);
+// gemm.hip: split-k form of dpgp_gemm_strided_f64 (slab ks of the product into c + ks c_ss, alpha = 1, beta = 0)
+int launch_gemm_splitk_f64(int batch, int m, int n, int k, const double *a, long long a_sb, long long a_si, long long a_sk,
+                           const double *b, long long b_sb, long long b_sk, long long b_sj, double *c, long long c_sb,
+                           long long c_si, long long c_sj, int ksplit, long long c_ss, hipStream_t st);
 // ---- chain_big.hip: the dense chain of the fused ELBO for M > 128 in fp64 (one persistent workgroup per output dim and step)
 bool chain_big_applicable(int D, int M, int elem);
 size_t chain_big_ws_elems(int M);                        // per output dim, doubles (layout: chain_big.hip)
@@ -127,6 +137,7 @@ size_t psi2_grad_part_elems(int B, int N, int M, int Q);
 int launch_psi2_grad(int B, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
                      const double *gamma, const double *alpha, const double *GP, double *part, double *stage, double *dmu,
                      double *ds, double *dz, double *dgamma, hipStream_t st);
+#define DPGP_LB_TILE_ELEMS (16 * 17)   // elements of one tile of the lb_out image (= TSZ of linalg_dev.h)
 #define DPGP_PREP_ROWS 16   // output dims per row-block of dpgp_model_prepare (scal has 2 + ceil(D / 16) entries)
 
 // ---- psi2_pairs_grad.hip: the Psi2 term of stage B in the pair-tile form (Q <= 10) ---------------------------------------

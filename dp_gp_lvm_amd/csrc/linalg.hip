@@ -33,6 +33,7 @@ extern "C" void dpgp_debug_stamps(long long *out) { (void)hipMemcpyFromSymbol(ou
 #define SUB_END(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 1) g_chain_stamps[(i) + k] += __builtin_amdgcn_s_memtime() - ts__; } while (0)
 #endif
 #include "linalg_dev.h"
+static_assert(TSZ == DPGP_LB_TILE_ELEMS, "lb_out image: tile size");
 
 // ---------------------------------------------------------------------------------------------------------------
 // Per-output workspace (elements of TL), see la_chain_ws_elems:
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
                                                       int *__restrict__ info, double *__restrict__ guard,
                                                       TL *__restrict__ ws, size_t ws_stride, int mode,
                                                       const double *kl_part, double *sums, const double *model_scal,
-                                                      double *model_pack, double *model_out) {
+                                                      double *model_pack, double *model_out, TL *lb_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *scratch = reinterpret_cast<double *>(smem_raw);
     int &fail = *reinterpret_cast<int *>(smem_raw + 64);
@@ -212,6 +213,10 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
     }
     __syncthreads();
     STAMP(2);
+    // the over-T model solves L_B against all D columns of Psi1^T Y afterwards (elbo_t.hip): it gets the factor as the LDS image
+    // of its lower tiles [nb (nb + 1) / 2][16][LDT], verbatim
+    if (lb_out && mode == 0)
+        for (int e = t; e < nlow * TSZ; e += 256) lb_out[(size_t)d * nlow * TSZ + e] = tiles[e];
     double ld = 0.0, cc = 0.0;
     for (int i = t; i < M; i += 256) {
         const int I = i >> 4, r = i & 15;
@@ -298,7 +303,8 @@ template <typename TP, typename TL>
 int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const double *v_part, int ns1,
                    const double *alpha, const double *beta, const double *yy_part, const double *logdet_k,
                    const int *info_k, double *terms, int *info, double *guard, TL *ws, int algo, hipStream_t st,
-                   const double *kl_part, double *sums, const double *model_scal, double *model_pack, double *model_out) {
+                   const double *kl_part, double *sums, const double *model_scal, double *model_pack, double *model_out,
+                   TL *lb_out) {
     const int Mp = dpgp_round_up(M, 16);
     int mode = 2;
     size_t lds = la_lds_bytes(Mp, sizeof(TL));
@@ -307,6 +313,7 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
         mode = need <= LA_LDS_LIMIT ? 0 : 1;
         if (mode == 0) lds = need;
     }
+    if (lb_out && mode != 0) return -30;                       // (the factor is only exported from the LDS-resident form)
     const bool two = (mode == 0) && lds <= 80 * 1024;
     auto kern = two ? chain_b_kernel<TP, TL, 2> : chain_b_kernel<TP, TL, 1>;
     if (lds > 48 * 1024 &&
@@ -315,7 +322,7 @@ int launch_chain_b(int D, int N, int M, const TP *psi2_part, int ns2, const doub
         return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(D), dim3(256), lds, st, D, N, M, Mp, psi2_part, ns2, v_part, ns1, alpha, beta, yy_part,
                        logdet_k, info_k, terms, info, guard, ws, la_chain_ws_elems(M), mode, kl_part, sums, model_scal, model_pack,
-                       model_out);
+                       model_out, lb_out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
@@ -333,7 +340,7 @@ extern "C" int dpgp_debug_chain_b_occupancy(int Mp, int extra) {
     template int launch_chain_b<TP, TL>(int, int, int, const TP *, int, const double *, int, const double *,      \
                                         const double *, const double *, const double *, const int *, double *, int *, \
                                         double *, TL *, int, hipStream_t, const double *, double *, const double *, double *, \
-                                        double *);
+                                        double *, TL *);
 INST_CHAIN_B(float, float)
 INST_CHAIN_B(float, double)
 INST_CHAIN_B(double, double)

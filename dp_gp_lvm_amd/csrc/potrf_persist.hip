@@ -473,6 +473,93 @@ int launch_ptrsm_persist(int B, int Mw, const double *l, size_t lstride, double 
     return DPGP_OK;
 }
 
+// ---- c = L_t^-1 V_t for all D columns of V_t (the over-T model, dp_gp_lvm.py:657-667: every atom t is solved against all
+// columns of Psi1_t^T Y) and quad[t][d] = scale_t^2 |c_td|^2.  M <= 128; L_t arrives as the LDS image of its lower tiles
+// (chain_b_kernel, lb_out), V_t as nsl slabs of a split-k product.  Workgroup = (64 columns, t), wave = 16 columns: the
+// register-chained left solve of pp_trsm_tile on a [16 columns][128 rows] staging tile, as in ptrsm_persistent_kernel (c).
+__global__ __launch_bounds__(256) void tcols_quad_kernel(int M, int Mp, int D, const double *__restrict__ lb,
+                                                         const double *__restrict__ vp, int nsl, long long v_ss,
+                                                         const double *__restrict__ scale, double *__restrict__ quad) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *tiles = reinterpret_cast<double *>(smem_raw + LA_LDS_HDR);
+    double *linv = tiles + (size_t)TSZ * (PP_NT * (PP_NT + 1) / 2);
+    double *stage = linv + (size_t)TSZ * PP_NT;
+    const int t = threadIdx.x, lane = t & 63, kk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int at = blockIdx.y, nb = Mp / 16, nlow = nb * (nb + 1) / 2;
+    const double *lt = lb + (size_t)at * nlow * TSZ;
+    for (int e = t; e < PP_NT * (PP_NT + 1) / 2 * TSZ; e += 256) {
+        double v;
+        if (e < nlow * TSZ) {
+            v = lt[e];
+        } else {                                                   // identity padding up to 128 rows
+            const int tt = e / TSZ, r = (e - tt * TSZ) / LDT, c = e - tt * TSZ - r * LDT;
+            int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+            while (I * (I + 1) / 2 > tt) --I;
+            v = (tt == I * (I + 1) / 2 + I && r == c) ? 1.0 : 0.0;
+        }
+        tiles[e] = v;
+    }
+    __syncthreads();
+    if (wv < 2) {
+        const int c = 4 * wv + kk;
+        tri_inverse_dpp<double>(tiles + lds_tile_index(c, c, PP_NT) * TSZ, linv + c * TSZ, LDT, lane);
+    }
+    __syncthreads();
+    const int col0 = 64 * blockIdx.x + 16 * wv;
+    if (col0 >= D) return;
+    const int r0 = lane >> 3, c2 = (lane & 7) * 2;
+    double *S = stage + (size_t)wv * 16 * PP_SLD;
+    const double *vt = vp + (size_t)at * M * D;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = r0 + 8 * q;
+        double a0 = 0.0, a1 = 0.0;
+        if (r < M) {
+            for (int ks = 0; ks < nsl; ++ks) {
+                const double *row = vt + (long long)ks * v_ss + (size_t)r * D + col0 + c2;
+                if (col0 + c2 < D) a0 += row[0];
+                if (col0 + c2 + 1 < D) a1 += row[1];
+            }
+        }
+        S[c2 * PP_SLD + r] = a0;
+        S[(c2 + 1) * PP_SLD + r] = a1;
+    }
+    pp_trsm_tile(S, tiles, linv, lane);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const double x0 = S[c2 * PP_SLD + r0 + 8 * q], x1 = S[(c2 + 1) * PP_SLD + r0 + 8 * q];
+        s0 += x0 * x0;
+        s1 += x1 * x1;
+    }
+#pragma unroll
+    for (int o = 8; o <= 32; o <<= 1) {
+        s0 += __shfl_xor(s0, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+    }
+    if (r0 == 0) {
+        const double sc = scale[at] * scale[at];
+        if (col0 + c2 < D) quad[(size_t)at * D + col0 + c2] = sc * s0;
+        if (col0 + c2 + 1 < D) quad[(size_t)at * D + col0 + c2 + 1] = sc * s1;
+    }
+}
+
+int launch_tcols_quad(int T, int M, int D, const double *lb, const double *vp, int nsl, long long v_ss, const double *scale,
+                      double *quad, hipStream_t st) {
+    const int Mp = dpgp_round_up(M, 16);
+    if (Mp > PP_PW) return -30;
+    const size_t lds = pp_lds_bytes();
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(tcols_quad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return DPGP_ERR_LAUNCH;
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(tcols_quad_kernel, dim3(dpgp_ceil_div(D, 64), T), dim3(256), lds, st, M, Mp, D, lb, vp, nsl, v_ss, scale, quad);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
 bool potrf_persist_applicable(int B, int M, int elem_size) { return elem_size == 8 && M > 128 && B >= 128; }
 
 int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st, size_t wstride) {

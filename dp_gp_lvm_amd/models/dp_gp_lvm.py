@@ -12,6 +12,7 @@ Multi-GPU: the per-output-dimension terms are independent given (q(X), Z, atoms)
 ranks of ``process_group`` (rank r keeps columns r*D/W .. (r+1)*D/W of Y and the matching rows of phi); q(X), Z and the
 atoms are replicated.  The only exchange per evaluation is a sum all-reduce of the two scalars (f_hat, DP objective).
 """
+import os
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -621,6 +622,11 @@ def dp_gp_lvm_t(y_train,
     n_, d_, m_ = num_samples, d_hi - d_lo, num_inducing_points             # (d_: the LOCAL output dims; the sums over d are local)
     mp_ = 16 * ((m_ + 15) // 16)
     last_info = [torch.zeros((), dtype=torch.int32, device=device)]
+    # the fused forward pass (csrc/elbo.hip, dpgp_elbo_fhat_t): M <= 128 and at least T local output dims; otherwise, and
+    # whenever gradients are wanted, f_hat is composed of the library's operators (_FHatT)
+    fused_t = ops.ElboTWorkspace(truncation_level, d_, n_, m_, num_latent_dims, precision, device) \
+        if (ops.elbo_fhat_t_supported(m_) and d_ >= truncation_level and device.type == 'cuda'
+            and os.environ.get('DPGP_FUSED_T', '1') != '0') else None       # (DPGP_FUSED_T=0: cross-checks only)
 
     def _chain(x_u_, x_mean_, s_, gat, aat, bat):
         """Psi statistics and the Cholesky factors of the T atoms (library operators)."""
@@ -711,8 +717,9 @@ def dp_gp_lvm_t(y_train,
         phi = torch.softmax(r['dp_logits'], dim=-1)
         if mask_size != 1:
             phi = torch.repeat_interleave(phi, mask_size, dim=0)
-        f_hat = _FHatT.apply(r['x_mean'], s, r['x_u'], gat, aat, bat, phi[d_lo:d_hi].transpose(0, 1).contiguous())   # local dims
+        phit = phi[d_lo:d_hi].transpose(0, 1).contiguous()                                        # local dims
         mu = r['x_mean']
+        f_hat = _FHatT.apply(mu, s, r['x_u'], gat, aat, bat, phit)
         kl = 0.5 * (torch.sum(mu * mu) + torch.sum(s - torch.log(s)) - mu.shape[0] * mu.shape[1])     # gp_expressions.py:10-24
         hyper = torch.sum(log_normal_log_pdf(gat)) + torch.sum(log_normal_log_pdf(aat)) + torch.sum(log_normal_log_pdf(bat))
         w = F.softplus(r['dp_w'])
@@ -730,9 +737,46 @@ def dp_gp_lvm_t(y_train,
             out = torch.stack([out[3] - (f_tot - out[2]) - out[4], f_tot, out[2], out[3], out[4]])
         return out
 
+    tbuf = {}
+    if fused_t is not None:
+        t_, q_ = truncation_level, num_latent_dims
+        tbuf = dict(s=torch.empty((n_, q_), dtype=TORCH_DTYPE, device=device),
+                    phi=torch.empty((d_, t_), dtype=TORCH_DTYPE, device=device),
+                    atoms=torch.empty(t_ * q_ + 2 * t_, dtype=TORCH_DTYPE, device=device),
+                    scal=torch.zeros(_lib.lib().dpgp_model_scal_count(d_), dtype=TORCH_DTYPE, device=device),
+                    red=torch.zeros(2, dtype=TORCH_DTYPE, device=device), out=torch.zeros(5, dtype=TORCH_DTYPE, device=device))
+
+    def _evaluate_fused(finish=True):
+        """dpgp_model_prepare_t -> dpgp_elbo_fhat_t (the model-level tail rides in its last launch) -> [one packed all-reduce
+        and dpgp_model_finalize when D is sharded]: eleven launches, no host arithmetic (round 2: ~200 launches of library
+        operators and torch element-wise kernels)."""
+        lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+        r = dp_model.raw
+        t_, q_ = truncation_level, num_latent_dims
+        _lib.check(lib.dpgp_model_prepare_t(
+            d_, t_, q_, n_, d_lo, mask_size, r['logits'].data_ptr(), gamma_atoms_raw.data_ptr(), sig_var_atoms_raw.data_ptr(),
+            beta_atoms_raw.data_ptr(), x_var_raw.data_ptr(), r['gamma_1'].data_ptr(), r['gamma_2'].data_ptr(), r['w'].data_ptr(),
+            s_1, s_2, 1 if rank == 0 else 0, tbuf['s'].data_ptr(), tbuf['phi'].data_ptr(), tbuf['atoms'].data_ptr(),
+            tbuf['scal'].data_ptr(), st), 'dpgp_model_prepare_t')
+        at = tbuf['atoms']
+        _, _, sums_t, info_t = ops.elbo_fhat_t(
+            y_dev, yy, x_u, x_mean, tbuf['s'], at[:t_ * q_].view(t_, q_), at[t_ * q_:t_ * q_ + t_], at[t_ * q_ + t_:],
+            tbuf['phi'].t(), jitter=GP_DEFAULT_JITTER, prec=precision, workspace=fused_t,
+            model_tail=(tbuf['scal'], tbuf['red'], None if sharded else tbuf['out']))
+        last_info[0] = info_t.abs().max()
+        return _finish_fused() if finish else tbuf['out']
+
+    def _finish_fused():
+        if sharded:
+            lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+            dist.all_reduce(tbuf['red'], op=dist.ReduceOp.SUM, group=process_group)     # (f_hat, DP objective): 2 fp64 scalars
+            _lib.check(lib.dpgp_model_finalize(tbuf['red'].data_ptr(), fused_t.sums[1:2].data_ptr(),
+                                               tbuf['scal'][1:2].data_ptr(), tbuf['out'].data_ptr(), st), 'dpgp_model_finalize')
+        return tbuf['out']
+
     def evaluate():
         with torch.no_grad():
-            out = _exchange(_objective_of(raw_vars))
+            out = _evaluate_fused() if fused_t is not None else _exchange(_objective_of(raw_vars))
         return out, last_info[0]
 
     graph = {}
@@ -752,9 +796,11 @@ def dp_gp_lvm_t(y_train,
             g_ = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_):
                 with torch.no_grad():
-                    graph['out'] = _objective_of(raw_vars)
+                    graph['out'] = _evaluate_fused(finish=False) if fused_t is not None else _objective_of(raw_vars)
             graph['g'] = g_
         graph['g'].replay()
+        if fused_t is not None:
+            return _finish_fused().clone()
         return _exchange(graph['out'].clone())              # (the all-reduce of a sharded model runs eagerly behind the replay)
 
     def _gradients():

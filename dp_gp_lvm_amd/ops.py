@@ -301,6 +301,60 @@ def elbo_fhat(y, z, mu, s, gamma, alpha, beta, jitter=1e-8, prec='mixed', algo='
     return w.terms, w.sums, w.info
 
 
+class ElboTWorkspace:
+    """Device buffers of ``elbo_fhat_t`` for one problem shape (allocated once, reused by every evaluation)."""
+
+    def __init__(self, t, d, n, m, q, prec, device):
+        nbytes = int(_lib.lib().dpgp_elbo_fhat_t_workspace_bytes(t, d, n, m, q, _lib.PREC[prec]))
+        if nbytes == 0:
+            raise ValueError('elbo_fhat_t: unsupported shape / precision (T=%d D=%d N=%d M=%d Q=%d %s)' % (t, d, n, m, q, prec))
+        self.shape, self.prec, self.nbytes = (t, d, n, m, q), prec, nbytes
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.per_t = torch.empty(t, dtype=torch.float64, device=device)
+        self.quad = torch.empty((t, d), dtype=torch.float64, device=device)
+        self.sums = torch.empty(2, dtype=torch.float64, device=device)
+        self.info = torch.empty(t, dtype=torch.int32, device=device)
+
+
+def elbo_fhat_t_supported(m):
+    """dpgp_elbo_fhat_t keeps the factors L_B,t in LDS (first version): M <= 128."""
+    return 16 * ((int(m) + 15) // 16) <= 128
+
+
+def elbo_fhat_t(y, yy, z, mu, s, gamma_atoms, alpha_atoms, beta_atoms, phit, jitter=1e-8, prec='mixed', workspace=None,
+                model_tail=None):
+    """
+    f_hat of the over-T model (reference dp_gp_lvm.py:608-676) for the D output dims in ``y`` [N,D]: T atoms, each solved against
+    all D columns, weighted by ``phit`` [T,D] (any strides: phi[D,T].t() is read in place).  ``yy`` [D] = column sums of y^2.
+    All inputs fp64 device tensors.  model_tail = (scal, pack, out) as for ``elbo_fhat``.
+    Returns (per_t [T], quad [T,D], sums [2] = (f_hat, KL), info [T]) — device tensors, no host synchronisation (nine launches).
+    """
+    f64 = torch.float64
+    z, mu, s = _prep(z, f64, 'z'), _prep(mu, f64, 'mu'), _prep(s, f64, 's')
+    gamma, alpha, beta, t = _hyp(gamma_atoms, alpha_atoms, beta_atoms, f64)
+    if not y.is_cuda:
+        raise RuntimeError('y must live on the GPU')
+    if y.dtype != f64 or y.stride(1) != 1:
+        y = y.to(f64).contiguous()
+    n, d = y.shape
+    m, q = z.shape
+    yy = _prep(yy, f64, 'yy').reshape(-1)
+    if not phit.is_cuda or phit.dtype != f64:
+        raise RuntimeError('phit must be an fp64 GPU tensor')
+    assert mu.shape == (n, q) and s.shape == (n, q) and gamma.shape == (t, q)
+    assert yy.numel() == d and phit.shape == (t, d), 'yy must be [D], phit [T x D]'
+    w = workspace if workspace is not None else ElboTWorkspace(t, d, n, m, q, prec, y.device)
+    assert w.shape == (t, d, n, m, q) and w.prec == prec, 'workspace was sized for another problem'
+    tail = (None, None, None) if model_tail is None else tuple(None if t_ is None else t_.data_ptr() for t_ in model_tail)
+    _lib.check(_lib.lib().dpgp_elbo_fhat_t(t, d, n, m, q, y.data_ptr(), y.stride(0), yy.data_ptr(), z.data_ptr(), mu.data_ptr(),
+                                           s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(), phit.data_ptr(),
+                                           phit.stride(0), phit.stride(1), float(jitter), _lib.PREC[prec], w.per_t.data_ptr(),
+                                           w.quad.data_ptr(), w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes,
+                                           _stream(), *tail),
+               'dpgp_elbo_fhat_t')
+    return w.per_t, w.quad, w.sums, w.info
+
+
 def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None):
     """Backward pass, stage A: adjoints of the per-output dense algebra from the workspace of a finished ``elbo_fhat`` call
     (dp_gp_lvm.py:108-145 differentiated; prec mixed / f64).  M <= 128: one HIP kernel per output dim with B in LDS

@@ -214,6 +214,26 @@ int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, 
                           const double *w_kuu, const double *g_v, const double *g_psi1, int prec, void *ws,
                           size_t ws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream);
 
+/* ---- f_hat of the over-T model dp_gp_lvm_t (reference: src/models/dp_gp_lvm.py:608-676; the [T,M,N] x [N,D] contraction at
+ * :657-658): T atoms with their own kernel hyper-parameters, every atom coupled to all D columns of y through phit[T,D].
+ *   inputs (fp64 device arrays): y[N,ldy], yy[D] = column sums of y^2, z[M,Q], mu[N,Q], s[N,Q], gamma[T,Q], alpha[T], beta[T],
+ *     phit: assignment probabilities phi_dt of the D output dims on this GPU, element strides below
+ *   outputs: per_t[T] = N/2 log beta_t + beta_t/2 (tr(L^-1 Psi2 L^-T) - alpha_t N) - sum log diag L_A,t,
+ *            quad[T,D] = beta_t^2 |L_A,t^-1 L^-1 Psi1_t^T y_d|^2,   sums[2] = { f_hat (of these D output dims), KL(q(X)||p(X)) },
+ *            info[T] (as for dpgp_elbo_fhat; a failed atom makes f_hat NaN)
+ *   prec: DPGP_PREC_MIXED (Psi2 on the fp32 matrix path) or DPGP_PREC_F64; Psi1, the contraction and the chain are fp64.
+ *   M <= 128 and T <= D (-30 / -2 otherwise: the host composes the same value from the operators above).
+ *   ws: dpgp_elbo_fhat_t_workspace_bytes(T,D,N,M,Q,prec).  Nine launches, no host synchronisation.                       */
+size_t dpgp_elbo_fhat_t_workspace_bytes(int T, int D, int N, int M, int Q, int prec);
+int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double *y, int ldy, const double *yy, const double *z,
+                     const double *mu, const double *s, const double *gamma, const double *alpha, const double *beta,
+                     const double *phit, long long phi_st, long long phi_sd, double jitter, int prec, double *per_t,
+                     double *quad, double *sums, int *info, void *ws, size_t ws_bytes, void *stream,
+                     const double *model_scal, double *model_pack, double *model_out);
+/*   phit is read as phit[t * phi_st + d * phi_sd] (phi[D,T] of dpgp_model_prepare_t: phi_st = 1, phi_sd = T).
+ *   model_scal / model_pack / model_out (each may be NULL): the model-level tail in the last launch, as dpgp_exec_t's fields
+ *   of the same names — model_scal = scal of dpgp_model_prepare_t for the same D output dims. */
+
 /* hipEvent helpers for hosts without their own HIP binding */
 void *dpgp_event_create(void);
 void dpgp_event_destroy(void *event);
@@ -239,6 +259,12 @@ int dpgp_model_prepare(int D, int T, int Q, int N, int d_offset, int mask_size, 
                        const double *s_raw, const double *g1_raw, const double *g2_raw, const double *w_raw, double s1,
                        double s2, int add_constants, double *gamma, double *alpha, double *beta, double *s, double *phi,
                        double *scal, void *stream);
+/* dpgp_model_prepare for the over-T model: no mixing; outputs s[N,Q], phi[D,T], atoms[T*Q + 2 T] = softplus of the atoms
+ * (gamma [T,Q] | alpha [T] | beta [T]) and scal as above. */
+int dpgp_model_prepare_t(int D, int T, int Q, int N, int d_offset, int mask_size, const double *logits,
+                         const double *gamma_atoms_raw, const double *alpha_atoms_raw, const double *beta_atoms_raw,
+                         const double *s_raw, const double *g1_raw, const double *g2_raw, const double *w_raw, double s1,
+                         double s2, int add_constants, double *s, double *phi, double *atoms, double *scal, void *stream);
 /* Model-level backward pass (first version): d objective / d (the reference's eleven raw trainable variables,
  * dp_gp_lvm.py:63-94, dirichlet_process.py:40-59) from d f_hat / d (mu, S, z, gamma, alpha, beta) of dpgp_elbo_grad_chain +
  * dpgp_elbo_grad_psi, for the D output dims resident on this GPU.  phi[D,T]: as written by dpgp_model_prepare.  Outputs are

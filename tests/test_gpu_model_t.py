@@ -51,6 +51,28 @@ def test_equal_atoms_known_answer(dev, fixture):
     np.testing.assert_allclose(o_d, o_t, rtol=1e-9)
 
 
+@pytest.mark.parametrize('shape', [(300, 70, 100, 5, 6), (513, 129, 128, 9, 8), (90, 8, 33, 2, 8)])
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_fused_forward_equals_the_composed_one(dev, shape, prec, monkeypatch):
+    """dpgp_elbo_fhat_t (csrc/elbo.hip: the fused reduction on the T atoms, Psi1^T Y as a split-k product, all D columns solved
+    against L_B,t in one kernel) against the same objective composed of the library's operators (DPGP_FUSED_T=0; the path the
+    gradients use, itself pinned to the reference above): ragged N, D not a multiple of 64, M = 100 / 128 / 33, T = D."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+    from dp_gp_lvm_amd.utils.synthetic import make_problem
+    n, d, m, q, t = shape
+    p = make_problem(shape=(n, d, m, q), truncation_level=t, seed=11)
+    init = dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']), gamma_atoms=p['gamma_atoms'],
+                alpha_atoms=p['alpha_atoms'], beta_atoms=p['beta_atoms'], gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'], w_2=p['w2'])
+    kw = dict(num_latent_dims=q, num_inducing_points=m, truncation_level=t, alpha_prior_params=np.array([p['s1'], p['s2']]),
+              device=dev, initial_values=init, precision=prec)
+    fused = dp_gp_lvm_t(p['y'], **kw).objective_terms.cpu().numpy()
+    monkeypatch.setenv('DPGP_FUSED_T', '0')
+    composed = dp_gp_lvm_t(p['y'], **kw).objective_terms.cpu().numpy()
+    # (the two evaluate algebraically different forms — B = K + beta Psi2 against A = I + beta L^-1 Psi2 L^-T: they part at
+    #  cond(K_uu) eps, 1e-9 for the 33 inducing points in two latent dims)
+    np.testing.assert_allclose(fused, composed, rtol=1e-8 if prec == 'f64' else 2e-6)
+
+
 def test_accessors_and_shapes(dev):
     from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
     rng = np.random.default_rng(3)
