@@ -21,17 +21,31 @@
 #define GM_KC 32
 #define GM_LD (GM_KC + 4)
 
-template <bool KFAST>
-__device__ __forceinline__ void gm_stage(const double *__restrict__ g, long long si, long long sk, int i0, int imax, int k0,
-                                         int kmax, double *__restrict__ s) {
-    for (int e = threadIdx.x; e < GM_T * GM_KC; e += 256) {
-        int i, k;
-        if (KFAST) { i = e / GM_KC; k = e % GM_KC; } else { k = e / GM_T; i = e % GM_T; }
-        double v = 0.0;
-        if (i0 + i < imax && k0 + k < kmax) v = g[(long long)(i0 + i) * si + (long long)(k0 + k) * sk];
-        s[i * GM_LD + k] = v;
+// one operand chunk [GM_T][GM_KC] in two halves: global -> registers (8 per thread, issued before the products of the
+// previous chunk so that their latency hides beneath the MFMAs), registers -> LDS after the barrier
+struct GmChunk {
+    double v[GM_T * GM_KC / 256];
+    __device__ __forceinline__ static void index(int e, bool kfast, int &i, int &k) {
+        if (kfast) { i = e / GM_KC; k = e % GM_KC; } else { k = e / GM_T; i = e % GM_T; }
     }
-}
+    __device__ __forceinline__ void load(const double *__restrict__ g, long long si, long long sk, int i0, int imax, int k0,
+                                         int kmax, bool kfast) {
+#pragma unroll
+        for (int u = 0; u < GM_T * GM_KC / 256; ++u) {
+            int i, k;
+            index((int)threadIdx.x + 256 * u, kfast, i, k);
+            v[u] = (i0 + i < imax && k0 + k < kmax) ? g[(long long)(i0 + i) * si + (long long)(k0 + k) * sk] : 0.0;
+        }
+    }
+    __device__ __forceinline__ void store(double *__restrict__ s, bool kfast) const {
+#pragma unroll
+        for (int u = 0; u < GM_T * GM_KC / 256; ++u) {
+            int i, k;
+            index((int)threadIdx.x + 256 * u, kfast, i, k);
+            s[i * GM_LD + k] = v[u];
+        }
+    }
+};
 
 __global__ __launch_bounds__(256, 2) void gemm_strided_f64_kernel(int batch, int m, int n, int k, double alpha,
                                                                   const double *__restrict__ a, long long a_sb, long long a_si,
@@ -53,13 +67,20 @@ __global__ __launch_bounds__(256, 2) void gemm_strided_f64_kernel(int batch, int
         f64x4 acc[4];
 #pragma unroll
         for (int J = 0; J < 4; ++J) acc[J] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        GmChunk ca, cb_;
+        if (kbeg < kend) {
+            ca.load(ab, a_si, a_sk, i0, m, kbeg, kend, a_kfast);
+            cb_.load(bb, b_sj, b_sk, j0, n, kbeg, kend, b_kfast);
+        }
         for (int k0 = kbeg; k0 < kend; k0 += GM_KC) {
             __syncthreads();
-            if (a_kfast) gm_stage<true>(ab, a_si, a_sk, i0, m, k0, kend, As);
-            else gm_stage<false>(ab, a_si, a_sk, i0, m, k0, kend, As);
-            if (b_kfast) gm_stage<true>(bb, b_sj, b_sk, j0, n, k0, kend, Bs);
-            else gm_stage<false>(bb, b_sj, b_sk, j0, n, k0, kend, Bs);
+            ca.store(As, a_kfast);
+            cb_.store(Bs, b_kfast);
             __syncthreads();
+            if (k0 + GM_KC < kend) {
+                ca.load(ab, a_si, a_sk, i0, m, k0 + GM_KC, kend, a_kfast);
+                cb_.load(bb, b_sj, b_sk, j0, n, k0 + GM_KC, kend, b_kfast);
+            }
 #pragma unroll
             for (int ks = 0; ks < GM_KC / 4; ++ks) {
                 const double av = As[(16 * wv + li) * GM_LD + 4 * ks + kk];

@@ -488,18 +488,28 @@ __global__ __launch_bounds__(256) void tcols_quad_kernel(int M, int Mp, int D, c
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int at = blockIdx.y, nb = Mp / 16, nlow = nb * (nb + 1) / 2;
     const double *lt = lb + (size_t)at * nlow * TSZ;
-    for (int e = t; e < PP_NT * (PP_NT + 1) / 2 * TSZ; e += 256) {
-        double v;
-        if (e < nlow * TSZ) {
-            v = lt[e];
-        } else {                                                   // identity padding up to 128 rows
-            const int tt = e / TSZ, r = (e - tt * TSZ) / LDT, c = e - tt * TSZ - r * LDT;
-            int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
-            while ((I + 1) * (I + 2) / 2 <= tt) ++I;
-            while (I * (I + 1) / 2 > tt) --I;
-            v = (tt == I * (I + 1) / 2 + I && r == c) ? 1.0 : 0.0;
+    {   // the image verbatim, 8 independent 16-byte loads in flight per thread (nlow TSZ is even, the image 16-byte aligned)
+        const pp_f2 *src = reinterpret_cast<const pp_f2 *>(lt);
+        const int npair = nlow * TSZ / 2;
+        for (int e0 = t; e0 < npair; e0 += 256 * 8) {
+            pp_f2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + 256 * u < npair) v[u] = src[e0 + 256 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + 256 * u < npair) {
+                    tiles[2 * (e0 + 256 * u)] = v[u][0];
+                    tiles[2 * (e0 + 256 * u) + 1] = v[u][1];
+                }
         }
-        tiles[e] = v;
+    }
+    for (int e = nlow * TSZ + t; e < PP_NT * (PP_NT + 1) / 2 * TSZ; e += 256) {      // identity padding up to 128 rows
+        const int tt = e / TSZ, r = (e - tt * TSZ) / LDT, c = e - tt * TSZ - r * LDT;
+        int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+        while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+        while (I * (I + 1) / 2 > tt) --I;
+        tiles[e] = (tt == I * (I + 1) / 2 + I && r == c) ? 1.0 : 0.0;
     }
     __syncthreads();
     if (wv < 2) {
@@ -512,19 +522,32 @@ __global__ __launch_bounds__(256) void tcols_quad_kernel(int M, int Mp, int D, c
     const int r0 = lane >> 3, c2 = (lane & 7) * 2;
     double *S = stage + (size_t)wv * 16 * PP_SLD;
     const double *vt = vp + (size_t)at * M * D;
+    // the slabs of the split-k product are added on the way in; all loads of a slab are issued before its sums
+    {
+        double a0[16], a1[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = r0 + 8 * q;
-        double a0 = 0.0, a1 = 0.0;
-        if (r < M) {
-            for (int ks = 0; ks < nsl; ++ks) {
-                const double *row = vt + (long long)ks * v_ss + (size_t)r * D + col0 + c2;
-                if (col0 + c2 < D) a0 += row[0];
-                if (col0 + c2 + 1 < D) a1 += row[1];
+        for (int q = 0; q < 16; ++q) a0[q] = a1[q] = 0.0;
+        const bool in0 = col0 + c2 < D, in1 = col0 + c2 + 1 < D;
+        for (int ks = 0; ks < nsl; ++ks) {
+            const double *sl = vt + (long long)ks * v_ss + col0 + c2;
+            double x0[16], x1[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = r0 + 8 * q;
+                x0[q] = (r < M && in0) ? sl[(size_t)r * D] : 0.0;
+                x1[q] = (r < M && in1) ? sl[(size_t)r * D + 1] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                a0[q] += x0[q];
+                a1[q] += x1[q];
             }
         }
-        S[c2 * PP_SLD + r] = a0;
-        S[(c2 + 1) * PP_SLD + r] = a1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            S[c2 * PP_SLD + r0 + 8 * q] = a0[q];
+            S[(c2 + 1) * PP_SLD + r0 + 8 * q] = a1[q];
+        }
     }
     pp_trsm_tile(S, tiles, linv, lane);
     double s0 = 0.0, s1 = 0.0;

@@ -763,7 +763,7 @@ def dp_gp_lvm_t(y_train,
             y_dev, yy, x_u, x_mean, tbuf['s'], at[:t_ * q_].view(t_, q_), at[t_ * q_:t_ * q_ + t_], at[t_ * q_ + t_:],
             tbuf['phi'].t(), jitter=GP_DEFAULT_JITTER, prec=precision, workspace=fused_t,
             model_tail=(tbuf['scal'], tbuf['red'], None if sharded else tbuf['out']))
-        last_info[0] = info_t.abs().max()
+        last_info[0] = info_t                 # (per atom; cholesky_info reduces it when asked: no launch per evaluation)
         return _finish_fused() if finish else tbuf['out']
 
     def _finish_fused():
@@ -882,7 +882,8 @@ def dp_gp_lvm_t(y_train,
 
         @property
         def cholesky_info(self):
-            return evaluate()[1]
+            info = evaluate()[1]
+            return info.abs().max() if info.dim() else info
 
         shard = (d_lo, d_hi)
 
