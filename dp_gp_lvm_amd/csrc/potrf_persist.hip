@@ -27,7 +27,7 @@
 #define PP_KLD (PP_KQ + 2)        // row stride of a staged chunk [128][PP_KLD]
 
 typedef double pp_f2 __attribute__((ext_vector_type(2)));
-#ifdef PP_STAMPS              // diagnostic build (scratch/build_persist_variant.sh stamps2 -DPP_STAMPS): phase clocks of workgroup 0
+#ifdef PP_STAMPS              // diagnostic build (scratch/build_variant.sh stamps2 potrf_persist.hip -DPP_STAMPS): phase clocks of workgroup 0
 __device__ long long g_pp_stamps[64];
 extern "C" void dpgp_debug_persist_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(long long) * 64); }
 #define PP_STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_pp_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
