@@ -173,12 +173,12 @@ __device__ __forceinline__ void pairs_group(int tb, pp_h8 (&bop)[GG][KS], int tb
             stage(c0, a0, bop[0], acc[1], c1);
         }
     } else {
-        pp_h8 a_cur[KS], a_nxt[KS];
-        load_a(a_cur, 0);
-        mma(c0, a_cur, bop[0]);
-#pragma unroll 1
-        for (int nt = 0; nt < ntile; ++nt) {
-            load_a(a_nxt, min(nt + 1, ntile - 1));
+        // (the row loop is unrolled twice so that the two operand buffers swap roles without register moves: the 16 v_mov of
+        //  a_cur = a_nxt were 7 % of the vector issue time of a row tile at G = 6)
+        pp_h8 a_0[KS], a_1[KS];
+        load_a(a_0, 0);
+        mma(c0, a_0, bop[0]);
+        auto row = [&](const pp_h8 (&a_cur)[KS], const pp_h8 (&a_nxt)[KS]) __attribute__((always_inline)) {
             if constexpr (GG == 1) {
                 stage(c1, a_nxt, bop[0], acc[0], c0);              // (behind the last row tile: one surplus MFMA chain)
                 c0 = c1;
@@ -190,8 +190,14 @@ __device__ __forceinline__ void pairs_group(int tb, pp_h8 (&bop)[GG][KS], int tb
                     else stage(c0, a_nxt, bop[0], acc[g + 1], c1);
                 }
             }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+        };
+#pragma unroll 1
+        for (int nt = 0; nt < ntile; nt += 2) {
+            load_a(a_1, min(nt + 1, ntile - 1));
+            row(a_0, a_1);
+            if (nt + 1 >= ntile) break;
+            load_a(a_0, min(nt + 2, ntile - 1));
+            row(a_1, a_0);
         }
     }
     if (tb_next >= 0) pairs_load<KS, GG, NW>(bop, tb_next, img, l5, half);
