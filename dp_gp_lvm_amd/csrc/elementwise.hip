@@ -23,6 +23,14 @@ __device__ __forceinline__ void gram_tile(int b, int i0, int j0, int N0, int N1,
     typedef T vec4 __attribute__((ext_vector_type(4)));
     T *xs = reinterpret_cast<T *>(smem_raw);          // [Q][64]
     T *zs = xs + GRAM_T * Q;                           // [Q][64]
+    // fp64: the table of dpgp_exp2_tab behind the tiles (64 doubles; callers size the LDS for it) — 12 instead of ~24 fp64
+    // operations per entry next to the 2 Q of the squared distance
+    const double *etab = nullptr;
+    if constexpr (sizeof(T) == 8) {
+        double *et = reinterpret_cast<double *>(zs + GRAM_T * Q);
+        dpgp_exp2_tab_init(et);
+        etab = et;
+    }
     const int t = threadIdx.x;
     const TIN *g = gamma + (size_t)b * Q;
     {   // fill: thread = (point r = t & 63, latent dims q = t >> 6, + 4, ...): no division, one square root per (thread, q)
@@ -68,7 +76,7 @@ __device__ __forceinline__ void gram_tile(int b, int i0, int j0, int N0, int N1,
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             int j = j0 + tx * 4 + c;
-            v[c] = al * dpgp_exp2(scale * acc[r][c]);
+            v[c] = al * dpgp_exp2_hot(scale * acc[r][c], etab);
             if ((symmetric & 1) && i == j) v[c] += diag_add;
         }
         int j = j0 + tx * 4;
@@ -104,7 +112,7 @@ int launch_gram(int B, int N0, int N1, int Q, const TIN *x0, const TIN *x1, cons
     const char *nt_ = getenv("DPGP_GRAM_NT");
     if (nt_ ? nt_[0] == '1' : (size_t)B * N0 * N1 * sizeof(T) > ((size_t)256 << 20)) sym |= 2;
     dim3 grid(dpgp_ceil_div(N1, GRAM_T), dpgp_ceil_div(N0, GRAM_T), B);
-    size_t lds = sizeof(T) * 2 * GRAM_T * Q;
+    size_t lds = sizeof(T) * 2 * GRAM_T * Q + (sizeof(T) == 8 ? sizeof(double) * DPGP_EXP2_TAB_ELEMS : 0);
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((gram_kernel<TIN, T>), grid, dim3(256), lds, st, N0, N1, Q, x0, x1, gamma, alpha, beta, flags,
                        (T)jitter, out, ld_out, batch_stride, sym);
     DPGP_LAUNCH_CHECK();
@@ -602,20 +610,36 @@ __global__ __launch_bounds__(256) void elbo_front_kernel(int N, int Q, const dou
     const int blk = (int)blockIdx.x;
 #ifdef FRONT_DIAG_SKIP             // (timing experiments only: wrong results) bit 0: KL / y'y / constants, 1: K_uu tiles, 2: scale table
     if ((FRONT_DIAG_SKIP & 1) && blk < first_gram_block) return;
-    if ((FRONT_DIAG_SKIP & 2) && blk >= first_gram_block && blk < first_scale_block) return;
-    if ((FRONT_DIAG_SKIP & 4) && blk >= first_scale_block) return;
+    // (bits 1 / 2 are tested where the interleaved blocks are told apart)
 #endif
     if (blk < first_gram_block) {
         kl_yy_block<double>(blk, N, Q, mu, s, kl_out, D, y, ldy, yy_out, z, M, consts, first_consts_block, scratch);
         return;
     }
-    if (blk >= first_scale_block) {                       // the pair-scale table of the pair-tile psi2 kernel (psi2_consts.h)
-        const int nb = (psi2_consts_layout(M, Q).Ppad + 255) / 256, sb = blk - first_scale_block;
-        const int dch = psi2_scale_dchunk(D), b0 = (sb / nb) * dch;
-        psi2_pair_scale_chunk<double, double>(b0, min(dch, D - b0), sb % nb, M, Q, z, gamma, alpha, pair_scale);
-        return;
+    // K_uu tiles (fp64 vector work) and scale-table blocks (gather, exp, 17 MB of stores at config 3) are INTERLEAVED in dispatch
+    // order: one after the other they took 22.9 + 20.9 us of the launch's 44 (scratch/front_roles.sh), neither filling the GPU's
+    // other half.  Position i of the ng + ns blocks is a scale block iff floor((i + 1) ns / (ng + ns)) > floor(i ns / (ng + ns)).
+    const int ng = first_scale_block - first_gram_block, nsb = (int)gridDim.x - first_scale_block;
+    int g = blk - first_gram_block;
+    if (nsb > 0) {
+        const long long T = (long long)ng + nsb;
+        const int c0 = (int)((long long)g * nsb / T), c1 = (int)((long long)(g + 1) * nsb / T);
+        if (c1 > c0) {                                    // the pair-scale table of the pair-tile psi2 kernel (psi2_consts.h)
+#ifdef FRONT_DIAG_SKIP
+            if (FRONT_DIAG_SKIP & 4) return;
+#endif
+            const int nb = (psi2_consts_layout(M, Q).Ppad + 255) / 256, sb = c0;
+            const int dch = psi2_scale_dchunk(D), b0 = (sb / nb) * dch;
+            psi2_pair_scale_chunk<double, double>(b0, min(dch, D - b0), sb % nb, M, Q, z, gamma, alpha, pair_scale,
+                                                  reinterpret_cast<float *>(smem_raw));   // (16 (Q + 1) floats of the launch's LDS)
+            return;
+        }
+        g -= c0;
     }
-    const int tm = (M + GRAM_T - 1) / GRAM_T, g = blk - first_gram_block, b = g / (tm * tm), r = g - b * tm * tm;
+#ifdef FRONT_DIAG_SKIP
+    if (FRONT_DIAG_SKIP & 2) return;
+#endif
+    const int tm = (M + GRAM_T - 1) / GRAM_T, b = g / (tm * tm), r = g - b * tm * tm;
     gram_tile<double, TL>(b, (r / tm) * GRAM_T, (r % tm) * GRAM_T, M, M, Q, z, z, gamma, alpha, beta, DPGP_FLAG_JITTER, jitter,
                           kuu, ld_kuu, kuu_stride, 1, smem_raw);
 }

@@ -163,12 +163,22 @@ __host__ __device__ inline int psi2_scale_dchunk(int D) {
 // output dims [b0, b0 + nb) of pair block pblk: the pair's squared differences are formed ONCE (the gather of two z rows and
 // the index arithmetic of psi2_pair_of were the cost of the per-(output dim, pair) form: 43.6 us at config 3 for 17 MB of
 // output) and every output dim adds Q FMAs, one v_exp_f32 and one coalesced store
+// lds != nullptr (>= nb (Q + 1) floats of LDS, all 256 threads of the workgroup call): the chunk's gamma rows and alpha^2 are
+// staged there first — read from global memory inside the loop every output dim waited for its own Q + 1 scalar loads
 template <typename TIN, typename TG>
 __device__ __forceinline__ void psi2_pair_scale_chunk(int b0, int nb, int pblk, int M, int Q, const TIN *__restrict__ z,
                                                       const TG *__restrict__ gamma, const TG *__restrict__ alpha,
-                                                      float *__restrict__ scale) {
+                                                      float *__restrict__ scale, float *__restrict__ lds = nullptr) {
     const int P = (int)((long long)M * (M + 1) / 2), Ppad = (P + 31) & ~31;
     const int p = pblk * 256 + (int)threadIdx.x;
+    if (lds) {
+        for (int e = (int)threadIdx.x; e < nb * (Q + 1); e += 256) {
+            const int bb = e / (Q + 1), q = e - bb * (Q + 1);
+            const float al = (float)alpha[b0 + bb];
+            lds[e] = q < Q ? (float)gamma[(size_t)(b0 + bb) * Q + q] : al * al;
+        }
+        __syncthreads();
+    }
     if (p >= Ppad) return;
     float d2[DPGP_MAX_Q];
 #pragma unroll
@@ -184,12 +194,21 @@ __device__ __forceinline__ void psi2_pair_scale_chunk(int b0, int nb, int pblk, 
             }
     }
     for (int b = b0; b < b0 + nb; ++b) {
-        float bsum = 0.0f;
+        float bsum = 0.0f, al2;
+        if (lds) {
+            const float *gl = lds + (b - b0) * (Q + 1);
 #pragma unroll
-        for (int q = 0; q < DPGP_MAX_Q; ++q)
-            if (q < Q) bsum += (float)gamma[(size_t)b * Q + q] * d2[q];
-        const float al = (float)alpha[b];
-        scale[(size_t)b * Ppad + p] = al * al * __builtin_amdgcn_exp2f((float)(-0.25 * DPGP_LOG2E) * bsum);
+            for (int q = 0; q < DPGP_MAX_Q; ++q)
+                if (q < Q) bsum += gl[q] * d2[q];
+            al2 = gl[Q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < DPGP_MAX_Q; ++q)
+                if (q < Q) bsum += (float)gamma[(size_t)b * Q + q] * d2[q];
+            const float al = (float)alpha[b];
+            al2 = al * al;
+        }
+        scale[(size_t)b * Ppad + p] = al2 * __builtin_amdgcn_exp2f((float)(-0.25 * DPGP_LOG2E) * bsum);
     }
 }
 template <typename TIN, typename TG>
