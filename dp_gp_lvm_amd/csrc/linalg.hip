@@ -125,77 +125,126 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
     double ip = 0.0, kin2 = 0.0, p2n2 = 0.0;     // <K^-1, Psi2>, |K^-1|_F^2, |Psi2|_F^2 (the last two: conditioning guard)
     const int ii = t >> 4, jj = t & 15;
     const int nlow = nb * (nb + 1) / 2;
+    // the border vector v^T = sum of the ns1 partial Psi1^T y slabs: its loads are issued first and drain beneath the assembly
+    // below (behind it they were ~2 us of exposed latency per evaluation); thread j < Mp holds entry j
+    double vborder = 0.0;
+    if (mode == 0 && t < M) {                              // (LDS-resident sizes: Mp <= 256, one entry per thread)
+        for (int k0 = 0; k0 < ns1; k0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (k0 + k < ns1) ? v_part[((size_t)(k0 + k) * D + d) * M + t] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vborder += v[k];
+        }
+    }
     {
         // 4 tiles per pass: thread = (tile u, row r, 4 consecutive columns) -> 16/32-byte loads, all issued before use
         typedef TP tp4 __attribute__((ext_vector_type(4)));
         typedef TL tl4 __attribute__((ext_vector_type(4)));
         const int u = t >> 6, r = (t & 63) >> 2, c4 = (t & 3) * 4;
-#pragma unroll 3
-        for (int t0 = 0; t0 < nlow; t0 += 4) {
+        // tile of pass t0 for this thread's quarter u, and what is done with its loaded values
+        auto locate = [&](int t0, int &I, int &J) __attribute__((always_inline)) {
             const int tt = min(t0 + u, nlow - 1);
-            int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+            I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
             while ((I + 1) * (I + 2) / 2 <= tt) ++I;
             while (I * (I + 1) / 2 > tt) --I;
-            const int J = tt - I * (I + 1) / 2;
+            J = tt - I * (I + 1) / 2;
+        };
+        auto finish = [&](int t0, int I, int J, const tl4 &k0, const tl4 &ki, const double (&p2)[4]) __attribute__((always_inline)) {
+            if (t0 + u >= nlow) return;
             const int i = 16 * I + r, j = 16 * J + c4;
-            const size_t off = (size_t)i * Mp + j;
-            tl4 k0 = *reinterpret_cast<const tl4 *>(K0 + off);
-            tl4 ki = *reinterpret_cast<const tl4 *>(KI + off);
-            double p2[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int kb = 0; kb < ns2; kb += 8) {      // up to 8 slab loads in flight (psi2_nsplit() never exceeds 8)
-                tp4 v[8];
+            // (the 2-per-CU instantiation is LDS-resident by construction: a destination that is provably not global
+            //  memory lets the loads of the next passes be issued ahead of these stores)
+            TL *dst = (OCC == 2 || mode == 0) ? tiles + lds_tile_index(I, J, nb) * TSZ + r * LDT + c4 : Wb + (size_t)i * Mp + j;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (kb + k < ns2)
-                        v[k] = *reinterpret_cast<const tp4 *>(psi2_part + ((size_t)(kb + k) * D + d) * (size_t)Mp * Mp + off);
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (kb + k < ns2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) p2[e] += (double)v[k][e];
-                    }
-            }
-            if (t0 + u < nlow) {
-                // (the 2-per-CU instantiation is LDS-resident by construction: a destination that is provably not global
-                //  memory lets the loads of the next passes be issued ahead of these stores)
-                TL *dst = (OCC == 2 || mode == 0) ? tiles + lds_tile_index(I, J, nb) * TSZ + r * LDT + c4 : Wb + off;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int je = j + e;
-                    TL bv;
-                    if (je <= i && i < M) {            // inside the real lower triangle
-                        bv = k0[e] + be * (TL)p2[e];
-                        const double wt = (i == je ? 1.0 : 2.0);
-                        ip += (double)ki[e] * p2[e] * wt;
-                        kin2 += (double)ki[e] * (double)ki[e] * wt;
-                        p2n2 += p2[e] * p2[e] * wt;
-                    } else {
-                        bv = (i == je) ? (TL)1 : (TL)0;   // identity padding (and don't-care zeros above the diagonal)
-                    }
-                    dst[e] = bv;
+            for (int e = 0; e < 4; ++e) {
+                const int je = j + e;
+                TL bv;
+                if (je <= i && i < M) {            // inside the real lower triangle
+                    bv = k0[e] + be * (TL)p2[e];
+                    const double wt = (i == je ? 1.0 : 2.0);
+                    ip += (double)ki[e] * p2[e] * wt;
+                    kin2 += (double)ki[e] * (double)ki[e] * wt;
+                    p2n2 += p2[e] * p2[e] * wt;
+                } else {
+                    bv = (i == je) ? (TL)1 : (TL)0;   // identity padding (and don't-care zeros above the diagonal)
                 }
+                dst[e] = bv;
+            }
+        };
+        constexpr int NB = sizeof(TP) == 4 ? 3 : 1;        // passes whose loads are in flight together (fp32 slabs: 48 registers each)
+        if (NB > 1 && ns2 <= 8) {
+            // (the loop below left to the compiler waits for every pass's loads in turn — its tile search and the slab loop keep
+            //  it from hoisting them: 9 passes x ~1.2 us at M = 128 on the critical path of every evaluation)
+            for (int t0 = 0; t0 < nlow; t0 += 4 * NB) {
+                int I[NB], J[NB];
+                tl4 k0[NB], ki[NB];
+                tp4 v[NB][8];
+#pragma unroll
+                for (int b_ = 0; b_ < NB; ++b_) {
+                    locate(t0 + 4 * b_, I[b_], J[b_]);
+                    const size_t off = (size_t)(16 * I[b_] + r) * Mp + 16 * J[b_] + c4;
+                    k0[b_] = *reinterpret_cast<const tl4 *>(K0 + off);
+                    ki[b_] = *reinterpret_cast<const tl4 *>(KI + off);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < ns2) v[b_][k] = *reinterpret_cast<const tp4 *>(psi2_part + ((size_t)k * D + d) * (size_t)Mp * Mp + off);
+                }
+#pragma unroll
+                for (int b_ = 0; b_ < NB; ++b_) {
+                    double p2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < ns2) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) p2[e] += (double)v[b_][k][e];
+                        }
+                    finish(t0 + 4 * b_, I[b_], J[b_], k0[b_], ki[b_], p2);
+                }
+            }
+        } else {
+            for (int t0 = 0; t0 < nlow; t0 += 4) {
+                int I, J;
+                locate(t0, I, J);
+                const size_t off = (size_t)(16 * I + r) * Mp + 16 * J + c4;
+                tl4 k0 = *reinterpret_cast<const tl4 *>(K0 + off);
+                tl4 ki = *reinterpret_cast<const tl4 *>(KI + off);
+                double p2[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int kb = 0; kb < ns2; kb += 8) {      // up to 8 slab loads in flight
+                    tp4 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (kb + k < ns2)
+                            v[k] = *reinterpret_cast<const tp4 *>(psi2_part + ((size_t)(kb + k) * D + d) * (size_t)Mp * Mp + off);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (kb + k < ns2) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) p2[e] += (double)v[k][e];
+                        }
+                }
+                finish(t0, I, J, k0, ki, p2);
             }
         }
     }
-    // border tile-row: row 0 holds v^T = sum of the ns1 partial Psi1^T y slabs (independent loads, 8 in flight: a serial
-    // loop over the slabs costs ~1 us of memory latency per slab, 20 us at ns1 = 16), rows 1..15 are zero
-    for (int e = t; e < 16 * Mp; e += 256) {
-        const int row = e / Mp, j = e - row * Mp;
-        TL bv = 0;
-        if (row == 0 && j < M) {
-            double a = 0.0;
-            for (int k0 = 0; k0 < ns1; k0 += 8) {
-                double v[8];
+    // border tile-row: row 0 holds v^T, rows 1..15 are zero
+    if (mode == 0) {
+        if (t < Mp) tiles[(size_t)nlow * TSZ + (t >> 4) * LDT + (t & 15)] = (TL)vborder;     // border vector (linalg_dev.h)
+    } else {
+        for (int e = t; e < 16 * Mp; e += 256) {
+            const int row = e / Mp, j = e - row * Mp;
+            TL bv = 0;
+            if (row == 0 && j < M) {
+                double a = 0.0;
+                for (int k0 = 0; k0 < ns1; k0 += 8) {
+                    double v[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (k0 + k < ns1) ? v_part[((size_t)(k0 + k) * D + d) * M + j] : 0.0;
+                    for (int k = 0; k < 8; ++k) v[k] = (k0 + k < ns1) ? v_part[((size_t)(k0 + k) * D + d) * M + j] : 0.0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) a += v[k];
+                    for (int k = 0; k < 8; ++k) a += v[k];
+                }
+                bv = (TL)a;
             }
-            bv = (TL)a;
-        }
-        if (mode == 0) {
-            if (row == 0) tiles[(size_t)nlow * TSZ + (j >> 4) * LDT + (j & 15)] = bv;     // border vector (linalg_dev.h)
-        } else {
             Wb[(size_t)(Mp + row) * Mp + j] = bv;
         }
     }
