@@ -538,12 +538,18 @@ __global__ __launch_bounds__(256) void model_prepare_kernel(
         aat[t] = softplus_d(aat_raw[t]);
         bat[t] = softplus_d(bat_raw[t]);
     }
-    if (t >= 64 && t - 64 < T - 1) {
-        const int k = t - 64;
+    // (one digamma per thread — thread = (stick k, argument f) — instead of three in a row on the threads k < T - 1: every row
+    //  block waits for these before its first output dim)
+    __shared__ double dg[3][PREP_MAX_T];
+    if (t >= 64 && t - 64 < 3 * (T - 1)) {
+        const int k = (t - 64) / 3, f = (t - 64) - 3 * k;
         const double g1 = softplus_d(g1_raw[k]), g2 = softplus_d(g2_raw[k]);
-        const double p12 = digamma_d(g1 + g2);
-        c1[k] = digamma_d(g1) - p12;
-        c2[k] = digamma_d(g2) - p12;
+        dg[f][k] = digamma_d(f == 0 ? g1 : (f == 1 ? g2 : g1 + g2));
+    }
+    __syncthreads();
+    if (t < T - 1) {
+        c1[t] = dg[0][t] - dg[2][t];
+        c2[t] = dg[1][t] - dg[2][t];
     }
     __syncthreads();
     const int rb = blockIdx.x - 1, cols = Q + 1;
