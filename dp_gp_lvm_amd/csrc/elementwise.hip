@@ -308,7 +308,9 @@ typedef _Float16 p1_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 p1_h2 __attribute__((ext_vector_type(2)));
 typedef float p1_f4 __attribute__((ext_vector_type(4)));
 
-template <typename TIN, int KF1>
+// NJ: 16-column tiles a workgroup covers (8 = 128 columns; 4 when M <= 64: half the operand registers, MFMAs and exponentials
+// — config 5 (M = 64, Q = 20) spent them on zero padding: 183 us for 7e7 exponentials)
+template <typename TIN, int KF1, int NJ>
 __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, int B, const TIN *__restrict__ z,
                                                           const unsigned char *__restrict__ consts,
                                                           const TIN *__restrict__ mu, const TIN *__restrict__ s,
@@ -318,12 +320,12 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
     constexpr int SL = 32 * KF1;                          // K slots (f16) per row of an operand image
     constexpr int QP = 4 * ((32 * KF1 - 2) / 6 / 4 + 1);  // row stride of the per-(row,q) arrays: >= Q, multiple of 4
     constexpr int QPC = QP < 32 ? QP : 32;                // (Q <= DPGP_MAX_Q = 30)
-    __shared__ __align__(16) _Float16 bimg[128 * SL];     // m-side image of this 128-column chunk
+    __shared__ __align__(16) _Float16 bimg[16 * NJ * SL]; // m-side image of this chunk of 16 NJ columns
     __shared__ __align__(16) _Float16 aimg[4][16 * SL];   // n-side image, one per wave
     __shared__ float yv[4][16];
     __shared__ float zc[32], gq[32];
     __shared__ __align__(16) float red[16][128];
-    const int b = blockIdx.z, mc = blockIdx.y * 128, sp = blockIdx.x;
+    const int b = blockIdx.z, mc = blockIdx.y * (16 * NJ), sp = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kk = lane >> 4;
     // the z-only constants (column means, m-side image: the same image as the psi2 kernel's, psi2_consts.h) are copied
     const Psi2Consts C = psi2_consts_layout(M, Q);        // C.SL == SL
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
         zc[t] = reinterpret_cast<const float *>(consts)[t];
     }
     typedef unsigned p1_u4 __attribute__((ext_vector_type(4)));
-    for (int e = t; e < 128 * (SL / 8); e += 256) {       // 16-byte vectors; rows up to round_up(M, 64) exist
+    for (int e = t; e < 16 * NJ * (SL / 8); e += 256) {       // 16-byte vectors; rows up to round_up(M, 64) exist
         const int m = e / (SL / 8), k = e - m * (SL / 8);
         p1_u4 v = {0u, 0u, 0u, 0u};
         if (mc + m < C.Mp64) v = reinterpret_cast<const p1_u4 *>(bimg_g + (size_t)(mc + m) * SL)[k];
@@ -342,15 +344,15 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
     for (int e = t; e < 4 * 16 * SL / 2; e += 256) reinterpret_cast<unsigned *>(&aimg[0][0])[e] = 0u;
     __syncthreads();
     // m-side operands of this lane: 8 column tiles x KF1 K-steps, resident in registers
-    p1_h8 bop[8][KF1];
+    p1_h8 bop[NJ][KF1];
 #pragma unroll
-    for (int J = 0; J < 8; ++J)
+    for (int J = 0; J < NJ; ++J)
 #pragma unroll
         for (int ks = 0; ks < KF1; ++ks)
             bop[J][ks] = *reinterpret_cast<const p1_h8 *>(bimg + (16 * J + li) * SL + 32 * ks + 8 * kk);
-    float acc[8];
+    float acc[NJ];
 #pragma unroll
-    for (int J = 0; J < 8; ++J) acc[J] = 0.0f;
+    for (int J = 0; J < NJ; ++J) acc[J] = 0.0f;
     _Float16 *am = &aimg[wv][0];
     const int nbeg = sp * n_per_split, nend = min(N, nbeg + n_per_split);
     // q(X) rows and y of a 16-row tile are fetched one tile ahead (registers), so that their global-load latency overlaps
@@ -433,15 +435,15 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
         float y4[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) y4[v] = yv[wv][4 * kk + v];
-        p1_f4 c[8];
+        p1_f4 c[NJ];
 #pragma unroll
-        for (int J = 0; J < 8; ++J) c[J] = (p1_f4){0, 0, 0, 0};
+        for (int J = 0; J < NJ; ++J) c[J] = (p1_f4){0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KF1; ++ks)                    // K-step outermost: 8 independent accumulation chains in flight
 #pragma unroll
-            for (int J = 0; J < 8; ++J) c[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop[ks], bop[J][ks], c[J], 0, 0, 0);
+            for (int J = 0; J < NJ; ++J) c[J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop[ks], bop[J][ks], c[J], 0, 0, 0);
 #pragma unroll
-        for (int J = 0; J < 8; ++J)
+        for (int J = 0; J < NJ; ++J)
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[J] = fmaf(y4[v], dpgp_exp2(c[J][v]), acc[J]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next tile overwrites the image just read
@@ -449,9 +451,9 @@ __global__ __launch_bounds__(256) void psi1T_y_f16_kernel(int N, int M, int Q, i
     // ---- sum the 4 row groups of each wave and the 4 waves ----
     const bool any_oor = __syncthreads_or(oor ? 1 : 0) != 0;   // (also the barrier cq -> red needs: cq aliases red)
 #pragma unroll
-    for (int J = 0; J < 8; ++J) red[wv * 4 + kk][16 * J + li] = acc[J];
+    for (int J = 0; J < NJ; ++J) red[wv * 4 + kk][16 * J + li] = acc[J];
     __syncthreads();
-    if (t < 128 && mc + t < M) {
+    if (t < 16 * NJ && mc + t < M) {
         double v = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += (double)red[k][t];
@@ -464,8 +466,15 @@ static int launch_psi1T_y_f16_kf(int B, int N, int M, int Q, const TIN *z, const
                                  const TIN *gamma, const TIN *alpha, const TIN *y, int ldy, double *part, int ns,
                                  const unsigned char *consts, hipStream_t st) {
     int nper = dpgp_round_up(dpgp_ceil_div(N, ns), 64);
+    if (M <= 64) {
+        dim3 grid(ns, 1, B);
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1T_y_f16_kernel<TIN, KF1, 4>), grid, dim3(256), 0, st, N, M, Q, B, z, consts, mu, s, gamma,
+                           alpha, y, ldy, part, nper);
+        DPGP_LAUNCH_CHECK();
+        return DPGP_OK;
+    }
     dim3 grid(ns, dpgp_ceil_div(M, 128), B);
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1T_y_f16_kernel<TIN, KF1>), grid, dim3(256), 0, st, N, M, Q, B, z, consts, mu, s, gamma, alpha, y,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((psi1T_y_f16_kernel<TIN, KF1, 8>), grid, dim3(256), 0, st, N, M, Q, B, z, consts, mu, s, gamma, alpha, y,
                        ldy, part, nper);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
