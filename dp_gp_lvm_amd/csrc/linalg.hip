@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
                 dst[e] = bv;
             }
         };
-        constexpr int NB = sizeof(TP) == 4 ? 3 : 1;        // passes whose loads are in flight together (fp32 slabs: 48 registers each)
+        constexpr int NB = sizeof(TP) == 4 ? 2 : 1;        // passes whose loads are in flight together (fp32 slabs: 48 registers each;
+                                                           // three: 185 registers = two waves per SIMD, config 5's 560 workgroups then need two rounds)
         if (NB > 1 && ns2 <= 8) {
             // (the loop below left to the compiler waits for every pass's loads in turn — its tile search and the slab loop keep
             //  it from hoisting them: 9 passes x ~1.2 us at M = 128 on the critical path of every evaluation)
