@@ -31,8 +31,12 @@ typedef double pp_f2 __attribute__((ext_vector_type(2)));
 __device__ long long g_pp_stamps[64];
 extern "C" void dpgp_debug_persist_stamps(long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(long long) * 64); }
 #define PP_STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_pp_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PP_T0() const long long pt0__ = __builtin_amdgcn_s_memtime()
+#define PP_T1(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pp_stamps[i] += __builtin_amdgcn_s_memtime() - pt0__; } while (0)
 #else
 #define PP_STAMP(i)
+#define PP_T0()
+#define PP_T1(i)
 #endif
 
 static size_t pp_lds_bytes() {
@@ -42,6 +46,8 @@ static size_t pp_lds_bytes() {
 }
 
 // ---- (c) one wave, one 16-row tile I below the diagonal block: S (staging, [16][PP_SLD]) holds A_Ik on entry and P_I on exit
+// (INPLACE: the inverted diagonal tiles sit in the diagonal slots of `tiles` themselves, linv unused)
+template <bool INPLACE = false>
 __device__ __forceinline__ void pp_trsm_tile(double *S, const double *tiles, const double *linv, int lane) {
     typedef f64x4 acc_t;
     const int li = lane & 15, kk = lane >> 4;
@@ -57,7 +63,7 @@ __device__ __forceinline__ void pp_trsm_tile(double *S, const double *tiles, con
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-lt[4 * ks], X[cp][ks], a, 0, 0, 0);
         }
-        const double *iv = linv + c * TSZ + li * LDT + kk;
+        const double *iv = (INPLACE ? tiles + lds_tile_index(c, c, PP_NT) * TSZ : linv + c * TSZ) + li * LDT + kk;
 #ifdef PP_DEBUG_NOPS
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #endif
@@ -272,6 +278,217 @@ __global__ __launch_bounds__(256) void pbig_persistent_kernel(int Mw, double *__
         __threadfence_block();
         __syncthreads();
         PP_STAMP(8 * k + 6);
+    }
+    PP_STAMP(63);
+    if (t == 0) info[b] = first_fail;
+}
+
+// ---- LEFT-LOOKING form of the same factorisation (round 3, second half): block column k is first brought up to date with
+// all block columns to its left — the accumulators of a 128 x 128 block run over K = 128 k without touching memory — and is
+// then finished where it sits: the diagonal block goes from the accumulators straight into the LDS tiles of potrf_lds, a
+// block below it from the accumulators through the wave's staging tile into the register-chained solve of pp_trsm_tile and
+// only then to memory.  Every block of the matrix is read once (its old values) and written once (its part of L); the
+// right-looking kernel above reads and writes a trailing block once per block column to its left and a panel block twice more
+// (update out, panel in / out): 4.9 against 6.8 MB per 512 x 512 matrix, and HBM is what binds this kernel.
+// LDS: the 36 tiles of the diagonal block (their diagonal tiles replaced by their inverses once L_kk is stored) + ONE staged
+// chunk pair [128][32] x 2 (the next chunk waits in registers), which the four staging tiles of the solve alias.
+#define PL_KQ 32
+#define PL_KLD (PL_KQ + 2)
+static size_t pl_lds_bytes() {
+    return LA_LDS_HDR + sizeof(double) * ((size_t)TSZ * (PP_NT * (PP_NT + 1) / 2) + (size_t)2 * PP_PW * PL_KLD);
+}
+static_assert(2 * PP_PW * PL_KLD >= 4 * 16 * PP_SLD, "the staging tiles of the solve alias the chunk pair");
+
+__global__ __launch_bounds__(256) void pleft_persistent_kernel(int Mw, double *__restrict__ w, size_t wstride,
+                                                               int *__restrict__ info) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    int &fail = *reinterpret_cast<int *>(smem_raw + 64);
+    double *tiles = reinterpret_cast<double *>(smem_raw + LA_LDS_HDR);
+    double *chunk = tiles + (size_t)TSZ * (PP_NT * (PP_NT + 1) / 2);   // xs [128][PL_KLD] | ys [128][PL_KLD]
+    double *stage = chunk;                                             // (aliases: 4 x [16][PP_SLD], used between update loops)
+    typedef f64x4 acc_t;
+    const int t = threadIdx.x, lane = t & 63, li = lane & 15, kk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = blockIdx.x, nblk = Mw / PP_PW;
+    double *A = w + (size_t)b * wstride;
+    constexpr int nlow = PP_NT * (PP_NT + 1) / 2;
+    const int rt0 = wv, rt1 = PP_NT - 1 - wv;                          // this wave's two row tiles of a block
+    const int srow = t >> 4, sc2 = (t & 15) * 2;                       // thread -> (row, column pair) of a [128][32] chunk
+    int first_fail = 0;
+    acc_t acc[2][PP_NT];
+    // acc <- old values of block (Iblk, k) - sum_{j < k} P_Iblk,j P_k,j^T   (k >= 1; diag: Iblk == k, lower tiles only).  The
+    // accumulators START from the old values (their loads are issued with the first chunk's and land beneath its staging): a
+    // second register set for them at the end of the loop, as in the right-looking kernel, spilled 91 registers here.
+    auto update_block = [&](int Iblk, int k, bool diag) __attribute__((always_inline)) {
+        const int nch = (PP_PW / PL_KQ) * k;
+        const double *Pi = A + (size_t)(PP_PW * Iblk) * Mw, *Pk = A + (size_t)(PP_PW * k) * Mw;
+        const double *Cb = Pi + PP_PW * k;
+        pp_f2 px[8], py[8];
+        auto fetch = [&](int m) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) px[q] = *reinterpret_cast<const pp_f2 *>(Pi + (size_t)(srow + 16 * q) * Mw + PL_KQ * m + sc2);
+            if (!diag) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) py[q] = *reinterpret_cast<const pp_f2 *>(Pk + (size_t)(srow + 16 * q) * Mw + PL_KQ * m + sc2);
+            }
+        };
+        double *xs = chunk, *ys = chunk + (size_t)PP_PW * PL_KLD;
+        fetch(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rt = i ? rt1 : rt0;
+#pragma unroll
+            for (int Jt = 0; Jt < PP_NT; ++Jt) {
+                if (!diag || Jt <= rt) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[i][Jt][v] = Cb[(size_t)(16 * rt + kk + 4 * v) * Mw + 16 * Jt + li];
+                } else {
+                    acc[i][Jt] = (acc_t){0, 0, 0, 0};
+                }
+            }
+        }
+        for (int m = 0; m < nch; ++m) {
+            __syncthreads();                                           // the previous chunk (or the staging tiles) is no longer read
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const pp_f2 vx = px[q], vy = diag ? px[q] : py[q];
+                double *dx = xs + (srow + 16 * q) * PL_KLD + sc2, *dy = ys + (srow + 16 * q) * PL_KLD + sc2;
+                dx[0] = -vx[0]; dx[1] = -vx[1];
+                dy[0] = vy[0]; dy[1] = vy[1];
+            }
+            __syncthreads();
+            if (m + 1 < nch) fetch(m + 1);
+#pragma unroll 2
+            for (int ks = 0; ks < PL_KQ / 4; ++ks) {
+                const double x0 = xs[(16 * rt0 + li) * PL_KLD + 4 * ks + kk], x1 = xs[(16 * rt1 + li) * PL_KLD + 4 * ks + kk];
+#pragma unroll
+                for (int Jt = 0; Jt < PP_NT; ++Jt) {
+                    if (diag && Jt > rt1) continue;                    // (rt0 <= rt1: nothing of this column for the wave)
+                    const double yv = ys[(16 * Jt + li) * PL_KLD + 4 * ks + kk];
+                    if (!diag || Jt <= rt0) acc[0][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, yv, acc[0][Jt], 0, 0, 0);
+                    acc[1][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, yv, acc[1][Jt], 0, 0, 0);
+                }
+            }
+        }
+    };
+    for (int k = 0; k < nblk; ++k) {
+        double *Akk = A + (size_t)(PP_PW * k) * Mw + PP_PW * k;
+        const int nbelow = Mw - PP_PW * (k + 1);
+        if (t == 0) fail = 0;
+        PP_STAMP(8 * k + 0);
+        // ---- the diagonal block, up to date, into the LDS tiles ----
+        if (k == 0) {
+            // (tile, row, column pair); six independent loads in flight per thread: one at a time this loop took 47k cycles
+            for (int e0 = t; e0 < nlow * 128; e0 += 256 * 6) {
+                pp_f2 v[6];
+                int dst[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int e = e0 + 256 * u;
+                    const int tt = min(e >> 7, nlow - 1), r = (e >> 3) & 15, c2 = (e & 7) * 2;
+                    int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+                    while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+                    while (I * (I + 1) / 2 > tt) --I;
+                    const int J = tt - I * (I + 1) / 2;
+                    v[u] = *reinterpret_cast<const pp_f2 *>(Akk + (size_t)(16 * I + r) * Mw + 16 * J + c2);
+                    dst[u] = (e < nlow * 128) ? tt * TSZ + r * LDT + c2 : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    if (dst[u] >= 0) {
+                        tiles[dst[u]] = v[u][0];
+                        tiles[dst[u] + 1] = v[u][1];
+                    }
+            }
+        } else {
+            update_block(k, k, true);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rt = i ? rt1 : rt0;
+#pragma unroll
+                for (int Jt = 0; Jt < PP_NT; ++Jt)
+                    if (Jt <= rt) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            tiles[lds_tile_index(rt, Jt, PP_NT) * TSZ + (kk + 4 * v) * LDT + li] = acc[i][Jt][v];
+                    }
+            }
+        }
+        for (int e = t; e < PP_PW * (nbelow / 2); e += 256) {          // zeros to the right of the block: drain behind the factorisation
+            const int r = e / (nbelow / 2), c2 = (e - r * (nbelow / 2)) * 2;
+            *reinterpret_cast<pp_f2 *>(Akk + (size_t)r * Mw + PP_PW + c2) = (pp_f2){0.0, 0.0};
+        }
+        __syncthreads();                                               // (also: nobody reads the chunk pair any more)
+        PP_STAMP(8 * k + 1);
+        potrf_lds<double, 1>(tiles, chunk, PP_NT, PP_NT, &fail);       // (`chunk`: its scratch tile)
+        lds_barrier();
+        PP_STAMP(8 * k + 2);
+        if (fail && first_fail == 0) first_fail = PP_PW * k + fail;
+        for (int e = t; e < PP_PW * PP_PW / 2; e += 256) {             // L_kk out, zeros above its diagonal
+            const int i = e >> 6, j = (e & 63) * 2;
+            pp_f2 v;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                v[u] = (j + u <= i) ? tiles[lds_tile_index(i >> 4, (j + u) >> 4, PP_NT) * TSZ + (i & 15) * LDT + ((j + u) & 15)] : 0.0;
+            *reinterpret_cast<pp_f2 *>(Akk + (size_t)i * Mw + j) = v;
+        }
+        if (k + 1 == nblk) break;
+        lds_barrier();                                                 // the diagonal tiles have been read out
+        if (wv < 2) {                                                  // their inverses, in place
+            const int c = 4 * wv + kk;
+            double *tc = tiles + lds_tile_index(c, c, PP_NT) * TSZ;
+            tri_inverse_dpp<double>(tc, tc, LDT, lane);
+        }
+        __syncthreads();
+        PP_STAMP(8 * k + 3);
+        // ---- the blocks below: up to date in the accumulators, solved through the staging tile, stored once ----
+        double *S = stage + (size_t)wv * 16 * PP_SLD;
+        pp_f2 pre[16];                                                 // k == 0: the next row tile's rows, fetched beneath the current solve
+        if (k == 0) {
+            const double *P0 = A + (size_t)(PP_PW * 1) * Mw;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const pp_f2 *>(P0 + (size_t)(16 * rt0 + q) * Mw + 2 * lane);
+        }
+        for (int I = k + 1; I < nblk; ++I) {
+            double *Pik = A + (size_t)(PP_PW * I) * Mw + PP_PW * k;
+            PP_T0();
+            if (k > 0) {
+                update_block(I, k, false);
+                __syncthreads();                                       // every wave is done with the chunk pair: staging may begin
+            }
+            PP_T1(40 + k);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rt = i ? rt1 : rt0;
+                if (k == 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        S[q * PP_SLD + 2 * lane] = pre[q][0];
+                        S[q * PP_SLD + 2 * lane + 1] = pre[q][1];
+                    }
+                    const int In = i ? I + 1 : I, rn = i ? rt0 : rt1;  // the tile after this one
+                    if (In < nblk) {
+                        const double *Pn = A + (size_t)(PP_PW * In) * Mw;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const pp_f2 *>(Pn + (size_t)(16 * rn + q) * Mw + 2 * lane);
+                    }
+                } else {
+#pragma unroll
+                    for (int Jt = 0; Jt < PP_NT; ++Jt)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) S[(kk + 4 * v) * PP_SLD + 16 * Jt + li] = acc[i][Jt][v];
+                }
+                pp_trsm_tile<true>(S, tiles, nullptr, lane);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const pp_f2 v = {S[q * PP_SLD + 2 * lane], S[q * PP_SLD + 2 * lane + 1]};
+                    *reinterpret_cast<pp_f2 *>(Pik + (size_t)(16 * rt + q) * Mw + 2 * lane) = v;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();                                               // block column k complete in memory
+        PP_STAMP(8 * k + 4);
     }
     PP_STAMP(63);
     if (t == 0) info[b] = first_fail;
@@ -587,6 +804,17 @@ bool potrf_persist_applicable(int B, int M, int elem_size) { return elem_size ==
 
 int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st, size_t wstride) {
     if (!wstride) wstride = (size_t)Mw * Mw;
+    const char *le_ = getenv("DPGP_POTRF_LEFT");                 // (0: the right-looking kernel, cross-checks / profiling)
+    if (!le_ || le_[0] != '0') {
+        const size_t lds = pl_lds_bytes();
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pleft_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
+        DPGP_PRELAUNCH();
+        hipLaunchKernelGGL(pleft_persistent_kernel, dim3(B), dim3(256), lds, st, Mw, w, wstride, info);
+        DPGP_LAUNCH_CHECK();
+        return DPGP_OK;
+    }
     const size_t lds = pp_lds_bytes();
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pbig_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)

@@ -1,0 +1,7 @@
+#!/bin/bash
+# the left-looking persistent Cholesky against the right-looking one (DPGP_POTRF_LEFT=0): correctness and time, M = 512 and 384 / 640
+cd "$(dirname "$0")/.."
+for left in 1 0; do
+  echo "== DPGP_POTRF_LEFT=$left"
+  DPGP_POTRF_LEFT=$left timeout -k 10 120 python scratch/test_persist.py 1
+done
