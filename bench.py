@@ -159,12 +159,12 @@ def secondary(dev, shape, p):
     # SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops, kernel-trace durations), committed with the build they were taken on
     try:
         pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03', 'linalg_pmc.json')))
-        sha = open(os.path.join(REPO, 'profiles', 'r03', 'GIT_SHA_OF_PROFILED_BUILD.txt')).read().strip()
+        sha = open(os.path.join(REPO, 'profiles', 'r03', 'GIT_SHA_OF_PROFILED_BUILD.txt')).read().split()[0]
         pick = lambda k: {a: b for a, b in pmc[k].items() if a != 'counters'} if k in pmc else None
         out['rocprof'] = {'source': 'profiles/r03/linalg_pmc.json @ ' + sha,
                           'gram_kuu': pick('void gram_kernel<double, double>'), 'gram_large': pick('void gram_kernel<float, float>'),
                           'cholesky_m128_b512': pick('void potrf_batched_lds_kernel<double>'),
-                          'cholesky_m512_b256': pick('pbig_persistent_kernel')}
+                          'cholesky_m512_b256': pick('pleft_persistent_kernel') or pick('pbig_persistent_kernel')}
     except (OSError, ValueError, KeyError):
         pass
     return out
