@@ -40,7 +40,7 @@ if rec:
     json.dump(rec, open(os.path.join(O, 'traffic.json'), 'w'), indent=1)
     P('traffic.json:', json.dumps(rec))
 P('== PMC of the gram / Cholesky workloads (python3 scratch/prof_linalg.py 3), averages per dispatch')
-la_k = ('gram', 'potrf', 'pbig')
+la_k = ('gram', 'potrf', 'pbig', 'pleft')
 la = collections.defaultdict(dict)
 for tag in ('pmc_la_fetch', 'pmc_la_write', 'pmc_la_sq'):
     for k, d in agg_pmc(tag, la_k).items():
