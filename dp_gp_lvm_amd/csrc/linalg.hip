@@ -450,22 +450,57 @@ __global__ __launch_bounds__(256, 2) void potrf_batched_lds_kernel(int M, int Mp
     T *A = a + (size_t)b * M * M;
     if (t == 0) fail = 0;
     STAMP(60);
-    for (int e = t; e < nlow * 256; e += 256) {               // (tile, row, column): consecutive threads along a row
-        const int tt = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
-        while ((I + 1) * (I + 2) / 2 <= tt) ++I;
-        while (I * (I + 1) / 2 > tt) --I;
-        const int J = tt - I * (I + 1) / 2, i = 16 * I + r, j = 16 * J + c;
-        tiles[tt * TSZ + r * LDT + c] = (i < M && j < M) ? A[(size_t)i * M + j] : ((i == j) ? (T)1 : (T)0);
+    if ((M & 1) == 0 && sizeof(T) == 8) {
+        // even M: 16-byte loads along the rows, four in flight per thread; pairs in tiles above the diagonal are skipped
+        typedef T t2 __attribute__((ext_vector_type(2)));
+        const int hp = Mp / 2, total = Mp * hp;
+        for (int e0 = t; e0 < total; e0 += 256 * 4) {
+            t2 v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u, i = e / hp, j = 2 * (e - i * hp);
+                const bool want = e < total && (j >> 4) <= (i >> 4);
+                dst[u] = want ? lds_tile_index(i >> 4, j >> 4, nb) * TSZ + (i & 15) * LDT + (j & 15) : -1;
+                v[u] = (t2){(i == j) ? (T)1 : (T)0, (i == j + 1) ? (T)1 : (T)0};      // identity padding
+                if (want && i < M && j < M) v[u] = *reinterpret_cast<const t2 *>(A + (size_t)i * M + j);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) {
+                    tiles[dst[u]] = v[u][0];
+                    tiles[dst[u] + 1] = v[u][1];
+                }
+        }
+    } else {
+        for (int e = t; e < nlow * 256; e += 256) {           // (tile, row, column): consecutive threads along a row
+            const int tt = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            int I = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= tt) ++I;
+            while (I * (I + 1) / 2 > tt) --I;
+            const int J = tt - I * (I + 1) / 2, i = 16 * I + r, j = 16 * J + c;
+            tiles[tt * TSZ + r * LDT + c] = (i < M && j < M) ? A[(size_t)i * M + j] : ((i == j) ? (T)1 : (T)0);
+        }
     }
     __syncthreads();
     STAMP(61);
     potrf_lds<T, 2>(tiles, dinv, nb, nb, &fail);
     __syncthreads();
     STAMP(62);
-    for (int e = t; e < M * M; e += 256) {
-        const int i = e / M, j = e - i * M;
-        A[e] = (j <= i) ? tiles[lds_tile_index(i >> 4, j >> 4, nb) * TSZ + (i & 15) * LDT + (j & 15)] : (T)0;
+    if ((M & 1) == 0 && sizeof(T) == 8) {
+        typedef T t2 __attribute__((ext_vector_type(2)));
+        const int hm = M / 2;
+        for (int e = t; e < M * hm; e += 256) {               // 16-byte stores
+            const int i = e / hm, j = 2 * (e - i * hm);
+            const T *src = tiles + lds_tile_index(i >> 4, j >> 4, nb) * TSZ + (i & 15) * LDT + (j & 15);
+            const t2 v = {(j <= i) ? src[0] : (T)0, (j + 1 <= i) ? src[1] : (T)0};
+            *reinterpret_cast<t2 *>(A + (size_t)i * M + j) = v;
+        }
+    } else {
+        for (int e = t; e < M * M; e += 256) {
+            const int i = e / M, j = e - i * M;
+            A[e] = (j <= i) ? tiles[lds_tile_index(i >> 4, j >> 4, nb) * TSZ + (i & 15) * LDT + (j & 15)] : (T)0;
+        }
     }
     STAMP(63);
     if (t == 0) info[b] = fail;
