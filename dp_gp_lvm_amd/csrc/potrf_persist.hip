@@ -315,6 +315,10 @@ __global__ __launch_bounds__(256) void pleft_persistent_kernel(int Mw, double *_
     const int rt0 = wv, rt1 = PP_NT - 1 - wv;                          // this wave's two row tiles of a block
     const int srow = t >> 4, sc2 = (t & 15) * 2;                       // thread -> (row, column pair) of a [128][32] chunk
     int first_fail = 0;
+#ifdef PL_DEPHASE_SLEEPS           // (experiment, scratch/dephase.sh: scratch/build_variant.sh dp<n> potrf_persist.hip -DPL_DEPHASE_SLEEPS=<n>)
+    if (b & 1)                     // odd workgroups start late: their HBM bursts fall between the even ones' — measured: no gain
+        for (int i = 0; i < PL_DEPHASE_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     acc_t acc[2][PP_NT];
     // acc <- old values of block (Iblk, k) - sum_{j < k} P_Iblk,j P_k,j^T   (k >= 1; diag: Iblk == k, lower tiles only).  The
     // accumulators START from the old values (their loads are issued with the first chunk's and land beneath its staging): a
