@@ -34,7 +34,7 @@ SIGNATURES = {
                                _vp, _vp]),
     'dpgp_elbo_fhat_t_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
     'dpgp_elbo_fhat_t': (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _d, _i, _vp, _vp,
-                              _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+                              _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dpgp_elbo_grad_chain': (_i, [_i, _i, _i, _i, _vp, _vp, _d, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dpgp_elbo_grad_psi_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'dpgp_elbo_grad_psi': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp,

@@ -376,7 +376,8 @@ extern "C" int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double 
                                 const double *mu, const double *s, const double *gamma, const double *alpha, const double *beta,
                                 const double *phit, long long phi_st, long long phi_sd, double jitter, int prec, double *per_t,
                                 double *quad, double *sums, int *info, void *ws, size_t ws_bytes, void *stream,
-                                const double *model_scal, double *model_pack, double *model_out) {
+                                const double *model_scal, double *model_pack, double *model_out, void *stream_aux,
+                                void *ev_fork, void *ev_join) {
     if (T <= 0) return -1;
     if (D < T) return -2;                                   // (the model asserts truncation_level <= D, dp_gp_lvm.py:567)
     if (N <= 0) return -3;
@@ -401,6 +402,24 @@ extern "C" int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double 
     double *lb = reinterpret_cast<double *>(w + E.off_lb), *p1 = reinterpret_cast<double *>(w + E.off_p1);
     double *vp = reinterpret_cast<double *>(w + E.off_vp);
     int rc;
+    // Psi1 and the product Psi1^T Y need only the inputs; the fused reduction on the atoms needs neither: with a second stream
+    // (and two events) they run side by side — both are latency-bound at T = 8 (84 us against 111 us at config 3).  Not while
+    // `stream` is being captured into a graph (the replay keeps the serial order).
+    hipStream_t aux = (stream_aux && ev_fork && ev_join) ? (hipStream_t)stream_aux : nullptr;
+    if (aux) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) aux = nullptr;
+    }
+    if (aux && (hipEventRecord((hipEvent_t)ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)ev_fork, 0) != hipSuccess))
+        return DPGP_ERR_LAUNCH;
+    hipStream_t sb = aux ? aux : st;
+    if (aux) {                                                 // the branch first, so that both start at once
+        if ((rc = dpgp_psi1_f64(T, N, M, Q, z, mu, s, gamma, alpha, p1, (void *)sb))) return rc - 100;
+        if ((rc = launch_gemm_splitk_f64(T, M, D, N, p1, (long long)N * M, 1, M, y, 0, ldy, 1, vp, (long long)M * D, D, 1, E.ksplit,
+                                         (long long)T * M * D, sb)))
+            return rc - 200;
+        if (hipEventRecord((hipEvent_t)ev_join, aux) != hipSuccess) return DPGP_ERR_LAUNCH;
+    }
     // (the first T columns of y stand in for the per-output columns of the fused reduction: its terms 3 and 4 are not used)
     if (prec == DPGP_PREC_MIXED)
         rc = elbo_run<float, double>(T, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums2, info,
@@ -409,11 +428,15 @@ extern "C" int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double 
         rc = elbo_run<double, double>(T, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums2, info,
                                       w + E.off_fused, E.L, st, nullptr, lb);
     if (rc) return rc;
-    if ((rc = dpgp_psi1_f64(T, N, M, Q, z, mu, s, gamma, alpha, p1, stream))) return rc - 100;
-    // V_t[m][d] = sum_n Psi1_t[n][m] y[n][d]
-    if ((rc = launch_gemm_splitk_f64(T, M, D, N, p1, (long long)N * M, 1, M, y, 0, ldy, 1, vp, (long long)M * D, D, 1, E.ksplit,
-                                     (long long)T * M * D, st)))
-        return rc - 200;
+    if (!aux) {
+        if ((rc = dpgp_psi1_f64(T, N, M, Q, z, mu, s, gamma, alpha, p1, stream))) return rc - 100;
+        // V_t[m][d] = sum_n Psi1_t[n][m] y[n][d]
+        if ((rc = launch_gemm_splitk_f64(T, M, D, N, p1, (long long)N * M, 1, M, y, 0, ldy, 1, vp, (long long)M * D, D, 1, E.ksplit,
+                                         (long long)T * M * D, st)))
+            return rc - 200;
+    } else if (hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0) != hipSuccess) {
+        return DPGP_ERR_LAUNCH;
+    }
     if ((rc = launch_tcols_quad(T, M, D, lb, vp, E.ksplit, (long long)T * M * D, beta, quad, st))) return rc;
     DPGP_PRELAUNCH();
     hipLaunchKernelGGL(fhat_t_combine_kernel, dim3(1), dim3(256), 0, st, T, D, N, terms, phit, quad, yy, beta, sums2, per_t, sums,

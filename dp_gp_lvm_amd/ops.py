@@ -314,6 +314,23 @@ class ElboTWorkspace:
         self.quad = torch.empty((t, d), dtype=torch.float64, device=device)
         self.sums = torch.empty(2, dtype=torch.float64, device=device)
         self.info = torch.empty(t, dtype=torch.int32, device=device)
+        # second stream + fork / join events: Psi1 and Psi1^T Y beside the fused reduction on the atoms (include/dpgp.h);
+        # DPGP_PARALLEL_BRANCH_T=0 keeps one stream
+        import os
+        l = _lib.lib()
+        self.aux = (l.dpgp_stream_create(), l.dpgp_event_create(), l.dpgp_event_create()) \
+            if os.environ.get('DPGP_PARALLEL_BRANCH_T', '1') != '0' else (None, None, None)
+
+    def __del__(self):
+        try:
+            if self.aux[0]:
+                l = _lib.lib()
+                l.dpgp_stream_destroy(self.aux[0])
+                l.dpgp_event_destroy(self.aux[1])
+                l.dpgp_event_destroy(self.aux[2])
+                self.aux = (None, None, None)
+        except Exception:
+            pass
 
 
 def elbo_fhat_t_supported(m):
@@ -350,7 +367,7 @@ def elbo_fhat_t(y, yy, z, mu, s, gamma_atoms, alpha_atoms, beta_atoms, phit, jit
                                            s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(), phit.data_ptr(),
                                            phit.stride(0), phit.stride(1), float(jitter), _lib.PREC[prec], w.per_t.data_ptr(),
                                            w.quad.data_ptr(), w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes,
-                                           _stream(), *tail),
+                                           _stream(), *tail, *w.aux),
                'dpgp_elbo_fhat_t')
     return w.per_t, w.quad, w.sums, w.info
 

@@ -229,10 +229,14 @@ int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double *y, int ldy
                      const double *mu, const double *s, const double *gamma, const double *alpha, const double *beta,
                      const double *phit, long long phi_st, long long phi_sd, double jitter, int prec, double *per_t,
                      double *quad, double *sums, int *info, void *ws, size_t ws_bytes, void *stream,
-                     const double *model_scal, double *model_pack, double *model_out);
+                     const double *model_scal, double *model_pack, double *model_out, void *stream_aux, void *ev_fork,
+                     void *ev_join);
 /*   phit is read as phit[t * phi_st + d * phi_sd] (phi[D,T] of dpgp_model_prepare_t: phi_st = 1, phi_sd = T).
  *   model_scal / model_pack / model_out (each may be NULL): the model-level tail in the last launch, as dpgp_exec_t's fields
- *   of the same names — model_scal = scal of dpgp_model_prepare_t for the same D output dims. */
+ *   of the same names — model_scal = scal of dpgp_model_prepare_t for the same D output dims.
+ *   stream_aux / ev_fork / ev_join (all three or none; dpgp_stream_create / dpgp_event_create): Psi1 and the product Psi1^T Y run
+ *   on stream_aux beside the fused reduction on the atoms — both are short latency-bound chains at small T.  Ignored while
+ *   `stream` is being captured into a graph. */
 
 /* hipEvent helpers for hosts without their own HIP binding */
 void *dpgp_event_create(void);
