@@ -412,7 +412,7 @@ def main():
                 torch.cuda.synchronize()
                 res['objective_over_t'] = {'ms': 1e3 * (time.perf_counter() - t0) / reps, 'reps': reps,
                                            'truncation_level': int(p['phi'].shape[1]),
-                                           'note': 'dp_gp_lvm_t objective: dpgp_model_prepare_t + dpgp_elbo_fhat_t (fused, eleven launches) for M <= 128; '
+                                           'note': 'dp_gp_lvm_t objective: dpgp_model_prepare_t + dpgp_elbo_fhat_t (fused, eleven launches on two streams) for M <= 128; '
                                                    'composed of the library operators otherwise and for the gradients'}
                 if a.prec == 'mixed':
                     res['objective_over_t']['with_gradients_ms'] = grad_ms(model_t, reps)
