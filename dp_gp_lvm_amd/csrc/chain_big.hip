@@ -47,24 +47,23 @@ static CbLayout cb_layout(int M) {
     return c;
 }
 
-// Kw = lower(K0) with identity padding, Ww = I; block-lower region only (what the persistent kernels read); grid (Mw / 64, D)
+// Kw = lower(K0) with identity padding; block-lower region only (what the persistent kernels read); grid (Mw / 64, D).
+// (Ww, the scratch of the solve W = L_K^-1 I, needs no initialisation: launch_ptrsm_persist(..., identity = 1))
 __global__ __launch_bounds__(256) void cbig_pad_kernel(int M, int Mp, int Mw, double *__restrict__ ws, size_t stride, size_t off_kw,
                                                        size_t off_ww) {
     const int d = blockIdx.y, i0 = CB_ROWS * blockIdx.x, t = threadIdx.x;
     const double *K0 = ws + (size_t)d * stride;
-    double *Kw = ws + (size_t)d * stride + off_kw, *Ww = ws + (size_t)d * stride + off_ww;
+    double *Kw = ws + (size_t)d * stride + off_kw;
     const int lim = 128 * (i0 / 128 + 1), npair = lim / 2;         // columns of the block-lower region of these rows
     for (int e = t; e < CB_ROWS * npair; e += 256) {
         const int i = i0 + e / npair, j = 2 * (e % npair);
-        cb_f2 kv, wv;
+        cb_f2 kv;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int jj = j + u;
             kv[u] = (jj > i) ? 0.0 : ((i < M) ? K0[(size_t)i * Mp + jj] : (i == jj ? 1.0 : 0.0));
-            wv[u] = (i == jj) ? 1.0 : 0.0;
         }
         *reinterpret_cast<cb_f2 *>(Kw + (size_t)i * Mw + j) = kv;
-        *reinterpret_cast<cb_f2 *>(Ww + (size_t)i * Mw + j) = wv;
     }
 }
 
@@ -120,14 +119,20 @@ __global__ __launch_bounds__(256) void cbig_assemble_kernel(int D, int M, int Mp
     if (t == 0) ws[(size_t)d * stride + off_tail + 16 + blockIdx.x] = p2n2;
 }
 
-// c = L_B^-1 v (v = sum of the Psi1^T y slabs), |c|^2 and the two log-determinants; one workgroup per output dim
+// c = L_B^-1 v (v = sum of the Psi1^T y slabs), |c|^2 and the two log-determinants; one workgroup per output dim.
+// Forward substitution in blocks of 64 rows: the part of the rows left of the block as a matrix-vector product over all 256
+// threads (thread = (row, quarter of the columns), 32-byte loads), the 64 x 64 diagonal block staged in LDS and solved by one
+// wave with one lane per row (64 dependent steps of a shuffle and an LDS read).  (Round 3's first version went 16 rows at a
+// time, each step a global-load round trip and two barriers: 285 us at M = 512.)
+#define CB_TB 64
 __global__ __launch_bounds__(256) void cbig_trsv_kernel(int D, int M, int Mw, double *__restrict__ ws, size_t stride, size_t off_kw,
                                                         size_t off_bw, size_t off_tail, const double *__restrict__ v_part,
                                                         int ns1) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *scratch = reinterpret_cast<double *>(smem_raw);       // 8 doubles
-    double *rs = scratch + 8;                                      // 16 doubles
-    double *c = rs + 16;                                           // Mw doubles
+    double *rs = scratch + 8;                                      // CB_TB doubles
+    double *ld = rs + CB_TB;                                       // [CB_TB][CB_TB + 1]: the diagonal block
+    double *c = ld + CB_TB * (CB_TB + 1);                          // Mw doubles
     const int d = blockIdx.x, t = threadIdx.x;
     const double *LB = ws + (size_t)d * stride + off_bw, *LK = ws + (size_t)d * stride + off_kw;
     for (int j = t; j < Mw; j += 256) {
@@ -137,29 +142,33 @@ __global__ __launch_bounds__(256) void cbig_trsv_kernel(int D, int M, int Mw, do
         c[j] = a;
     }
     __syncthreads();
-    const int ntile = (M + 15) / 16, i = t >> 4, g = t & 15;
-    for (int I = 0; I < ntile; ++I) {
-        const double *row = LB + (size_t)(16 * I + i) * Mw;
+    const int nblk = (M + CB_TB - 1) / CB_TB, i = t >> 2, g = t & 3;
+    for (int Ib = 0; Ib < nblk; ++Ib) {
+        const double *row = LB + (size_t)(CB_TB * Ib + i) * Mw;
         double a = 0.0;
-        for (int j = g; j < 16 * I; j += 16) a += row[j] * c[j];
+        for (int j = 4 * g; j < CB_TB * Ib; j += 16) {
+            const cb_f4 l4 = *reinterpret_cast<const cb_f4 *>(row + j);
+            a += (l4[0] * c[j] + l4[1] * c[j + 1]) + (l4[2] * c[j + 2] + l4[3] * c[j + 3]);
+        }
+        a += __shfl_xor(a, 1, 4);
+        a += __shfl_xor(a, 2, 4);
+        if (g == 0) rs[i] = c[CB_TB * Ib + i] - a;
+        for (int e = t; e < CB_TB * CB_TB / 4; e += 256) {        // the diagonal block -> LDS (16 threads per row)
+            const int r = e >> 4, c4 = (e & 15) * 4;
+            const cb_f4 l4 = *reinterpret_cast<const cb_f4 *>(LB + (size_t)(CB_TB * Ib + r) * Mw + CB_TB * Ib + c4);
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) a += __shfl_xor(a, o, 16);
-        if (g == 0) rs[i] = c[16 * I + i] - a;
+            for (int u = 0; u < 4; ++u) ld[r * (CB_TB + 1) + c4 + u] = l4[u];
+        }
         __syncthreads();
-        if (t < 16) {                                              // forward substitution through the diagonal tile: lane = row
-            const double *dr = LB + (size_t)(16 * I + t) * Mw + 16 * I;
-            double lr[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) lr[j] = dr[j];
-            const double rd = 1.0 / lr[t & 15];
+        if (t < CB_TB) {                                           // one wave, lane = row (rows >= M: identity padding, v = 0)
+            const double rd = 1.0 / ld[t * (CB_TB + 1) + t];
             double x = rs[t];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double xj = __shfl(x * rd, j, 16);
-                if (t > j) x -= lr[j] * xj;
+            for (int j = 0; j < CB_TB; ++j) {
+                const double xj = __shfl(x * rd, j, 64);
+                if (t > j) x -= ld[t * (CB_TB + 1) + j] * xj;
                 if (t == j) x = xj;
             }
-            c[16 * I + t] = x;
+            c[CB_TB * Ib + t] = x;
         }
         __syncthreads();
     }
@@ -220,7 +229,7 @@ int launch_chain_big_k(int D, int M, double *ws, int *info_k, hipStream_t st) {
     DPGP_LAUNCH_CHECK();
     int rc;
     if ((rc = launch_potrf_persist(D, c.Mw, ws + c.kw, info_k, st, c.stride))) return rc;
-    return launch_ptrsm_persist(D, c.Mw, ws + c.kw, c.stride, ws + c.ww, c.stride, ws + c.tail + 0, c.stride, st);
+    return launch_ptrsm_persist(D, c.Mw, ws + c.kw, c.stride, ws + c.ww, c.stride, ws + c.tail + 0, c.stride, st, 1);
 }
 
 template <typename TP>
@@ -235,7 +244,10 @@ int launch_chain_big_b(int D, int N, int M, const TP *psi2_part, int ns2, const 
                        ws, c.stride, c.bw, c.tail);
     DPGP_LAUNCH_CHECK();
     if ((rc = launch_potrf_persist(D, c.Mw, ws + c.bw, info, st, c.stride))) return rc;
-    const size_t lds = sizeof(double) * (size_t)(24 + c.Mw);
+    const size_t lds = sizeof(double) * (size_t)(8 + CB_TB + CB_TB * (CB_TB + 1) + c.Mw);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(cbig_trsv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH();
     hipLaunchKernelGGL(cbig_trsv_kernel, dim3(D), dim3(256), lds, st, D, M, c.Mw, ws, c.stride, c.kw, c.bw, c.tail, v_part, ns1);
     DPGP_LAUNCH_CHECK();

@@ -83,7 +83,7 @@ int launch_potrf_persist(int B, int Mw, double *w, int *info, hipStream_t st, si
 // X = L^-1 R in place for lower-triangular R (zeros above the diagonal), same scheme; only nrm2[b * nstride] = |X_b|_F^2 is a
 // result (X is scratch afterwards: its last 128 rows are not stored)
 int launch_ptrsm_persist(int B, int Mw, const double *l, size_t lstride, double *x, size_t xstride, double *nrm2,
-                         size_t nstride, hipStream_t st);
+                         size_t nstride, hipStream_t st, int identity = 0);   // identity: R = I, x need not be initialised
 // quad[t][d] = scale[t]^2 |L_t^-1 v_td|^2 for the D columns of V_t = sum of nsl slabs vp[ks v_ss + (t M + r) D + d]; M <= 128,
 // lb: the lb_out image of launch_chain_b
 int launch_tcols_quad(int T, int M, int D, const double *lb, const double *vp, int nsl, long long v_ss, const double *scale,

@@ -516,7 +516,9 @@ static size_t pt_lds_bytes() {
 
 __global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const double *__restrict__ Lall, size_t lstride,
                                                                double *__restrict__ Xall, size_t xstride,
-                                                               double *__restrict__ nrm2, size_t nstride) {
+                                                               double *__restrict__ nrm2, size_t nstride, int identity) {
+    // identity != 0: R = I — X need not be initialised (its diagonal blocks are taken as I, the blocks below as 0 where they
+    // are first touched): the caller saves writing Mw^2 / 2 doubles per matrix and this kernel reading them
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *scratch = reinterpret_cast<double *>(smem_raw);
     double *base = reinterpret_cast<double *>(smem_raw + LA_LDS_HDR);
@@ -559,7 +561,11 @@ __global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const dou
             pp_f2 pre[16];
             if (wv < nct) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const pp_f2 *>(Xk + (size_t)(r0 + 8 * q) * Mw + 16 * wv + c2);
+                for (int q = 0; q < 16; ++q) {
+                    const int col = 16 * wv + c2 - PP_PW * k, r = r0 + 8 * q;             // (column inside the diagonal block if >= 0)
+                    if (identity && col >= 0) pre[q] = (pp_f2){r == col ? 1.0 : 0.0, r == col + 1 ? 1.0 : 0.0};
+                    else pre[q] = *reinterpret_cast<const pp_f2 *>(Xk + (size_t)r * Mw + 16 * wv + c2);
+                }
             }
             for (int ct = wv; ct < nct; ct += 4) {
 #pragma unroll
@@ -570,7 +576,11 @@ __global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const dou
                 if (ct + 4 < nct) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        pre[q] = *reinterpret_cast<const pp_f2 *>(Xk + (size_t)(r0 + 8 * q) * Mw + 16 * (ct + 4) + c2);
+                    {
+                        const int col = 16 * (ct + 4) + c2 - PP_PW * k, r = r0 + 8 * q;
+                        if (identity && col >= 0) pre[q] = (pp_f2){r == col ? 1.0 : 0.0, r == col + 1 ? 1.0 : 0.0};
+                        else pre[q] = *reinterpret_cast<const pp_f2 *>(Xk + (size_t)r * Mw + 16 * (ct + 4) + c2);
+                    }
                 }
                 pp_trsm_tile(S, tiles, linv, lane);
 #pragma unroll
@@ -641,7 +651,8 @@ __global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const dou
 #pragma unroll
                         for (int Jt = 0; Jt < PP_NT; ++Jt)
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) cold[i][Jt][v] = Cb[(size_t)(16 * rt + kk + 4 * v) * Mw + 16 * Jt + li];
+                            for (int v = 0; v < 4; ++v)
+                                cold[i][Jt][v] = (identity && cJ == k) ? 0.0 : Cb[(size_t)(16 * rt + kk + 4 * v) * Mw + 16 * Jt + li];
                     }
                 }
                 const double *xs = base + (size_t)(step & 1) * (PP_PW * PP_KLD + PP_KQ * PT_YLD), *ys = xs + (size_t)PP_PW * PP_KLD;
@@ -683,13 +694,13 @@ __global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const dou
 }
 
 int launch_ptrsm_persist(int B, int Mw, const double *l, size_t lstride, double *x, size_t xstride, double *nrm2,
-                         size_t nstride, hipStream_t st) {
+                         size_t nstride, hipStream_t st, int identity) {
     const size_t lds = pt_lds_bytes();
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(ptrsm_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return DPGP_ERR_LAUNCH;
     DPGP_PRELAUNCH();
-    hipLaunchKernelGGL(ptrsm_persistent_kernel, dim3(B), dim3(256), lds, st, Mw, l, lstride, x, xstride, nrm2, nstride);
+    hipLaunchKernelGGL(ptrsm_persistent_kernel, dim3(B), dim3(256), lds, st, Mw, l, lstride, x, xstride, nrm2, nstride, identity);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
