@@ -1,5 +1,5 @@
 #!/bin/bash
-# the left-looking persistent Cholesky against the right-looking one (DPGP_POTRF_LEFT=0): correctness and time, M = 512 and 384 / 640
+# the left-looking persistent Cholesky against the right-looking one (DPGP_POTRF_LEFT=0): correctness (scratch/test_persist.py shapes) and time at B = 256, M = 512
 cd "$(dirname "$0")/.."
 for left in 1 0; do
   echo "== DPGP_POTRF_LEFT=$left"
