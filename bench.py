@@ -12,6 +12,7 @@ reference reads the objective only every 100 iterations, test/synthetic_data_har
 checked after timing.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--prec mixed] [--graph auto|on|off] [--no-cpu-baseline]
+        (N > 1 without a rendezvous in the environment: starts the N ranks itself as a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `value` is whole-job evaluations/s (D=512 is a fixed total: strong scaling).
@@ -196,8 +197,30 @@ def profiled_traffic(cfg, prec, world):
     return float(rec['bytes_per_launch']), rec
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment (the driver's command line): start the N
+    ranks as a CHILD process group — `python -m torch.distributed.run --nnodes 1 --nproc-per-node N bench.py <same flags>` —
+    before this process has imported torch or touched the GPU, let rank 0's JSON line through on stdout and return the
+    child's exit code.  (Never os.exec*: replacing a process that has initialised the GPU takes the machine down.)"""
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if not port:
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = str(sock.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a))
     import torch
     import torch.distributed as dist
     from dp_gp_lvm_amd import _lib

@@ -17,6 +17,7 @@
 // Workgroup = (output dim, 16 column tiles: 4 waves x 4 resident tiles); it loops over ALL row chunks with the second-product
 // accumulators in registers and writes them once — no partial slabs, no atomics (bit-reproducible).
 #include <type_traits>
+#include <utility>
 #include "internal.h"
 #include "psi2_consts.h"
 
@@ -26,39 +27,48 @@ typedef float pg_f16v __attribute__((ext_vector_type(16)));
 typedef float pg_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 
-#define PG_APAD 8
 #define PG_HDR 512
-#ifndef PG_G
-#define PG_G 4                       // resident column tiles per wave (2: the row images are re-read twice as often, 7.3 vs 6.6 ms at config 3)
-#endif
 #define PG_WSHIFT 12.0f              // the exponent tiles carry + PG_WSHIFT: W = 2^12 exp2(E) <= 4096 uses the f16 range downwards
                                      // (f16 pairs resolve W / max W down to ~2^-36 instead of 2^-24); undone in the finishing kernels
-#ifndef PG_OCC
-#define PG_OCC 2                     // workgroups per compute unit the pass kernel is built for (registers, LDS buffers)
+#ifndef PG_WLO
+#define PG_WLO 1                     // 0 (diagnostic builds only): no lo half of the exponentials (11-bit W in the second product)
 #endif
-#define PG_NF 32                     // feature rows of the second product (2Q + 1 used)
+#define PG_FB 32                     // feature rows of one block of the second product (one 32-row matrix instruction)
 
-// position of (feature f, row rr of a 32-row tile) in the transposed feature image of one (kind, row tile): the k-slot order
-// of the second product's operands = the register order the exponent tile arrives in
+// Kernel configuration by the K-steps of the exponent product (KS = psi2_pairs_ksteps(Q)):
+//   NFB  feature blocks of 32 rows of the second product (2Q + 1 features: Q <= 15 one block, Q <= 20 two)
+//   G    resident column tiles per wave;  NW waves per workgroup, ONE workgroup per compute unit (two waves per SIMD, 256
+//        registers per lane, the whole LDS): with G = 4 and four waves (round 3) the new loop spilled its column operands
+#ifndef PG_G4
+#define PG_G4 2
+#endif
+template <int KS> struct PgCfg { static constexpr int NFB = 1, G = PG_G4, NW = 8; };
+template <> struct PgCfg<6> { static constexpr int NFB = 1, G = 2, NW = 8; };
+template <> struct PgCfg<8> { static constexpr int NFB = 2, G = 2, NW = 8; };
+__host__ __device__ inline int pg_nfb(int KS) { return KS >= 8 ? 2 : 1; }
+
+// position of (feature f < 32 of a block, row rr of a 32-row tile) in the transposed feature image of one (row tile, block,
+// kind): the k-slot order of the second product's operands = the register order the exponent tile arrives in
 __device__ __forceinline__ int pg_xt_index(int f, int rr) {
     const int c = rr >> 3, h = (rr >> 2) & 1, j = rr & 3, s_ = c >> 1, t_ = 4 * (c & 1) + j;
     return (((s_ * 2 + h) * 32) + f) * 8 + t_;
 }
-// feature f of row rr as an f16 (hi, lo) pair into the two transposed images (xh, xl: this row tile's)
-__device__ __forceinline__ void pg_put(_Float16 *xh, _Float16 *xl, int f, int rr, float v) {
+// feature f (< 32 NFB) of row rr as an f16 (hi, lo) pair into the transposed images of this row tile: xt = [block][hi | lo][1024]
+__device__ __forceinline__ void pg_put(_Float16 *xt, int f, int rr, float v) {
     v = dpgp_pin(v);
     const _Float16 vh = (_Float16)v;
-    const int ix = pg_xt_index(f, rr);
+    _Float16 *xh = xt + (size_t)(f >> 5) * 2048;
+    const int ix = pg_xt_index(f & 31, rr);
     xh[ix] = vh;
-    xl[ix] = (_Float16)(v - (float)vh);
+    xh[1024 + ix] = (_Float16)(v - (float)vh);
 }
 
 // ---- the row of the exponent GEMM's A operand for observation n of output dim d (as phase A of psi2_pairs_kernel) --------
-// dst: 8 KS words (16 KS f16 slots); xh != nullptr: also the features a'_q, b_q (the values the slots were split from) of
-// this row (rr within its tile) into the transposed images
+// dst: 8 KS words (16 KS f16 slots); xt != nullptr: also the features a'_q, b_q (the values the slots were split from) of
+// this row (rr within its tile) into the transposed images of its row tile
 template <int KS>
 __device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const double *__restrict__ mu, const double *__restrict__ s,
-                                           const float *gq, const float *zc, unsigned *dst, _Float16 *xh, _Float16 *xl, int rr) {
+                                           const float *gq, const float *zc, unsigned *dst, _Float16 *xt, int rr) {
     constexpr int SLP = 16 * KS;
     bool oor = false;
     float cc = -60000.0f;
@@ -76,17 +86,17 @@ __device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const doubl
             dst[3 * q] = __builtin_bit_cast(unsigned, w0);
             dst[3 * q + 1] = __builtin_bit_cast(unsigned, w1);
             dst[3 * q + 2] = __builtin_bit_cast(unsigned, w2);
-            if (xh) {
-                pg_put(xh, xl, 2 * q, rr, (float)ah + (float)alo);
-                pg_put(xh, xl, 2 * q + 1, rr, (float)bh + (float)blo);
+            if (xt) {
+                pg_put(xt, 2 * q, rr, (float)ah + (float)alo);
+                pg_put(xt, 2 * q + 1, rr, (float)bh + (float)blo);
             }
         }
         oor = !(cc >= -8192.0f);                                  // range guard of the f16-split exponent (psi2_pairs.hip)
         cc = fmaxf(cc, -60000.0f) + PG_WSHIFT;
     } else {
         for (int q = 0; q < 3 * Q; ++q) dst[q] = 0u;
-        if (xh)
-            for (int f = 0; f < 2 * Q; ++f) pg_put(xh, xl, f, rr, 0.0f);
+        if (xt)
+            for (int f = 0; f < 2 * Q; ++f) pg_put(xt, f, rr, 0.0f);
     }
     cc = dpgp_pin(cc);
     const _Float16 ch = (_Float16)cc;
@@ -146,21 +156,22 @@ __global__ __launch_bounds__(256) void pg_u_kernel(int M, int Q, int Mp, const d
 
 // ---- precomputed images -----------------------------------------------------------------------------------------------
 // Every workgroup of a pass re-reads the row images of its output dim chunk by chunk; they are built ONCE per evaluation
-// (observation side: per output dim; pair side: the exponent rows are shared by all output dims, the features carry u_dp):
-//   operand order   cimg[set][tile][ks][lane 0..63][8 halves]   lane = 32 half + row % 32 holds slots 16 ks + 8 half .. + 7
-//   row major       rimg[set][row][16 KS halves]                (the LDS copy adds the bank padding)
-//   features        ximg[set][tile][kind hi / lo][K-step 0 / 1][lane][8 halves]   (pg_xt_index: the second product's A operand)
+// (observation side: per output dim; pair side: the exponent rows are shared by all output dims — the forward's pair image in
+// psi2_consts — and the features carry u_dp):
+//   operand order   cimg[set][tile][ks][lane 0..63][8 halves]   lane = 32 half + row % 32 holds slots 16 ks + 8 half .. + 7:
+//                   the SAME image serves as the column operand of one pass (registers) and as the row operand of the other
+//                   (LDS: a wave-wide read of one K-step is 1 KB contiguous, no padding, and the fill is a linear copy)
+//   features        ximg[set][tile][block][kind hi / lo][K-step 0 / 1][lane][8 halves]   (pg_xt_index: the second product's A operand)
 template <int KS>
 __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const unsigned char *__restrict__ consts,
                                                             const double *__restrict__ mu, const double *__restrict__ s,
                                                             const double *__restrict__ gamma, _Float16 *__restrict__ cimg,
-                                                            _Float16 *__restrict__ rimg, _Float16 *__restrict__ ximg, int NT,
-                                                            int *__restrict__ flag) {
-    constexpr int SLP = 16 * KS, RW = SLP / 2 + 4;
+                                                            _Float16 *__restrict__ ximg, int NT, int *__restrict__ flag) {
+    constexpr int SLP = 16 * KS, RW = SLP / 2 + 4, NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *gq = reinterpret_cast<float *>(smem_raw), *zc = gq + 32;
     unsigned *rows = reinterpret_cast<unsigned *>(smem_raw + 256);                 // [256][RW]
-    _Float16 *xt = reinterpret_cast<_Float16 *>(rows + 256 * RW);                  // [8 tiles][2][2][64][8]
+    _Float16 *xt = reinterpret_cast<_Float16 *>(rows + 256 * RW);                  // [8 tiles][NFB][2][2][64][8]
     const int d = blockIdx.y, t = threadIdx.x, n0 = 256 * blockIdx.x;
     if (t < 32) {
         gq[t] = (t < Q) ? (float)gamma[(size_t)d * Q + t] : 0.0f;
@@ -168,11 +179,11 @@ __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const 
     }
     __syncthreads();
     {
-        _Float16 *xh = xt + (size_t)(t >> 5) * 2048, *xl = xh + 1024;
+        _Float16 *xr = xt + (size_t)(t >> 5) * 2048 * NFB;
         const bool valid = n0 + t < N;
-        const bool oor = pg_obs_row<KS>(valid, n0 + t, Q, mu, s, gq, zc, rows + t * RW, xh, xl, t & 31);
-        pg_put(xh, xl, 2 * Q, t & 31, valid ? 1.0f : 0.0f);
-        for (int f = 2 * Q + 1; f < PG_NF; ++f) pg_put(xh, xl, f, t & 31, 0.0f);
+        const bool oor = pg_obs_row<KS>(valid, n0 + t, Q, mu, s, gq, zc, rows + t * RW, xr, t & 31);
+        pg_put(xr, 2 * Q, t & 31, valid ? 1.0f : 0.0f);
+        for (int f = 2 * Q + 1; f < NF; ++f) pg_put(xr, f, t & 31, 0.0f);
         if (oor) atomicOr(flag, 1);
     }
     __syncthreads();
@@ -183,23 +194,17 @@ __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const 
         const unsigned *r = rows + (32 * tl + (lane & 31)) * RW + 8 * ks + 4 * (lane >> 5);
         cd[e] = (pg_u4){r[0], r[1], r[2], r[3]};
     }
-    pg_u4 *rd = reinterpret_cast<pg_u4 *>(rimg) + ((size_t)d * NT + tile0) * 32 * (SLP / 8);
-    for (int e = t; e < ntl * 32 * (SLP / 8); e += 256) {
-        const int row = e / (SLP / 8), w = e - row * (SLP / 8);
-        const unsigned *r = rows + row * RW + 4 * w;
-        rd[e] = (pg_u4){r[0], r[1], r[2], r[3]};
-    }
-    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * NT + tile0) * 256;
-    for (int e = t; e < ntl * 256; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
+    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * NT + tile0) * 256 * NFB;
+    for (int e = t; e < ntl * 256 * NFB; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
 }
 
-// pair side: thread = pair; ximg per output dim (features x kap_d u_dp), rimg once (blockIdx.y == 0)
+// pair side: thread = pair; ximg per output dim (features x kap_d u_dp)
 template <int KS>
 __global__ __launch_bounds__(256) void pg_pair_images_kernel(int M, int Q, const unsigned char *__restrict__ consts,
                                                              const float *__restrict__ u, const float *__restrict__ kap,
-                                                             _Float16 *__restrict__ rimg, _Float16 *__restrict__ ximg) {
-    constexpr int SLP = 16 * KS;
-    __shared__ __align__(16) _Float16 xt[8 * 2048];
+                                                             _Float16 *__restrict__ ximg) {
+    constexpr int SLP = 16 * KS, NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
+    __shared__ __align__(16) _Float16 xt[8 * 2048 * NFB];
     const Psi2Consts C = psi2_consts_layout(M, Q);
     const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
     const int d = blockIdx.y, t = threadIdx.x, p0 = 256 * blockIdx.x, p = p0 + t, PT = C.Ppad / 32;
@@ -215,211 +220,312 @@ __global__ __launch_bounds__(256) void pg_pair_images_kernel(int M, int Q, const
                 row[8 * ks + 4 * hf] = w[0]; row[8 * ks + 4 * hf + 1] = w[1];
                 row[8 * ks + 4 * hf + 2] = w[2]; row[8 * ks + 4 * hf + 3] = w[3];
             }
-        if (d == 0) {
-            pg_u4 *rd = reinterpret_cast<pg_u4 *>(rimg) + (size_t)p * (SLP / 8);
-#pragma unroll
-            for (int w = 0; w < SLP / 8; ++w) rd[w] = (pg_u4){row[4 * w], row[4 * w + 1], row[4 * w + 2], row[4 * w + 3]};
-        }
         const float up = kap[d] * u[(size_t)d * C.Ppad + p];
-        _Float16 *xh = xt + (size_t)(t >> 5) * 2048, *xl = xh + 1024;
+        _Float16 *xr = xt + (size_t)(t >> 5) * 2048 * NFB;
         const int rr = t & 31;
 #pragma unroll
         for (int q = 0; q < DPGP_MAX_Q; ++q) {                    // slots {h, l, h | h, l, h} of (s^2 / 64, s): words 3q .. 3q + 2
             if (q < Q && 3 * q + 2 < SLP / 2) {
                 const pg_h2 w0 = __builtin_bit_cast(pg_h2, row[3 * q]), w1 = __builtin_bit_cast(pg_h2, row[3 * q + 1]),
                             w2 = __builtin_bit_cast(pg_h2, row[3 * q + 2]);
-                pg_put(xh, xl, 2 * q, rr, up * ((float)w0[0] + (float)w0[1]));
-                pg_put(xh, xl, 2 * q + 1, rr, up * ((float)w1[1] + (float)w2[0]));
+                pg_put(xr, 2 * q, rr, up * ((float)w0[0] + (float)w0[1]));
+                pg_put(xr, 2 * q + 1, rr, up * ((float)w1[1] + (float)w2[0]));
             }
         }
-        pg_put(xh, xl, 2 * Q, rr, up);
-        for (int f = 2 * Q + 1; f < PG_NF; ++f) pg_put(xh, xl, f, rr, 0.0f);
+        pg_put(xr, 2 * Q, rr, up);
+        for (int f = 2 * Q + 1; f < NF; ++f) pg_put(xr, f, rr, 0.0f);
     }
     __syncthreads();
-    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * PT + tile0) * 256;
-    for (int e = t; e < ntl * 256; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
+    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * PT + tile0) * 256 * NFB;
+    for (int e = t; e < ntl * 256 * NFB; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
 }
 
-// ---- one pass: rows (LDS, chunked copies of rimg / ximg) x resident column tiles (cimg) ------------------------------------
-// out[set][column][PG_NF] = sum_rows exp2(E[row, column]) X[row, :].  Pass 1: rows = observations of output dim d, columns =
-// pairs; pass 2: rows = pairs, columns = observations of output dim d.  row_set / x_set / col_set: 1 = the images are per
-// output dim, 0 = shared.
+// ---- one pass: rows (LDS ring, LDS-DMA copies of an operand-order image and of ximg) x resident column tiles (cimg) --------
+// out[set][column][32 NFB] = sum_rows exp2(E[row, column]) X[row, :].  Pass 1: rows = observations of output dim d, columns =
+// pairs; pass 2: rows = pairs, columns = observations of output dim d.  row_per_d / col_per_d: 1 = that operand image is per
+// output dim, 0 = shared (the pair image).
+//
+// Per tile step (32 rows x 32 columns) the matrix pipe has NM = KS + 6 NFB instructions (KS of the NEXT step's exponent chain,
+// 3 NFB second-product instructions on the K-step-1 half of the PREVIOUS step's exponentials and 3 NFB on the K-step-0 half of
+// this step's) and the vector unit NV = 40: per two exponents  v_exp_f32 x 2, v_cvt_pk_f16_f32 (the hi words),
+// v_fma_mixlo_f16 + v_fma_mixhi_f16 (lo = f16(e - hi), straight into the register of e: no second conversion).  Round 3's
+// loop issued them as 7 matrix + 4 x 9 vector instructions in the first half of a step and 3 + 4 x 9 in the second (s_nops
+// included): both pipes were busy ~340 of 488 cycles per step and overlapped for 199 (rocprofv3: SQ_VALU_MFMA_BUSY_CYCLES,
+// SQ_ACTIVE_INST_VALU, SQ_VALU_MFMA_COEXEC_CYCLES).  Here ONE matrix instruction is followed by NV / NM vector instructions
+// throughout (the order is generated at compile time: pg_slot), the exponentials of element pair i + 1 sit between those of pair
+// i and their conversion (no wait state behind a transcendental), and the pipeline runs through the chunk boundaries.
+struct PgSlot { int kind, i; };      // kind 0: exponent chain K-step i; 1: product i of the previous step's K-step-1 half; 2: of this step's K-step-0 half
+struct PgUnit { int kind, i; };      // kind 0: v_exp_f32 of element i; 1: v_cvt_pk_f16_f32 (hi) of element pair i; 2: the two v_fma_mix_f32 (e - hi) of pair i; 3: v_cvt_pk_f16_f32 (lo)
+template <int KS, int NFB> struct PgSched {
+    // vector units of a step, in order (E: exponential, C: hi words, L: the two residuals, D: lo words)
+    //   E0 E1 | E2 E3 C0 L0 | (E_{2i+2} E_{2i+3} C_i L_i D_{i-1}) for i = 1 .. 6 | C7 L7 D6 D7
+    // the exponentials of pair i + 1 sit between those of pair i and their conversion (no wait state behind a transcendental), and
+    // the lo conversion of a pair follows the NEXT pair's residuals (the compiler pads an asm statement whose result is read by
+    // the very next instruction with an s_nop)
+    static constexpr int NU = 40, CYC = 256, NM = KS + 6 * NFB, NK = 3 * NFB;
+    static constexpr PgUnit unit(int u) {
+        if (u < 2) return PgUnit{0, u};
+        if (u < 6) return u < 4 ? PgUnit{0, u} : PgUnit{u - 3, 0};
+        if (u >= 36) return u == 36 ? PgUnit{1, 7} : (u == 37 ? PgUnit{2, 7} : PgUnit{3, u - 32});
+        const int i = (u - 6) / 5 + 1, r = (u - 6) % 5;
+        return r < 2 ? PgUnit{0, 2 * (i + 1) + r} : (r == 4 ? PgUnit{3, i - 1} : PgUnit{r - 1, i});
+    }
+    static constexpr int cost(int u) { return (unit(u).kind & 1) ? 4 : 8; }    // issue cycles (MI355X guide; v_fma_mixlo/hi_f16 would
+    static constexpr int cum(int u) { int c = 0; for (int k = 0; k < u; ++k) c += cost(k); return c; }   // save the second conversion but cost 8-9 each: measured)
+    static constexpr int U_D3 = 25;                               // unit D_3: behind it the words 0-3 are complete
+    static_assert(unit(U_D3).kind == 3 && unit(U_D3).i == 3, "unit table");
+    // the first J0 slots hold the KS-step exponent chain of the next step (NE1 of its instructions) and the NK products of the
+    // previous step's K-step-1 half; the others the products of this step's K-step-0 half, which need the words 0-3
+    static constexpr int J0raw = (cum(U_D3 + 1) * NM + CYC - 1) / CYC;
+    static constexpr int J0 = J0raw < KS + NK ? J0raw : KS + NK;
+    static constexpr int NE1 = J0 - NK;
+    static_assert(NE1 >= 0 && NE1 <= KS && NM - J0 >= NK, "slot table");
+    static constexpr PgSlot slot(int j) {
+        int e = 0, k = 0;
+        if (j < J0) {                                             // chain first on a tie
+            for (int jj = 0;; ++jj) {
+                const bool pe = (e < NE1) && (k >= NK || e * NK <= k * NE1);
+                if (jj == j) return pe ? PgSlot{0, e} : PgSlot{1, k};
+                if (pe) ++e; else ++k;
+            }
+        }
+        const int ne2 = KS - NE1;
+        for (int jj = J0;; ++jj) {                                // products first on a tie
+            const bool pk = (k < NK) && (e >= ne2 || k * ne2 <= e * NK);
+            if (jj == j) return pk ? PgSlot{2, k} : PgSlot{0, NE1 + e};
+            if (pk) ++k; else ++e;
+        }
+    }
+    static constexpr int first_of(int kind) { for (int j = 0; j < NM; ++j) if (slot(j).kind == kind) return j; return -1; }
+    // matrix slot j sits in front of the first unit that starts at or behind cycle CYC j / NM of the vector stream (slots >= J0:
+    // not in front of unit U_D3 + 1)
+    static constexpr int unit_of_slot(int j) {
+        const int want = (CYC * j + NM - 1) / NM;
+        int u = 0;
+        while (u < NU - 1 && cum(u) < want) ++u;
+        return (j >= J0 && u <= U_D3) ? U_D3 + 1 : u;
+    }
+};
+template <int... I, typename F> __device__ __forceinline__ void pg_unroll(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+__device__ __forceinline__ pg_h8 pg_quad(unsigned a, unsigned b, unsigned c, unsigned d) {
+    return __builtin_bit_cast(pg_h8, (pg_u4){a, b, c, d});
+}
+
+// One tile step.  c_cur: this step's exponent tile (16 values per lane); c_nxt: the next step's (chain a_n x b_n, issued here);
+// acc_p / x1h, x1l / (wh1, wl1): accumulators, K-step-1 feature operands and K-step-1 words of the PREVIOUS step (wh1, wl1 are
+// replaced by this step's on return); acc_c / x0h, x0l: this step's accumulators and K-step-0 feature operands.
+// hook(j): called behind matrix slot j (the caller's LDS reads ride there).
+template <int KS, int NFB, typename HOOK>
+__device__ __forceinline__ void pg_step(pg_f16v &c_nxt, const pg_f16v &c_cur, const pg_h8 (&a_n)[KS], const pg_h8 (&b_n)[KS],
+                                        pg_f16v (&acc_p)[NFB], pg_f16v (&acc_c)[NFB], const pg_h8 (&x0h)[NFB],
+                                        const pg_h8 (&x0l)[NFB], const pg_h8 (&x1h)[NFB], const pg_h8 (&x1l)[NFB], pg_h8 &wh1,
+                                        pg_h8 &wl1, HOOK &&hook) {
+    typedef PgSched<KS, NFB> S;
+    float ex[16];
+    unsigned hw[8], lw[8];
+    const pg_h8 wh1p = wh1, wl1p = wl1;
+    pg_h8 wh0, wl0;
+    auto matrix = [&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr PgSlot sl = S::slot(j);
+        if constexpr (sl.kind == 0) {
+            if constexpr (sl.i == 0) {
+                const pg_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                c_nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_n[0], b_n[0], zero, 0, 0, 0);
+            } else {
+                c_nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_n[sl.i], b_n[sl.i], c_nxt, 0, 0, 0);
+            }
+        } else if constexpr (PG_WLO || sl.i / NFB != 1) {
+            constexpr int fb = sl.i % NFB, pr = sl.i / NFB;       // products (X_hi, W_hi), (X_hi, W_lo), (X_lo, W_hi), blocks interleaved
+            if constexpr (sl.kind == 1)
+                acc_p[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? x1l[fb] : x1h[fb], pr == 1 ? wl1p : wh1p, acc_p[fb], 0, 0, 0);
+            else
+                acc_c[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? x0l[fb] : x0h[fb], pr == 1 ? wl0 : wh0, acc_c[fb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hook(jc);
+    };
+    auto vector = [&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        pg_unroll(std::make_integer_sequence<int, S::NM>{}, [&](auto jc) __attribute__((always_inline)) {
+            if constexpr (S::unit_of_slot(decltype(jc)::value) == u) matrix(jc);
+        });
+        constexpr PgUnit un = S::unit(u);
+        constexpr int i = un.i;
+        if constexpr (un.kind == 0) {
+            ex[i] = __builtin_amdgcn_exp2f(c_cur[i]);
+        } else if constexpr (un.kind == 1) {
+            const pg_h2 hi = {(_Float16)ex[2 * i], (_Float16)ex[2 * i + 1]};
+            hw[i] = __builtin_bit_cast(unsigned, hi);
+            if constexpr (i == 3) wh0 = pg_quad(hw[0], hw[1], hw[2], hw[3]);
+        } else if constexpr (!PG_WLO) {
+        } else if constexpr (un.kind == 2) {
+            // e - hi in place, from the f16 halves (one instruction each instead of v_cvt_f32_f16 + v_sub_f32).  The registers were
+            // written by the compiler-visible v_exp_f32 just before, so the hazard recognizer (which does not see inside asm) has
+            // already cleared them against matrix instructions in flight; the operand words themselves are written by compiler-
+            // visible conversions.  ONE statement: the compiler pads every separate asm statement with an s_nop.
+            asm("v_fma_mix_f32 %0, %2, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mix_f32 %1, %2, -1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                : "+v"(ex[2 * i]), "+v"(ex[2 * i + 1]) : "v"(hw[i]));
+        } else {
+            const pg_h2 lo = {(_Float16)ex[2 * i], (_Float16)ex[2 * i + 1]};
+            lw[i] = __builtin_bit_cast(unsigned, lo);
+            if constexpr (i == 3) wl0 = pg_quad(lw[0], lw[1], lw[2], lw[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    pg_unroll(std::make_integer_sequence<int, S::NU>{}, vector);
+    wh1 = pg_quad(hw[4], hw[5], hw[6], hw[7]);
+    wl1 = pg_quad(lw[4], lw[5], lw[6], lw[7]);
+}
+
 template <int KS>
-__global__ __launch_bounds__(256, PG_OCC) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
-                                                         const _Float16 *__restrict__ ximg, const _Float16 *__restrict__ cimg,
-                                                         int col_per_d, float *__restrict__ out, int n_row_tiles, int n_col_tiles,
-                                                         int groups_per_d, int R) {
-    constexpr int SLP = 16 * KS, LDA = SLP + PG_APAD, G = PG_G;
+__global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::NW / 4) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
+                                                                   const _Float16 *__restrict__ ximg,
+                                                                   const _Float16 *__restrict__ cimg, int col_per_d,
+                                                                   float *__restrict__ out, int n_row_tiles, int n_col_tiles,
+                                                                   int groups_per_d, int NTb) {
+    constexpr int NFB = PgCfg<KS>::NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW, NF = PG_FB * NFB;
+    constexpr int PIECES = KS + 4 * NFB, TILE_BYTES = 1024 * PIECES;   // LDS bytes of one row tile: K-steps of the exponent operand, then the features
+    typedef PgSched<KS, NFB> S;
+    static_assert((G & 1) == 0, "the two exponent tiles alternate");
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    // Two LDS buffers of NTb = R / 32 row tiles each, filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, the
-    // data lands while the waves compute on the other buffer).  The destination of one wave-instruction is lane-linear (base +
-    // 16 lane), so a buffer is one array of 16-byte slots — [row][LDA halves] rows, then the feature image [kind][tile][128
-    // slots] — and every lane computes the SOURCE address of its slot (the padding slots of a row fetch any valid word).
     typedef __attribute__((address_space(3))) void lds_void;
-    constexpr int SPR = LDA / 8, DPR = SLP / 8;                 // 16-byte slots per LDS row / per image row
-    const int NTb = R / 32, ri_slots = ((NTb * 32 * SPR + 63) / 64) * 64;
-    const size_t buf_bytes = (size_t)16 * (ri_slots + NTb * 256);
-    const int d = blockIdx.x / groups_per_d, cg = blockIdx.x - d * groups_per_d;
+    // same-d workgroups on one XCD (blocks are dealt round-robin over the 8 XCDs: speed only): they re-read the same row images
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int d = bid / groups_per_d, cg = bid - d * groups_per_d;
     const int t = threadIdx.x, lane = t & 63, l5 = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int NTc = NTb;
-    const pg_u4 *rsrc = reinterpret_cast<const pg_u4 *>(rimg) + (row_per_d ? (size_t)d * n_row_tiles * 32 * DPR : 0);
-    const pg_u4 *xsrc = reinterpret_cast<const pg_u4 *>(ximg) + (size_t)d * n_row_tiles * 256;
+    const int RING = 3 * NTb;                                    // row-tile slots of the LDS ring: three chunks of NTb
+    const unsigned char *rsrc = reinterpret_cast<const unsigned char *>(rimg) + (row_per_d ? (size_t)d * n_row_tiles * KS * 1024 : 0);
+    const unsigned char *xsrc = reinterpret_cast<const unsigned char *>(ximg) + (size_t)d * n_row_tiles * NFB * 4096;
     const _Float16 *csrc = cimg + (col_per_d ? (size_t)d * n_col_tiles * KS * 64 * 8 : 0);
-    auto fill = [&](int buf, int rt0, int ntile) __attribute__((always_inline)) {
-        unsigned char *base = smem_raw + (size_t)buf * buf_bytes;
-        const int n_ri = ntile * 32 * SPR, n_ri_instr = (n_ri + 63) >> 6;
-        for (int i = wv; i < n_ri_instr; i += 4) {               // (wave-uniform trip count)
-            const int j = 64 * i + lane, row = j / SPR, col = j - row * SPR;
-            const pg_u4 *src = rsrc;
-            if (j < n_ri && col < DPR) src = rsrc + ((size_t)rt0 * 32 + row) * DPR + col;
-            __builtin_amdgcn_global_load_lds(src, (lds_void *)(base + (size_t)1024 * i), 16, 0, 0);
-        }
-        for (int i = wv; i < ntile * 4; i += 4) {                 // feature image: (tile, kind, half of 128 slots) per instruction
-            const int rt = i >> 2, kind = (i >> 1) & 1, hf = i & 1;
-            const pg_u4 *src = xsrc + ((size_t)(rt0 + rt) * 256 + kind * 128 + hf * 64 + lane);
-            __builtin_amdgcn_global_load_lds(src, (lds_void *)(base + (size_t)16 * (ri_slots + (kind * NTb + rt) * 128 + hf * 64)), 16, 0, 0);
+    // chunk c = row tiles [c NTb, (c + 1) NTb) -> ring slots (c % 3) NTb ...: 1 KB pieces by LDS-DMA (global_load_lds_dwordx4: lane-linear
+    // destination, no staging registers), piece i of the chunk by wave i % NW
+    auto fill = [&](int c) __attribute__((always_inline)) {
+        const int rt0 = c * NTb, ntile = min(NTb, n_row_tiles - rt0);
+        unsigned char *base = smem_raw + (size_t)(c % 3) * NTb * TILE_BYTES;
+        for (int i = wv; i < ntile * PIECES; i += NW) {           // (wave-uniform)
+            const int tl = i / PIECES, pc = i - tl * PIECES;
+            const unsigned char *src = pc < KS ? rsrc + ((size_t)(rt0 + tl) * KS + pc) * 1024
+                                               : xsrc + ((size_t)(rt0 + tl) * NFB * 4 + (pc - KS)) * 1024;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const pg_u4 *>(src) + lane, (lds_void *)(base + (size_t)1024 * i), 16, 0, 0);
         }
     };
+    const int n_chunks = (n_row_tiles + NTb - 1) / NTb;
+    fill(0);
+    if (n_chunks > 1) fill(1);
     pg_h8 bop[G][KS];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int ct = min(cg * 4 * G + wv + 4 * g, n_col_tiles - 1);   // (a surplus tile of the last group repeats the last one; not stored)
-        const pg_h8 *row = reinterpret_cast<const pg_h8 *>(csrc) + (size_t)ct * KS * 64 + 32 * half + l5;
+        const int ct = min(cg * NW * G + wv + NW * g, n_col_tiles - 1);   // (a surplus tile of the last group repeats the last one; not stored)
+        const pg_h8 *row = reinterpret_cast<const pg_h8 *>(csrc) + (size_t)ct * KS * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bop[g][ks] = row[ks * 64];
     }
-    pg_f16v acc[G];
+    pg_f16v acc[G][NFB];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[g][v] = 0.0f;
-
-    fill(0, 0, min(NTb, n_row_tiles));
+        for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[g][fb][v] = 0.0f;
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    for (int rt0 = 0, cb = 0; rt0 < n_row_tiles; rt0 += NTb, cb ^= 1) {
-        const int ntile = min(NTb, n_row_tiles - rt0);
-        if (rt0 + NTb < n_row_tiles) fill(cb ^ 1, rt0 + NTb, min(NTb, n_row_tiles - rt0 - NTb));   // lands during the work below
-        const _Float16 *ri = reinterpret_cast<const _Float16 *>(smem_raw + (size_t)cb * buf_bytes);
-        const _Float16 *xt = ri + (size_t)8 * ri_slots;
-        // ---- software pipeline over the tile steps (row tile nt, resident tile g) --------------------------------------
-        // Per step the matrix pipe has KS + 6 MFMAs and the vector unit 16 exp + the (hi, lo) split of W; one wave's
-        // instruction stream alternates them.  Step k runs
-        //   first half  (values 0-7 of its exponent tile): the exponent chain of step k + 1  and  the K-step-1 products of step k - 1
-        //   second half (values 8-15):                      the K-step-0 products of step k (their operands are complete by then)
-        // two independent accumulation chains alternate on the pipe.  The last step of a row tile finishes its own products
-        // (the feature operands change with the row tile).
-        auto load_a = [&](pg_h8 (&a)[KS], int nt) __attribute__((always_inline)) {
+
+    // LDS reads of ring slot pos: the exponent operand (KS x 16 bytes per lane) and the feature operands of one K-step half
+    auto load_a = [&](pg_h8 (&a)[KS], int pos) __attribute__((always_inline)) {
+        const pg_h8 *p = reinterpret_cast<const pg_h8 *>(smem_raw + (size_t)pos * TILE_BYTES) + lane;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                a[ks] = *reinterpret_cast<const pg_h8 *>(ri + (size_t)(32 * nt + l5) * LDA + 16 * ks + 8 * half);
-        };
-        // values 2i, 2i + 1 of the exponent tile -> word i of the (hi, lo) operands: v_exp_f32 x 2, v_cvt_pk_f16_f32 (hi pair),
-        // v_fma_mix_f32 x 2 (e - hi from the f16 halves: one instruction instead of v_cvt_f32_f16 + v_sub_f32), v_cvt_pk_f16_f32
-        // (lo pair).  Only the fma_mix is inline asm, and it works IN PLACE on the register of e: inline-asm VALU writes are
-        // invisible to the compiler's hazard recognizer — with the conversions that write the MFMA OPERANDS in asm, operand
-        // registers of an MFMA still in flight were overwritten (measured: non-deterministic garbage as soon as registers were
-        // reused across tiles).  e's register was just written by v_exp_f32 (checked by the compiler, never an MFMA operand),
-        // and the operand words are written by compiler-visible conversions.
-        typedef _Float16 pg_h2v __attribute__((ext_vector_type(2)));
-        auto pair = [&](const pg_f16v &c, int i, pg_h8 (&wh)[2], pg_h8 (&wl)[2]) __attribute__((always_inline)) {
-            float e0 = __builtin_amdgcn_exp2f(c[2 * i]), e1 = __builtin_amdgcn_exp2f(c[2 * i + 1]);
-            const pg_h2v hi = {(_Float16)e0, (_Float16)e1};
-            const unsigned ph = __builtin_bit_cast(unsigned, hi);
-            asm("s_nop 0\n\tv_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(e0) : "v"(ph));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(e1) : "v"(ph));
-            const pg_h2v lo = {(_Float16)e0, (_Float16)e1};
-            const int v = 2 * i;
-            wh[v >> 3][v & 7] = hi[0]; wh[v >> 3][(v & 7) + 1] = hi[1];
-            wl[v >> 3][v & 7] = lo[0]; wl[v >> 3][(v & 7) + 1] = lo[1];
-        };
-#ifdef PG_DIAG_NO_MMA               // (timing experiments only: wrong results)
-#define PG_MMA(A, B, C) __builtin_amdgcn_sched_barrier(0)
-#else
-#define PG_MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
-#endif
-#ifdef PG_DIAG_NO_VALU              // (timing experiments only: wrong results)
-#define PG_PAIR(C, I) __builtin_amdgcn_sched_barrier(0)
-#else
-#define PG_PAIR(C, I) pair(C, I, wh, wl); __builtin_amdgcn_sched_barrier(0)
-#endif
-        pg_h8 a_cur[KS], a_nxt[KS], xh[2], xl[2], wh[2], wl[2];
-        pg_f16v c_cur, c_nxt;
-        load_a(a_cur, 0);
+        for (int ks = 0; ks < KS; ++ks) a[ks] = p[ks * 64];
+    };
+    auto load_x = [&](pg_h8 (&xh)[NFB], pg_h8 (&xl)[NFB], int pos, int kstep) __attribute__((always_inline)) {
+        const pg_h8 *p = reinterpret_cast<const pg_h8 *>(smem_raw + (size_t)pos * TILE_BYTES + 1024 * KS) + lane;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) c_cur[v] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) c_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[ks], bop[0][ks], c_cur, 0, 0, 0);
-#pragma unroll 1
-        for (int nt = 0; nt < ntile; ++nt) {
-            load_a(a_nxt, min(nt + 1, ntile - 1));
-#pragma unroll
-            for (int s_ = 0; s_ < 2; ++s_) {
-                xh[s_] = *reinterpret_cast<const pg_h8 *>(xt + (((size_t)(0 * NTc + nt) * 2 + s_) * 64 + lane) * 8);
-                xl[s_] = *reinterpret_cast<const pg_h8 *>(xt + (((size_t)(1 * NTc + nt) * 2 + s_) * 64 + lane) * 8);
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                // the exponent chain of the next step: tile g + 1 of this row tile, or tile 0 of the next one (behind the last
-                // row tile of the chunk: one surplus chain)
-                const pg_h8 (&an)[KS] = (g + 1 < G) ? a_cur : a_nxt;
-                const pg_h8 (&bn)[KS] = bop[(g + 1) % G];
-#pragma unroll
-                for (int v = 0; v < 16; ++v) c_nxt[v] = 0.0f;
-                const pg_h8 wh1 = wh[1], wl1 = wl[1];             // (of step k - 1)
-                // ---- first half ----
-                PG_MMA(an[0], bn[0], c_nxt);
-                PG_PAIR(c_cur, 0);
-                if (g > 0) { PG_MMA(xh[1], wh1, acc[g > 0 ? g - 1 : 0]); }
-                if (KS > 1) { PG_MMA(an[1 % KS], bn[1 % KS], c_nxt); }
-                PG_PAIR(c_cur, 1);
-                if (g > 0) { PG_MMA(xh[1], wl1, acc[g > 0 ? g - 1 : 0]); }
-                if (KS > 2) { PG_MMA(an[2 % KS], bn[2 % KS], c_nxt); }
-                PG_PAIR(c_cur, 2);
-                if (g > 0) { PG_MMA(xl[1], wh1, acc[g > 0 ? g - 1 : 0]); }
-                if (KS > 3) { PG_MMA(an[3 % KS], bn[3 % KS], c_nxt); }
-                PG_PAIR(c_cur, 3);
-                // ---- second half ----
-                const pg_h8 wh0 = wh[0], wl0 = wl[0];
-                PG_MMA(xh[0], wh0, acc[g]);
-                PG_PAIR(c_cur, 4);
-                PG_MMA(xh[0], wl0, acc[g]);
-                PG_PAIR(c_cur, 5);
-                PG_MMA(xl[0], wh0, acc[g]);
-                PG_PAIR(c_cur, 6);
-                PG_PAIR(c_cur, 7);
-                if (g == G - 1) {                                  // the row tile's last step finishes its own K-step-1 products
-                    const pg_h8 wh1e = wh[1], wl1e = wl[1];
-                    PG_MMA(xh[1], wh1e, acc[g]);
-                    PG_MMA(xh[1], wl1e, acc[g]);
-                    PG_MMA(xl[1], wh1e, acc[g]);
-                }
-                c_cur = c_nxt;
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+        for (int fb = 0; fb < NFB; ++fb) {                        // [block][kind][K-step][64 lanes]
+            xh[fb] = p[((fb * 2 + 0) * 2 + kstep) * 64];
+            xl[fb] = p[((fb * 2 + 1) * 2 + kstep) * 64];
         }
-#undef PG_MMA
-#undef PG_PAIR
-        __builtin_amdgcn_s_waitcnt(0);                            // this wave's LDS-DMAs of the next chunk have landed ...
-        __syncthreads();                                           // ... everybody's have, and everybody is done with this buffer
+    };
+    pg_h8 a_0[KS], a_1[KS], x0h[NFB], x0l[NFB], x1h[NFB], x1l[NFB];
+    pg_h8 wh1 = pg_quad(0u, 0u, 0u, 0u), wl1 = wh1;             // (the first step's "previous" products add zero)
+    pg_f16v c[2];
+    load_a(a_0, 0);
+    load_x(x1h, x1l, 0, 1);
+    {
+        const pg_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        c[0] = zero;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_0[ks], bop[0][ks], c[0], 0, 0, 0);
     }
-    // ---- out[d][column][f]: register v of lane (column l5, half) is feature 8 (v / 4) + 4 half + v % 4 ----
+    int pos = 0, in_chunk = 0, chunk = 0;                         // ring slot of row tile rt, its index in its chunk, its chunk
+    // one row tile: G steps against the resident column tiles; a_cur / a_nxt swap roles from one row tile to the next
+    auto row_tile = [&](const pg_h8 (&a_cur)[KS], pg_h8 (&a_nxt)[KS], int rt) __attribute__((always_inline)) {
+        if (in_chunk == NTb - 1 && chunk + 1 < n_chunks) {
+            // in front of the chunk's last row tile: the next chunk is complete in LDS (own pieces: vmcnt, everybody's: barrier), and
+            // everybody has left the previous chunk, whose ring slots take the chunk after the next
+            __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0)
+            __syncthreads();
+            if (chunk + 2 < n_chunks) fill(chunk + 2);
+        }
+        const int pos_n = (rt + 1 < n_row_tiles) ? (pos + 1 == RING ? 0 : pos + 1) : pos;   // (behind the last row tile: one surplus chain)
+        pg_unroll(std::make_integer_sequence<int, G>{}, [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            auto hook = [&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                // LDS reads of the row tile, each behind the last matrix instruction that reads the registers it replaces and a
+                // few slots ahead of its first use (a read issued just in front of a wait for an OLDER one is waited for as well:
+                // lgkmcnt counts in order).  Step 0: this row tile's K-step-0 features behind the first product of the previous
+                // step (the previous step's K-step-0 products are all issued), its K-step-1 features behind the first K-step-0
+                // product (the previous row tile's K-step-1 products are all issued); the next row tile's exponent operand one
+                // step ahead of its first use.
+                if constexpr (g == 0 && j == S::first_of(1)) load_x(x0h, x0l, pos, 0);
+                if constexpr (g == (G >= 2 ? G - 2 : 0) && j == S::first_of(1)) load_a(a_nxt, pos_n);
+                if constexpr (g == 0 && j == S::J0) load_x(x1h, x1l, pos, 1);
+            };
+            if constexpr (g + 1 < G)
+                pg_step<KS, NFB>(c[(g + 1) & 1], c[g & 1], a_cur, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
+            else
+                pg_step<KS, NFB>(c[(g + 1) & 1], c[g & 1], a_nxt, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
+        });
+        pos = pos_n;
+        if (++in_chunk == NTb) { in_chunk = 0; ++chunk; }
+    };
+#pragma unroll 1
+    for (int rt = 0; rt + 1 < n_row_tiles; rt += 2) {          // (pairs: the two operand buffers swap roles without register moves;
+        row_tile(a_0, a_1, rt);                                   //  a break between the two made the compiler copy the accumulators)
+        row_tile(a_1, a_0, rt + 1);
+    }
+    if (n_row_tiles & 1) row_tile(a_0, a_1, n_row_tiles - 1);
+    // the last step's K-step-1 half
+#pragma unroll
+    for (int i = 0; i < 3 * NFB; ++i) {
+        const int fb = i % NFB, pr = i / NFB;
+        if (!PG_WLO && pr == 1) continue;
+        acc[G - 1][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? x1l[fb] : x1h[fb], pr == 1 ? wl1 : wh1, acc[G - 1][fb], 0, 0, 0);
+    }
+    // ---- out[d][column][f]: register v of lane (column l5, half) of block fb is feature 32 fb + 8 (v / 4) + 4 half + v % 4 ----
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int tile = cg * 4 * G + wv + 4 * g;
+        const int tile = cg * NW * G + wv + NW * g;
         if (tile >= n_col_tiles) continue;
-        float *o = out + (((size_t)d * n_col_tiles + tile) * 32 + l5) * PG_NF + 4 * half;
+        float *o = out + (((size_t)d * n_col_tiles + tile) * 32 + l5) * NF + 4 * half;
 #pragma unroll
-        for (int vq = 0; vq < 4; ++vq)
-            *reinterpret_cast<pg_f4 *>(o + 8 * vq) = (pg_f4){acc[g][4 * vq], acc[g][4 * vq + 1], acc[g][4 * vq + 2], acc[g][4 * vq + 3]};
+        for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+            for (int vq = 0; vq < 4; ++vq)
+                *reinterpret_cast<pg_f4 *>(o + 32 * fb + 8 * vq) =
+                    (pg_f4){acc[g][fb][4 * vq], acc[g][fb][4 * vq + 1], acc[g][fb][4 * vq + 2], acc[g][fb][4 * vq + 3]};
     }
 }
 
 // ---- finishing, pair side -----------------------------------------------------------------------------------------------
 // thread = pair p, block row = chunk of output dims: partial sums over the chunk's d of
 //   tp[c][0][p][q] = sum_d u_dp R2[2q],  tp[c][1][p][q] = sum_d u_dp R2[2q+1],  tp[c][2][p][q] = sum_d u_dp C_dp gamma_dq  (C = R2[2Q])
+template <int NF>
 __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int D, int Ppad, int dchunk,
                                                               const double *__restrict__ gamma, const float *__restrict__ u,
                                                               const float *__restrict__ r2, double *__restrict__ tp) {
@@ -432,20 +538,20 @@ __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int 
     const int d1 = min(D, (c + 1) * dchunk);
     for (int d = c * dchunk; d < d1; ++d) {
         const float ud = u[(size_t)d * Ppad + p] * (1.0f / 4096.0f);          // (x 2^-PG_WSHIFT)
-        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r2 + ((size_t)d * Ppad + p) * PG_NF);
-        float rv[PG_NF];
+        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r2 + ((size_t)d * Ppad + p) * NF);
+        float rv[NF];
 #pragma unroll
-        for (int k = 0; k < PG_NF / 4; ++k) {
+        for (int k = 0; k < NF / 4; ++k) {
             const pg_f4 v = row[k];
             rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
         }
         float cc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < PG_NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
+        for (int k = 0; k < NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
         const double uc = (double)ud * (double)cc;
 #pragma unroll
         for (int q = 0; q < DPGP_MAX_Q; ++q)
-            if (q < Q && 2 * q + 1 < PG_NF) {
+            if (q < Q && 2 * q + 1 < NF) {
                 a1[q] += (double)ud * (double)rv[2 * q];
                 a2[q] += (double)ud * (double)rv[2 * q + 1];
                 a3[q] += uc * gamma[(size_t)d * Q + q];
@@ -484,6 +590,7 @@ __global__ __launch_bounds__(256) void pg_gather_dz_kernel(int M, int Q, const d
     dz[e] += acc;
 }
 // block = output dim d: dgamma[d][q] += sum_p -1/4 delta_pq^2 u_dp C_dp
+template <int NF>
 __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int Ppad, const double *__restrict__ z,
                                                               const float *__restrict__ u, const float *__restrict__ r2,
                                                               double *__restrict__ dgamma) {
@@ -496,7 +603,7 @@ __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int 
     for (int p = t; p < P; p += 256) {
         int m, mp;
         psi2_pair_of(p, m, mp);
-        const double uc = (double)u[(size_t)d * Ppad + p] * (double)r2[((size_t)d * Ppad + p) * PG_NF + 2 * Q] * (1.0 / 4096.0);
+        const double uc = (double)u[(size_t)d * Ppad + p] * (double)r2[((size_t)d * Ppad + p) * NF + 2 * Q] * (1.0 / 4096.0);
 #pragma unroll
         for (int q = 0; q < DPGP_MAX_Q; ++q)
             if (q < Q) {
@@ -520,6 +627,7 @@ __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int 
 
 // ---- finishing, observation side: thread = observation n, block row = chunk of output dims ---------------------------------
 // dmu_part / ds_part [chunk][N][Q]: partial sums over the chunk's d;  dg_part[n-block][d][q]: this block's share of dgamma
+template <int NF>
 __global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D, int NT, int dchunk,
                                                             const unsigned char *__restrict__ consts,
                                                             const double *__restrict__ mu, const double *__restrict__ s,
@@ -541,20 +649,20 @@ __global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D,
     const int d1 = min(D, (c + 1) * dchunk);
     for (int d = c * dchunk; d < d1; ++d) {
         const double ik = 1.0 / ((double)kap[d] * 4096.0);            // (kap_d and 2^PG_WSHIFT)
-        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r1 + ((size_t)d * NT * 32 + (ok ? n : 0)) * PG_NF);
-        float rv[PG_NF];
+        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r1 + ((size_t)d * NT * 32 + (ok ? n : 0)) * NF);
+        float rv[NF];
 #pragma unroll
-        for (int k = 0; k < PG_NF / 4; ++k) {
+        for (int k = 0; k < NF / 4; ++k) {
             const pg_f4 v = row[k];
             rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
         }
         float cc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < PG_NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
+        for (int k = 0; k < NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
         const double rc = ok ? (double)cc * ik : 0.0;
 #pragma unroll
         for (int q = 0; q < DPGP_MAX_Q; ++q) {
-            if (q >= Q || 2 * q + 1 >= PG_NF) break;
+            if (q >= Q || 2 * q + 1 >= NF) break;
             const double g = gamma[(size_t)d * Q + q];
             const double ra = ok ? (double)rv[2 * q] * ik : 0.0, rb = ok ? (double)rv[2 * q + 1] * ik : 0.0;
             const double den = 2.0 * g * sv[q] + 1.0, w = g / den;
@@ -593,32 +701,33 @@ __global__ void pg_poison_kernel(const int *__restrict__ flag, double *dmu, doub
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-bool psi2_pgrad_supported(int M, int Q) { return psi2_pairs_ksteps(Q) <= 4 && 2 * Q + 1 <= PG_NF && M >= 1 && M <= 4096; }
+bool psi2_pgrad_supported(int M, int Q) {
+    const int ks = psi2_pairs_ksteps(Q);
+    return ks <= 8 && 2 * Q + 1 <= PG_FB * pg_nfb(ks) && M >= 1 && M <= 4096;
+}
 
 #define PG_DC_PAIRS 16               // chunks of output dims of the finishing kernels
 #define PG_DC_OBS 64
 struct PgLayout {
-    int KS, P, Ppad, NT, PT, nblk_obs;
-    size_t off_u, off_kap, off_flag, off_cobs, off_robs, off_xobs, off_rpair, off_xpair, off_r2, off_r1, off_tp, off_tt, off_dgp,
-        off_dmup, off_dsp, total;
+    int KS, NF, P, Ppad, NT, PT, nblk_obs;
+    size_t off_u, off_kap, off_flag, off_cobs, off_xobs, off_xpair, off_r2, off_r1, off_tp, off_tt, off_dgp, off_dmup, off_dsp, total;
 };
 static PgLayout pg_layout(int D, int N, int M, int Q) {
     PgLayout L;
     const Psi2Consts C = psi2_consts_layout(M, Q);
     L.KS = C.KS; L.P = C.P; L.Ppad = C.Ppad; L.NT = dpgp_ceil_div(N, 32); L.PT = C.Ppad / 32;
+    L.NF = PG_FB * pg_nfb(C.KS);
     L.nblk_obs = dpgp_ceil_div(N, 256);
-    const size_t h = sizeof(_Float16);
+    const size_t h = sizeof(_Float16), nfb = (size_t)pg_nfb(C.KS);
     size_t o = 0;
     L.off_u = o;     o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad);
     L.off_kap = o;   o += dpgp_align256(sizeof(float) * (size_t)D);
     L.off_flag = o;  o += 256;
     L.off_cobs = o;  o += dpgp_align256(h * (size_t)D * L.NT * L.KS * 64 * 8);
-    L.off_robs = o;  o += dpgp_align256(h * (size_t)D * L.NT * 32 * 16 * L.KS);
-    L.off_xobs = o;  o += dpgp_align256(h * (size_t)D * L.NT * 2048);
-    L.off_rpair = o; o += dpgp_align256(h * (size_t)L.Ppad * 16 * L.KS);
-    L.off_xpair = o; o += dpgp_align256(h * (size_t)D * L.PT * 2048);
-    L.off_r2 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad * PG_NF);
-    L.off_r1 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * PG_NF);
+    L.off_xobs = o;  o += dpgp_align256(h * (size_t)D * L.NT * 2048 * nfb);
+    L.off_xpair = o; o += dpgp_align256(h * (size_t)D * L.PT * 2048 * nfb);
+    L.off_r2 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad * L.NF);
+    L.off_r1 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * L.NF);
     L.off_tp = o;    o += dpgp_align256(sizeof(double) * (size_t)PG_DC_PAIRS * 3 * L.P * Q);
     L.off_tt = o;    o += dpgp_align256(sizeof(double) * (size_t)3 * L.P * Q);
     L.off_dgp = o;   o += dpgp_align256(sizeof(double) * (size_t)L.nblk_obs * D * Q);
@@ -633,12 +742,12 @@ template <int KS>
 static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                            const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
                            double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+    constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
     const PgLayout L = pg_layout(D, N, M, Q);
     const int Mp = dpgp_round_up(M, 16);
     float *u = reinterpret_cast<float *>(ws + L.off_u), *kap = reinterpret_cast<float *>(ws + L.off_kap);
     int *flag = reinterpret_cast<int *>(ws + L.off_flag);
-    _Float16 *cobs = reinterpret_cast<_Float16 *>(ws + L.off_cobs), *robs = reinterpret_cast<_Float16 *>(ws + L.off_robs),
-             *xobs = reinterpret_cast<_Float16 *>(ws + L.off_xobs), *rpair = reinterpret_cast<_Float16 *>(ws + L.off_rpair),
+    _Float16 *cobs = reinterpret_cast<_Float16 *>(ws + L.off_cobs), *xobs = reinterpret_cast<_Float16 *>(ws + L.off_xobs),
              *xpair = reinterpret_cast<_Float16 *>(ws + L.off_xpair);
     float *r2 = reinterpret_cast<float *>(ws + L.off_r2), *r1 = reinterpret_cast<float *>(ws + L.off_r1);
     double *tp = reinterpret_cast<double *>(ws + L.off_tp), *tt = reinterpret_cast<double *>(ws + L.off_tt);
@@ -649,44 +758,43 @@ static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *cons
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_u_kernel, dim3(D), dim3(256), 0, st, M, Q, Mp, z, gamma, alpha, GP, u, kap);
     DPGP_LAUNCH_CHECK();
     {
-        const size_t lds = 256 + sizeof(unsigned) * 256 * (8 * KS + 4) + sizeof(_Float16) * 8 * 2048;
+        const size_t lds = 256 + sizeof(unsigned) * 256 * (8 * KS + 4) + sizeof(_Float16) * 8 * 2048 * NFB;
         auto kern = pg_obs_images_kernel<KS>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
-        DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(dpgp_ceil_div(N, 256), D), dim3(256), lds, st, N, Q, consts, mu, s, gamma, cobs, robs, xobs,
-                           L.NT, flag);
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(dpgp_ceil_div(N, 256), D), dim3(256), lds, st, N, Q, consts, mu, s, gamma, cobs, xobs, L.NT,
+                           flag);
         DPGP_LAUNCH_CHECK();
     }
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(L.Ppad, 256), D), dim3(256), 0, st, M, Q, consts,
-                       (const float *)u, (const float *)kap, rpair, xpair);
+                       (const float *)u, (const float *)kap, xpair);
     DPGP_LAUNCH_CHECK();
-    // two LDS buffers per workgroup within 80 KB (2 workgroups per CU): row tiles per buffer from the bytes of a row (row image
-    // LDA halves + feature image 64 halves); the row-image region is rounded up to whole wave-instructions of the LDS-DMA fill
-    const size_t row = sizeof(_Float16) * (size_t)(16 * KS + PG_APAD + 64);
-    const size_t buf_budget = (size_t)(160 * 1024 / PG_OCC) / 2;
-    int NTb = (int)(buf_budget / (32 * row));
-    while (NTb > 1 && (size_t)16 * (((NTb * 32 * (16 * KS + PG_APAD) / 8 + 63) / 64) * 64 + NTb * 256) > buf_budget) --NTb;
-    const int R = 32 * NTb;
-    const size_t lds = (size_t)2 * 16 * (((NTb * 32 * (16 * KS + PG_APAD) / 8 + 63) / 64) * 64 + NTb * 256);
+    // LDS ring of the pass kernel: three chunks of NTb row tiles (KS + 4 NFB KB each) in the 160 KB of the one workgroup per CU
+    int NTb = (int)((size_t)(160 * 1024 * NW / 8) / ((size_t)3 * 1024 * (KS + 4 * NFB)));
+    if (const char *e = getenv("DPGP_PG_NTB")) {                 // (experiments only)
+        const int v = atoi(e);
+        if (v >= 1 && v <= NTb) NTb = v;
+    }
+    const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
     auto kern = pg_pass_kernel<KS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DPGP_ERR_LAUNCH;
     for (int pass = 1; pass <= 2; ++pass) {
         const int n_row_tiles = pass == 1 ? L.NT : L.PT, n_col_tiles = pass == 1 ? L.PT : L.NT;
-        const int groups = dpgp_ceil_div(n_col_tiles, 4 * PG_G);
+        const int groups = dpgp_ceil_div(n_col_tiles, NW * G);
         const long long nwg = (long long)D * groups;
         if (nwg > 0x7fffffffLL) return -1;
         DPGP_PRELAUNCH();
-        if (pass == 1)
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, (const _Float16 *)robs, 1, (const _Float16 *)xobs, pimg, 0, r2,
-                               n_row_tiles, n_col_tiles, groups, R);
-        else
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, (const _Float16 *)rpair, 0, (const _Float16 *)xpair,
-                               (const _Float16 *)cobs, 1, r1, n_row_tiles, n_col_tiles, groups, R);
+        if (pass == 1)       // rows: the observations of output dim d (cobs, xobs); columns: the pairs (the forward's pair image)
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, (const _Float16 *)cobs, 1, (const _Float16 *)xobs, pimg, 0, r2,
+                               n_row_tiles, n_col_tiles, groups, NTb);
+        else                 // rows: the pairs (pair image, xpair of output dim d); columns: the observations of output dim d
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, pimg, 0, (const _Float16 *)xpair, (const _Float16 *)cobs, 1, r1,
+                               n_row_tiles, n_col_tiles, groups, NTb);
         DPGP_LAUNCH_CHECK();
     }
     const int dcp = dpgp_ceil_div(D, PG_DC_PAIRS), ncp = dpgp_ceil_div(D, dcp);
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_finish_pairs_kernel, dim3(dpgp_ceil_div(L.P, 256), ncp), dim3(256), 0, st, M, Q, D, L.Ppad, dcp, gamma,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_finish_pairs_kernel<NF>), dim3(dpgp_ceil_div(L.P, 256), ncp), dim3(256), 0, st, M, Q, D, L.Ppad, dcp, gamma,
                        (const float *)u, (const float *)r2, tp);
     DPGP_LAUNCH_CHECK();
     const size_t n3 = (size_t)3 * L.P * Q;
@@ -694,11 +802,11 @@ static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *cons
     if (rc != DPGP_OK) return rc;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_gather_dz_kernel, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, z, consts, (const double *)tt, dz);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_dgamma_pairs_kernel, dim3(D), dim3(256), 0, st, M, Q, L.Ppad, z, (const float *)u, (const float *)r2,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_dgamma_pairs_kernel<NF>), dim3(D), dim3(256), 0, st, M, Q, L.Ppad, z, (const float *)u, (const float *)r2,
                        dgamma);
     DPGP_LAUNCH_CHECK();
     const int dco = dpgp_ceil_div(D, PG_DC_OBS), nco = dpgp_ceil_div(D, dco);
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_finish_obs_kernel, dim3(L.nblk_obs, nco), dim3(256), 0, st, N, Q, D, L.NT, dco, consts, mu, s, gamma,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_finish_obs_kernel<NF>), dim3(L.nblk_obs, nco), dim3(256), 0, st, N, Q, D, L.NT, dco, consts, mu, s, gamma,
                        (const float *)kap, (const float *)r1, dmup, dsp, dgp);
     DPGP_LAUNCH_CHECK();
     const size_t dq = (size_t)D * Q, nq = (size_t)N * Q;
@@ -720,8 +828,9 @@ int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, c
                       double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
     if (!psi2_pgrad_supported(M, Q)) return -4;
     switch (psi2_pairs_ksteps(Q)) {
-        case 2: return launch_pgrad_ks<2>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, ws, stage, dmu, ds, dz, dgamma, st);
-        case 4: return launch_pgrad_ks<4>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, ws, stage, dmu, ds, dz, dgamma, st);
+#define CASE(k) case k: return launch_pgrad_ks<k>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, ws, stage, dmu, ds, dz, dgamma, st);
+        CASE(2) CASE(4) CASE(6) CASE(8)
+#undef CASE
     }
     return -4;
 }

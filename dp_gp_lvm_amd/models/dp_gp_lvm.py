@@ -155,7 +155,9 @@ def dp_gp_lvm(y_train,
 
     def evaluate(events=None, out=None, _local_part_only=False):
         """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior).
-        Launches: prepare, gram, [chain_k on the side stream], kl_yy, psi1T_y, psi2, chain_b, tail (sum+pack+finalize)."""
+        Five launches: prepare, front (KL, y'y, K_uu tiles, operand constants, pair factors), psi1T_y,
+        psi2 (+ the K_uu tasks), chain_b (+ the final reduction: sum, pack, finalize); D sharded: the all-reduce and the
+        finalising launch follow."""
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
         r = dp_model.raw
         out = buf['out'] if out is None else out
@@ -878,7 +880,8 @@ def dp_gp_lvm_t(y_train,
 
         @property
         def objective_terms(self):
-            return evaluate()[0]
+            # (a copy: the fused path evaluates into one persistent buffer, which the next evaluation overwrites)
+            return evaluate()[0].clone()
 
         @property
         def cholesky_info(self):

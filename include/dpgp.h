@@ -223,7 +223,7 @@ int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, 
  *            info[T] (as for dpgp_elbo_fhat; a failed atom makes f_hat NaN)
  *   prec: DPGP_PREC_MIXED (Psi2 on the fp32 matrix path) or DPGP_PREC_F64; Psi1, the contraction and the chain are fp64.
  *   M <= 128 and T <= D (-30 / -2 otherwise: the host composes the same value from the operators above).
- *   ws: dpgp_elbo_fhat_t_workspace_bytes(T,D,N,M,Q,prec).  Nine launches, no host synchronisation.                       */
+ *   ws: dpgp_elbo_fhat_t_workspace_bytes(T,D,N,M,Q,prec).  Eleven launches, no host synchronisation.                     */
 size_t dpgp_elbo_fhat_t_workspace_bytes(int T, int D, int N, int M, int Q, int prec);
 int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double *y, int ldy, const double *yy, const double *z,
                      const double *mu, const double *s, const double *gamma, const double *alpha, const double *beta,

@@ -220,13 +220,7 @@ def test_model_gradients_odd_shapes(dev, shape, prec):
     np.testing.assert_allclose(got['dp_w'].cpu().numpy(), [float(ref['w_1_raw']), float(ref['w_2_raw'])], rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize('shape', [(300, 16, 100, 10), (500, 8, 128, 12), (200, 6, 70, 4), (150, 5, 130, 7), (200, 6, 64, 20),
-                                   (120, 5, 40, 30), (150, 4, 96, 17), (90, 3, 33, 29), (130, 7, 128, 13)])
-def test_matrix_pipe_stage_b_against_fp64(dev, shape):
-    """Mixed precision: the Psi2 term of stage B runs on the matrix pipe (psi2_grad_kernel), Psi1 in the reduction-free
-    kernels.  Against the fp64 kernel (itself at 1e-8 of the oracle's autograd, tests above) on the same stage-A adjoints;
-    M = 130: the HIP stage A keeps B in LDS (M <= 128) — without z and gamma for the host-side composition the call must
-    say so instead of computing something else."""
+def _stage_b_problem(dev, shape):
     n, d, m, q = shape
     rng = np.random.default_rng(n + m)
     y = rng.standard_normal((n, d))
@@ -237,15 +231,33 @@ def test_matrix_pipe_stage_b_against_fp64(dev, shape):
     alpha = np.exp(0.2 * rng.standard_normal(d))
     beta = np.exp(0.2 * rng.standard_normal(d)) * 2.0
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
-    args = [t(a) for a in (y, z, mu, s, gamma, alpha, beta)]
+    return [t(a) for a in (y, z, mu, s, gamma, alpha, beta)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_fused_stage_a_refuses_more_than_128_inducing_points(dev, prec):
+    """M = 130: the HIP stage A keeps B in LDS (M <= 128) — without z and gamma for the host-side composition the call must
+    say so instead of computing something else."""
+    n, d, m, q = 150, 5, 130, 7
+    args = _stage_b_problem(dev, (n, d, m, q))
+    w = ops.ElboWorkspace(d, n, m, q, prec, dev)
+    ops.elbo_fhat(*args, prec=prec, workspace=w)
+    with pytest.raises(ValueError):
+        ops.elbo_grad_chain(args[5], args[6], w)
+
+
+@pytest.mark.parametrize('shape', [(300, 16, 100, 10), (500, 8, 128, 12), (200, 6, 70, 4), (200, 6, 64, 20),
+                                   (120, 5, 40, 30), (150, 4, 96, 17), (90, 3, 33, 29), (130, 7, 128, 13)])
+def test_matrix_pipe_stage_b_against_fp64(dev, shape):
+    """Mixed precision: the Psi2 term of stage B runs on the matrix pipe (psi2_grad_kernel), Psi1 in the reduction-free
+    kernels.  Against the fp64 kernel (itself at 1e-8 of the oracle's autograd, tests above) on the same stage-A adjoints."""
+    n, d, m, q = shape
+    args = _stage_b_problem(dev, shape)
     out, adj, flagged = {}, {}, {}
     for prec in ('f64', 'mixed'):
         w = ops.ElboWorkspace(d, n, m, q, prec, dev)
         ops.elbo_fhat(*args, prec=prec, workspace=w)
-        if m > 128:
-            with pytest.raises(ValueError):
-                ops.elbo_grad_chain(args[5], args[6], w)
-            return
         flagged[prec] = bool((w.info == -2).any())              # conditioning guard of the forward evaluation
         assert int(w.info.clamp(min=0).max()) == 0
         gp, wk, gv, dab, info = ops.elbo_grad_chain(args[5], args[6], w)
