@@ -59,7 +59,7 @@ template <typename TP, typename TL>
 static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                     const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                     int algo, double *terms, double *sums, int *info, unsigned char *ws, const ElboLayout &L,
-                    hipStream_t st, const dpgp_exec_t *ex, TL *lb_out = nullptr) {
+                    hipStream_t st, const dpgp_exec_t *ex, TL *lb_out = nullptr, unsigned char *pgws = nullptr) {
     double *yy = reinterpret_cast<double *>(ws + L.off_yy);
     double *ldk = reinterpret_cast<double *>(ws + L.off_ld);
     int *ik = reinterpret_cast<int *>(ws + L.off_ik);
@@ -90,7 +90,12 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     // the K_uu branch rides in the psi2 dispatch when it is LDS-resident (or the exact-MFMA psi2 kernel runs, which carries
     // both forms); otherwise it is a launch of its own ahead of psi2
     const bool f16_psi2 = (sizeof(TP) == 4 && algo != DPGP_ALGO_MFMA_F32);
-    const bool fused_k = (algo != DPGP_ALGO_PLAIN) && (!f16_psi2 || la_chain_k_resident(M, (int)sizeof(TL))) &&
+    // pgws != nullptr (training step, dpgp_elbo_step): Psi2 comes out of pass 1 of the backward pass's stage B, which evaluates
+    // the same exponentials and does not depend on the adjoints (psi2_pairs_grad.hip) — no psi2 dispatch here, the K_uu branch is
+    // a launch of its own, and the chain reads ONE slab
+    const bool step = pgws != nullptr;
+    if (step && !(pairs_psi2 && psi2_pgrad_supported(M, Q) && dpgp_round_up(M, 16) <= 128)) return -30;
+    const bool fused_k = !step && (algo != DPGP_ALGO_PLAIN) && (!f16_psi2 || la_chain_k_resident(M, (int)sizeof(TL))) &&
                          !getenv("DPGP_UNFUSED_K");      // (experiments only)
     // M > 128 in fp64 with a matrix per compute unit: the persistent-workgroup chain (chain_big.hip); its K_uu side runs here
     bool big = false;
@@ -102,9 +107,15 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     // psi2 on the matrix cores; the same dispatch carries, ahead of the psi2 workgroups, the D workgroups of the K_uu
     // branch (Cholesky, log-det, inverse of K_uu), which are latency-bound and overlap the psi2 work completely
-    if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st,
-                                              (fused_k && !big) ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst,
-                                              pairs_psi2 ? 2 : 1, pscale)))
+    if (step) {
+        if constexpr (sizeof(TP) == 4) {
+            if ((rc = launch_psi2_pgrad(D, N, M, Q, pconst, z, mu, s, gamma, alpha, nullptr, pgws, nullptr, nullptr, nullptr, nullptr,
+                                        nullptr, st, 1, reinterpret_cast<float *>(p2), pscale)))
+                return rc;
+        }
+    } else if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st,
+                                                     (fused_k && !big) ? (void *)la : nullptr, (int)sizeof(TL), ldk, ik, pconst,
+                                                     pairs_psi2 ? 2 : 1, pscale)))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     if (aux && hipStreamWaitEvent(st, (hipEvent_t)ex->ev_join, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
@@ -118,7 +129,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
                                           sums, ex ? (const double *)ex->model_scal : nullptr,
                                           ex ? (double *)ex->model_pack : nullptr, ex ? (double *)ex->model_out : nullptr);
     }
-    return launch_chain_b<TP, TL>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
+    return launch_chain_b<TP, TL>(D, N, M, p2, step ? 1 : L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
                                   reinterpret_cast<double *>(ws + L.off_guard), la, algo, st, klp, sums,
                                   ex ? (const double *)ex->model_scal : nullptr, ex ? (double *)ex->model_pack : nullptr,
                                   ex ? (double *)ex->model_out : nullptr, lb_out);
@@ -156,17 +167,70 @@ extern "C" int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *al
                                      beta, yy, jitter, la, g_psi2, w_kuu, g_v, d_alpha_beta, info, (hipStream_t)stream);
 }
 
+// Stage B in mixed precision.  Workspace: [plain kernel's partials | psi2 constants | patch-form partials | Psi1 term | reduction
+// stage | pair-tile form].  fwd_consts / fwd_scale != nullptr (training step): the forward evaluation's constants and per-pair
+// factors are used as they are, and part 1 of the pair-tile form (images of the observations, pass 1) has already run on this
+// workspace (elbo_run with pgws).
+struct GradPsiWs { unsigned char *consts; double *part, *ws1, *stage; unsigned char *pgws; };
+static GradPsiWs grad_psi_ws(int D, int N, int M, int Q, unsigned char *ws) {
+    GradPsiWs W;
+    const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
+    W.consts = ws + dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
+    W.part = reinterpret_cast<double *>(W.consts + dpgp_align256(psi2_consts_bytes(M, Q)));
+    W.ws1 = reinterpret_cast<double *>((unsigned char *)W.part + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)));
+    W.stage = reinterpret_cast<double *>((unsigned char *)W.ws1 + dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)));
+    W.pgws = reinterpret_cast<unsigned char *>(W.stage) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
+    return W;
+}
+static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
+                          const double *gamma, const double *alpha, const double *g_psi2, const double *w_kuu, const double *g_v,
+                          const double *g_psi1, bool patch_form, unsigned char *ws, double *d_mu, double *d_s, double *d_z,
+                          double *d_gamma, hipStream_t st, const unsigned char *fwd_consts, const float *fwd_scale) {
+    // K_uu term by the plain kernel (no pass over the observations), Psi1 by the reduction-free kernels, Psi2 (nearly all
+    // of the work) on the matrix pipe -- where those apply; otherwise everything by the plain kernel
+    const bool fast = psi2_grad_supported(M, Q) && !getenv("DPGP_GRAD_PLAIN");
+    const bool big = dpgp_round_up(M, 16) > 128;             // the plain kernel holds one row of the M x M statistics per thread
+    if (big && !fast) return -30;
+    int rc = DPGP_OK;
+    if (!big) {
+        if (g_psi1 && !fast) return -15;
+        rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v ? g_v : w_kuu, (double *)ws,
+                                    d_mu, d_s, d_z, d_gamma, fast ? 0 : 1, st);
+        if (rc != DPGP_OK || !fast) return rc;
+    }
+    const GradPsiWs W = grad_psi_ws(D, N, M, Q, ws);
+    const unsigned char *consts = fwd_consts ? fwd_consts : W.consts;
+    if (!fwd_consts && (rc = launch_psi2_consts<double>(z, M, Q, W.consts, st)) != DPGP_OK) return rc;
+    if (big) {                                               // K_uu term for any M (partials in the plain kernel's workspace)
+        rc = launch_kuu_grad(D, M, Q, consts, gamma, w_kuu, (double *)ws, W.stage, d_z, d_gamma, st);
+        if (rc != DPGP_OK) return rc;
+    }
+    rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, g_psi1, W.ws1, W.stage, d_mu, d_s, d_z, d_gamma, st);
+    if (rc != DPGP_OK) return rc;
+    // the Psi2 term: pair-tile form (psi2_pairs_grad.hip) where it exists, else the per-observation patch form
+    if (psi2_pgrad_supported(M, Q) && !patch_form && !getenv("DPGP_GRAD_PATCH"))      // (DPGP_GRAD_PATCH: experiments)
+        return launch_psi2_pgrad(D, N, M, Q, consts, z, mu, s, gamma, alpha, g_psi2, W.pgws, W.stage, d_mu, d_s, d_z, d_gamma, st,
+                                 fwd_consts ? 2 : 3, nullptr, fwd_scale);
+    if (fwd_consts) return -30;
+    return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, W.part, W.stage, d_mu, d_s, d_z, d_gamma, st);
+}
+
 // Backward pass, stage B (grad.hip): the second streaming pass over the observations.
-extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q) {
+extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes_ex(int D, int N, int M, int Q, int prec) {
     if (D <= 0 || N <= 0 || M <= 0 || Q <= 0) return 0;
     size_t b = dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
+    if (prec == DPGP_PREC_F64) return b;                             // the plain kernel only
     if (psi2_grad_supported(M, Q)) {
         const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
         b += dpgp_align256(psi2_consts_bytes(M, Q)) + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)) +
              dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
-        b += dpgp_align256(psi2_pgrad_ws_bytes(D, N, M, Q));           // pair-tile form of the Psi2 term (Q <= 10)
+        // pair-tile form of the Psi2 term (Q <= 20): its images and the two passes' results — not when the patch form is asked for
+        if (prec != DPGP_PREC_MIXED_PATCH) b += dpgp_align256(psi2_pgrad_ws_bytes(D, N, M, Q));
     }
     return b;
+}
+extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q) {
+    return dpgp_elbo_grad_psi_workspace_bytes_ex(D, N, M, Q, DPGP_PREC_MIXED);      // (the largest)
 }
 extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                                      const double *s, const double *gamma, const double *alpha, const double *g_psi2,
@@ -204,45 +268,14 @@ extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y
     if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_F64) return -15;
     if (g_psi1 && (prec != DPGP_PREC_MIXED || !psi2_grad_supported(M, Q))) return -15;
     if (!ws) return -16;
-    if (ws_bytes < dpgp_elbo_grad_psi_workspace_bytes(D, N, M, Q)) return -17;
+    if (ws_bytes < dpgp_elbo_grad_psi_workspace_bytes_ex(D, N, M, Q, patch_form ? DPGP_PREC_MIXED_PATCH : prec)) return -17;
     if (!d_mu) return -18;
     if (!d_s) return -19;
     if (!d_z) return -20;
     if (!d_gamma) return -21;
-    if (prec == DPGP_PREC_MIXED) {
-        // K_uu term by the plain kernel (no pass over the observations), Psi1 by the reduction-free kernels, Psi2 (nearly all
-        // of the work) on the matrix pipe -- where those apply; otherwise everything by the plain kernel
-        const bool fast = psi2_grad_supported(M, Q) && !getenv("DPGP_GRAD_PLAIN");
-        hipStream_t st = (hipStream_t)stream;
-        const bool big = dpgp_round_up(M, 16) > 128;             // the plain kernel holds one row of the M x M statistics per thread
-        if (big && !fast) return -30;
-        int rc = DPGP_OK;
-        if (!big) {
-            if (g_psi1 && !fast) return -15;
-            rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v ? g_v : w_kuu, (double *)ws,
-                                        d_mu, d_s, d_z, d_gamma, fast ? 0 : 1, st);
-            if (rc != DPGP_OK || !fast) return rc;
-        }
-        const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
-        unsigned char *consts = (unsigned char *)ws + dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
-        double *part = reinterpret_cast<double *>(consts + dpgp_align256(psi2_consts_bytes(M, Q)));
-        double *ws1 = reinterpret_cast<double *>((unsigned char *)part + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)));
-        double *stage = reinterpret_cast<double *>((unsigned char *)ws1 + dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)));
-        rc = launch_psi2_consts<double>(z, M, Q, consts, st);
-        if (rc != DPGP_OK) return rc;
-        if (big) {                                               // K_uu term for any M (partials in the plain kernel's workspace)
-            rc = launch_kuu_grad(D, M, Q, consts, gamma, w_kuu, (double *)ws, stage, d_z, d_gamma, st);
-            if (rc != DPGP_OK) return rc;
-        }
-        rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, g_psi1, ws1, stage, d_mu, d_s, d_z, d_gamma, st);
-        if (rc != DPGP_OK) return rc;
-        // the Psi2 term: pair-tile form (psi2_pairs_grad.hip) where it exists, else the per-observation patch form
-        if (psi2_pgrad_supported(M, Q) && !patch_form && !getenv("DPGP_GRAD_PATCH")) {   // (DPGP_GRAD_PATCH: experiments)
-            unsigned char *pgws = reinterpret_cast<unsigned char *>(stage) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
-            return launch_psi2_pgrad(D, N, M, Q, consts, z, mu, s, gamma, alpha, g_psi2, pgws, stage, d_mu, d_s, d_z, d_gamma, st);
-        }
-        return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, part, stage, d_mu, d_s, d_z, d_gamma, st);
-    }
+    if (prec == DPGP_PREC_MIXED)
+        return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, g_psi1, patch_form, (unsigned char *)ws,
+                              d_mu, d_s, d_z, d_gamma, (hipStream_t)stream, nullptr, nullptr);
     if (dpgp_round_up(M, 16) > 128) return -30;
     return launch_psi_grad<double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
                                    d_z, d_gamma, 1, (hipStream_t)stream);
@@ -294,6 +327,62 @@ extern "C" int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int l
                               size_t ws_bytes, void *stream) {
     return dpgp_elbo_fhat_ex(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, prec, algo, terms, sums, info, ws,
                              ws_bytes, stream, nullptr);
+}
+
+// ---- training step (mixed precision, M <= 128, Q <= 20): f_hat terms AND the stage-A / stage-B gradients of one evaluation.
+// What one Adam iteration of the reference needs (forward + tf.gradients, test/synthetic_data_hard_test.py:143-155).  Compared
+// with dpgp_elbo_fhat + dpgp_elbo_grad_chain + dpgp_elbo_grad_psi the exponentials of the Psi2 statistic are evaluated twice
+// instead of three times: pass 1 of stage B (rows = observations, columns = pairs of inducing points) does not depend on the
+// adjoints, holds the constant 1 among its features and therefore yields Psi2 itself — the forward's psi2 dispatch is dropped.
+extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                              const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
+                              double *terms, double *sums, int *info, void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu,
+                              double *g_v, double *d_alpha_beta, int *info_grad, void *gws, size_t gws_bytes, double *d_mu,
+                              double *d_s, double *d_z, double *d_gamma, void *stream, const dpgp_exec_t *exec) {
+    if (D <= 0) return -1;
+    if (N <= 0) return -2;
+    if (M <= 0 || dpgp_round_up(M, 16) > 128) return -3;
+    if (Q <= 0 || Q > DPGP_MAX_Q || !psi2_pgrad_supported(M, Q)) return -4;
+    if (!y) return -5;
+    if (ldy < D) return -6;
+    if (!z) return -7;
+    if (!mu) return -8;
+    if (!s) return -9;
+    if (!gamma) return -10;
+    if (!alpha) return -11;
+    if (!beta) return -12;
+    if (!(jitter >= 0.0)) return -13;
+    if (!terms) return -14;
+    if (!sums) return -15;
+    if (!info) return -16;
+    if (!ws) return -17;
+    const ElboLayout L = elbo_layout(D, N, M, Q, DPGP_PREC_MIXED);
+    if (ws_bytes < L.total) return -18;
+    if (!g_psi2) return -19;
+    if (!w_kuu) return -20;
+    if (!g_v) return -21;
+    if (!d_alpha_beta) return -22;
+    if (!info_grad) return -23;
+    if (!gws) return -24;
+    if (gws_bytes < dpgp_elbo_grad_psi_workspace_bytes(D, N, M, Q)) return -25;
+    if (!d_mu) return -26;
+    if (!d_s) return -27;
+    if (!d_z) return -28;
+    if (!d_gamma) return -29;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char *w = (unsigned char *)ws;
+    const GradPsiWs W = grad_psi_ws(D, N, M, Q, (unsigned char *)gws);
+    int rc = elbo_run<float, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums, info, w,
+                                     L, st, exec, nullptr, W.pgws);
+    if (rc != DPGP_OK) return rc;
+    // stage A on the ONE slab pass 1 left
+    rc = launch_chain_grad<float>(D, N, M, reinterpret_cast<const float *>(w + L.off_p2), 1,
+                                  reinterpret_cast<const double *>(w + L.off_v), L.ns1, alpha, beta,
+                                  reinterpret_cast<const double *>(w + L.off_yy), jitter, reinterpret_cast<double *>(w + L.off_la),
+                                  g_psi2, w_kuu, g_v, d_alpha_beta, info_grad, st);
+    if (rc != DPGP_OK) return rc;
+    return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, nullptr, false, (unsigned char *)gws, d_mu,
+                          d_s, d_z, d_gamma, st, w + L.off_pc, reinterpret_cast<const float *>(w + L.off_sc));
 }
 
 // ---- f_hat of the over-T model (dp_gp_lvm_t, reference dp_gp_lvm.py:608-676): the T atoms play the part of the output dims in

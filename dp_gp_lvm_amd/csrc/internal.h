@@ -143,6 +143,9 @@ int launch_psi2_grad(int B, int N, int M, int Q, const unsigned char *consts, co
 // ---- psi2_pairs_grad.hip: the Psi2 term of stage B in the pair-tile form (Q <= 10) ---------------------------------------
 bool psi2_pgrad_supported(int M, int Q);
 size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q);
+// which: 1 = the part that does not depend on the adjoints (observation images, pass 1; psi2_part / scale != nullptr: Psi2 as a
+// by-product into slab 0 of the forward's partial slabs), 2 = the rest (after part 1 on the same ws), 3 = both
 int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
-                      double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st);
+                      double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st, int which = 3,
+                      float *psi2_part = nullptr, const float *scale = nullptr);

@@ -154,6 +154,43 @@ __global__ __launch_bounds__(256) void pg_u_kernel(int M, int Q, int Mp, const d
     }
 }
 
+// the same from the forward's per-pair factors scale[d][p] = alpha_d^2 exp2(beta_dp) (training step: the table exists)
+__global__ __launch_bounds__(256) void pg_u_scale_kernel(int Ppad, int Mp, const unsigned *__restrict__ pmap,
+                                                         const float *__restrict__ scale, const double *__restrict__ GP,
+                                                         float *__restrict__ u, float *__restrict__ kap) {
+    __shared__ float red[256];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const double *Gd = GP + (size_t)d * Mp * Mp;
+    float mx = 0.0f;
+    for (int p = t; p < Ppad; p += 256) {
+        const unsigned pm = pmap[p];
+        float val = 0.0f;
+        if (pm != 0xffffffffu) {
+            const int m = pm >> 16, mp = pm & 0xffffu;
+            val = (float)Gd[(size_t)m * Mp + mp] * (m == mp ? 1.0f : 2.0f) * scale[(size_t)d * Ppad + p];
+        }
+        u[(size_t)d * Ppad + p] = val;
+        mx = fmaxf(mx, fabsf(val));
+    }
+    red[t] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        float k = 1.0f;
+        const float m0 = red[0];
+        if (m0 > 0.0f && m0 < 3.0e38f) {
+            int ex;
+            (void)frexpf(m0, &ex);
+            ex = max(-100, min(100, ex));
+            k = ldexpf(1.0f, 8 - ex);
+        }
+        kap[d] = k;
+    }
+}
+
 // ---- precomputed images -----------------------------------------------------------------------------------------------
 // Every workgroup of a pass re-reads the row images of its output dim chunk by chunk; they are built ONCE per evaluation
 // (observation side: per output dim; pair side: the exponent rows are shared by all output dims — the forward's pair image in
@@ -254,6 +291,13 @@ __global__ __launch_bounds__(256) void pg_pair_images_kernel(int M, int Q, const
 // SQ_ACTIVE_INST_VALU, SQ_VALU_MFMA_COEXEC_CYCLES).  Here ONE matrix instruction is followed by NV / NM vector instructions
 // throughout (the order is generated at compile time: pg_slot), the exponentials of element pair i + 1 sit between those of pair
 // i and their conversion (no wait state behind a transcendental), and the pipeline runs through the chunk boundaries.
+struct PgPsi2Out {                    // Psi2 as a by-product of pass 1 (see the kernel's epilogue)
+    float *part;                      // [D][Mp][Mp] (fp32; entries m' <= m written), or nullptr
+    const float *scale;               // [D][Ppad] alpha_d^2 exp2(beta_dp) (psi2_pairs.hip)
+    const unsigned *pmap;             // [Ppad] m << 16 | m'
+    const int *flag;                  // range-guard flag of the image build
+    int Mp, Ppad, fsel;
+};
 struct PgSlot { int kind, i; };      // kind 0: exponent chain K-step i; 1: product i of the previous step's K-step-1 half; 2: of this step's K-step-0 half
 struct PgUnit { int kind, i; };      // kind 0: v_exp_f32 of element i; 1: v_cvt_pk_f16_f32 (hi) of element pair i; 2: the two v_fma_mix_f32 (e - hi) of pair i; 3: v_cvt_pk_f16_f32 (lo)
 template <int KS, int NFB> struct PgSched {
@@ -386,7 +430,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::NW / 4) void pg_pass
                                                                    const _Float16 *__restrict__ ximg,
                                                                    const _Float16 *__restrict__ cimg, int col_per_d,
                                                                    float *__restrict__ out, int n_row_tiles, int n_col_tiles,
-                                                                   int groups_per_d, int NTb) {
+                                                                   int groups_per_d, int NTb, PgPsi2Out po) {
     constexpr int NFB = PgCfg<KS>::NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW, NF = PG_FB * NFB;
     constexpr int PIECES = KS + 4 * NFB, TILE_BYTES = 1024 * PIECES;   // LDS bytes of one row tile: K-steps of the exponent operand, then the features
     typedef PgSched<KS, NFB> S;
@@ -508,10 +552,28 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::NW / 4) void pg_pass
         acc[G - 1][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? x1l[fb] : x1h[fb], pr == 1 ? wl1 : wh1, acc[G - 1][fb], 0, 0, 0);
     }
     // ---- out[d][column][f]: register v of lane (column l5, half) of block fb is feature 32 fb + 8 (v / 4) + 4 half + v % 4 ----
+    // po.part != nullptr (pass 1 of a training step): feature po.fsel (the constant 1) is the column sum of the exponentials, i.e.
+    // Psi2 of output dim d up to its per-pair factor — written where the forward's psi2 kernel writes it (slab 0 of the partial
+    // slabs, entries m' <= m), so the forward needs no psi2 dispatch of its own
+    float poison = 0.0f;
+    if (po.part && *po.flag) poison = __builtin_nanf("");
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int tile = cg * NW * G + wv + NW * g;
         if (tile >= n_col_tiles) continue;
+        if (po.part) {
+            const int fi = po.fsel & 31, vs = (fi >> 3) * 4 + (fi & 3), hs = (fi >> 2) & 1;
+            float cs = 0.0f;
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) cs = (fb == (po.fsel >> 5) && v == vs) ? acc[g][fb][v] : cs;
+            const int p = 32 * tile + l5;
+            const unsigned pm = po.pmap[p];
+            if (half == hs && pm != 0xffffffffu)
+                po.part[(size_t)d * po.Mp * po.Mp + (size_t)(pm >> 16) * po.Mp + (pm & 0xffffu)] =
+                    po.scale[(size_t)d * po.Ppad + p] * (cs * (1.0f / 4096.0f)) + poison;      // (x 2^-PG_WSHIFT)
+        }
         float *o = out + (((size_t)d * n_col_tiles + tile) * 32 + l5) * NF + 4 * half;
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb)
@@ -706,6 +768,15 @@ bool psi2_pgrad_supported(int M, int Q) {
     return ks <= 8 && 2 * Q + 1 <= PG_FB * pg_nfb(ks) && M >= 1 && M <= 4096;
 }
 
+template <int KS> static int pg_ring_tiles() {                   // row tiles per chunk of the pass kernel's LDS ring
+    // three chunks of NTb row tiles (KS + 4 NFB KB each) in the 160 KB of the one workgroup per CU
+    int NTb = (int)((size_t)(160 * 1024 * PgCfg<KS>::NW / 8) / ((size_t)3 * 1024 * (KS + 4 * PgCfg<KS>::NFB)));
+    if (const char *e = getenv("DPGP_PG_NTB")) {                 // (experiments only)
+        const int v = atoi(e);
+        if (v >= 1 && v <= NTb) NTb = v;
+    }
+    return NTb;
+}
 #define PG_DC_PAIRS 16               // chunks of output dims of the finishing kernels
 #define PG_DC_OBS 64
 struct PgLayout {
@@ -738,25 +809,18 @@ static PgLayout pg_layout(int D, int N, int M, int Q) {
 }
 size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q) { return psi2_pgrad_supported(M, Q) ? pg_layout(D, N, M, Q).total : 0; }
 
+// part 1 (does not depend on the adjoints): observation images, pass 1 -> R2 [and Psi2: psi2_part != nullptr]
 template <int KS>
-static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
-                           const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
-                           double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
-    constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
+static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
+                              const double *gamma, unsigned char *ws, float *psi2_part, const float *scale, hipStream_t st) {
+    constexpr int NFB = PgCfg<KS>::NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
     const PgLayout L = pg_layout(D, N, M, Q);
-    const int Mp = dpgp_round_up(M, 16);
-    float *u = reinterpret_cast<float *>(ws + L.off_u), *kap = reinterpret_cast<float *>(ws + L.off_kap);
+    const Psi2Consts C = psi2_consts_layout(M, Q);
     int *flag = reinterpret_cast<int *>(ws + L.off_flag);
-    _Float16 *cobs = reinterpret_cast<_Float16 *>(ws + L.off_cobs), *xobs = reinterpret_cast<_Float16 *>(ws + L.off_xobs),
-             *xpair = reinterpret_cast<_Float16 *>(ws + L.off_xpair);
-    float *r2 = reinterpret_cast<float *>(ws + L.off_r2), *r1 = reinterpret_cast<float *>(ws + L.off_r1);
-    double *tp = reinterpret_cast<double *>(ws + L.off_tp), *tt = reinterpret_cast<double *>(ws + L.off_tt);
-    double *dgp = reinterpret_cast<double *>(ws + L.off_dgp), *dmup = reinterpret_cast<double *>(ws + L.off_dmup),
-           *dsp = reinterpret_cast<double *>(ws + L.off_dsp);
-    const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + psi2_consts_layout(M, Q).off_pairs);
+    _Float16 *cobs = reinterpret_cast<_Float16 *>(ws + L.off_cobs), *xobs = reinterpret_cast<_Float16 *>(ws + L.off_xobs);
+    float *r2 = reinterpret_cast<float *>(ws + L.off_r2);
+    const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
     if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return DPGP_ERR_LAUNCH;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_u_kernel, dim3(D), dim3(256), 0, st, M, Q, Mp, z, gamma, alpha, GP, u, kap);
-    DPGP_LAUNCH_CHECK();
     {
         const size_t lds = 256 + sizeof(unsigned) * 256 * (8 * KS + 4) + sizeof(_Float16) * 8 * 2048 * NFB;
         auto kern = pg_obs_images_kernel<KS>;
@@ -766,31 +830,65 @@ static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *cons
                            flag);
         DPGP_LAUNCH_CHECK();
     }
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(L.Ppad, 256), D), dim3(256), 0, st, M, Q, consts,
-                       (const float *)u, (const float *)kap, xpair);
-    DPGP_LAUNCH_CHECK();
-    // LDS ring of the pass kernel: three chunks of NTb row tiles (KS + 4 NFB KB each) in the 160 KB of the one workgroup per CU
-    int NTb = (int)((size_t)(160 * 1024 * NW / 8) / ((size_t)3 * 1024 * (KS + 4 * NFB)));
-    if (const char *e = getenv("DPGP_PG_NTB")) {                 // (experiments only)
-        const int v = atoi(e);
-        if (v >= 1 && v <= NTb) NTb = v;
-    }
+    const int NTb = pg_ring_tiles<KS>();
     const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
     auto kern = pg_pass_kernel<KS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DPGP_ERR_LAUNCH;
-    for (int pass = 1; pass <= 2; ++pass) {
-        const int n_row_tiles = pass == 1 ? L.NT : L.PT, n_col_tiles = pass == 1 ? L.PT : L.NT;
-        const int groups = dpgp_ceil_div(n_col_tiles, NW * G);
+    const int groups = dpgp_ceil_div(L.PT, NW * G);
+    const long long nwg = (long long)D * groups;
+    if (nwg > 0x7fffffffLL) return -1;
+    PgPsi2Out po = {psi2_part, scale, reinterpret_cast<const unsigned *>(consts + C.off_pmap), flag, dpgp_round_up(M, 16), L.Ppad, 2 * Q};
+    // rows: the observations of output dim d (cobs, xobs); columns: the pairs (the forward's pair image)
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, (const _Float16 *)cobs, 1, (const _Float16 *)xobs, pimg, 0, r2, L.NT,
+                       L.PT, groups, NTb, po);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
+// part 2: u_dp from the adjoint of Psi2, pair features, pass 2 -> R1, finishing kernels.  scale != nullptr: the forward's
+// per-pair factors (then u is one multiplication per pair; otherwise it is formed from z, gamma, alpha)
+template <int KS>
+static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
+                              const double *s, const double *gamma, const double *alpha, const double *GP, const float *scale,
+                              unsigned char *ws, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+    constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
+    const PgLayout L = pg_layout(D, N, M, Q);
+    const Psi2Consts C = psi2_consts_layout(M, Q);
+    const int Mp = dpgp_round_up(M, 16);
+    float *u = reinterpret_cast<float *>(ws + L.off_u), *kap = reinterpret_cast<float *>(ws + L.off_kap);
+    int *flag = reinterpret_cast<int *>(ws + L.off_flag);
+    _Float16 *cobs = reinterpret_cast<_Float16 *>(ws + L.off_cobs), *xpair = reinterpret_cast<_Float16 *>(ws + L.off_xpair);
+    float *r2 = reinterpret_cast<float *>(ws + L.off_r2), *r1 = reinterpret_cast<float *>(ws + L.off_r1);
+    double *tp = reinterpret_cast<double *>(ws + L.off_tp), *tt = reinterpret_cast<double *>(ws + L.off_tt);
+    double *dgp = reinterpret_cast<double *>(ws + L.off_dgp), *dmup = reinterpret_cast<double *>(ws + L.off_dmup),
+           *dsp = reinterpret_cast<double *>(ws + L.off_dsp);
+    const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
+    DPGP_PRELAUNCH();
+    if (scale)
+        hipLaunchKernelGGL(pg_u_scale_kernel, dim3(D), dim3(256), 0, st, L.Ppad, Mp, reinterpret_cast<const unsigned *>(consts + C.off_pmap),
+                           scale, GP, u, kap);
+    else
+        hipLaunchKernelGGL(pg_u_kernel, dim3(D), dim3(256), 0, st, M, Q, Mp, z, gamma, alpha, GP, u, kap);
+    DPGP_LAUNCH_CHECK();
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(L.Ppad, 256), D), dim3(256), 0, st, M, Q, consts,
+                       (const float *)u, (const float *)kap, xpair);
+    DPGP_LAUNCH_CHECK();
+    {
+        const int NTb = pg_ring_tiles<KS>();
+        const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
+        auto kern = pg_pass_kernel<KS>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
+        const int groups = dpgp_ceil_div(L.NT, NW * G);
         const long long nwg = (long long)D * groups;
         if (nwg > 0x7fffffffLL) return -1;
+        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        // rows: the pairs (pair image, xpair of output dim d); columns: the observations of output dim d
         DPGP_PRELAUNCH();
-        if (pass == 1)       // rows: the observations of output dim d (cobs, xobs); columns: the pairs (the forward's pair image)
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, (const _Float16 *)cobs, 1, (const _Float16 *)xobs, pimg, 0, r2,
-                               n_row_tiles, n_col_tiles, groups, NTb);
-        else                 // rows: the pairs (pair image, xpair of output dim d); columns: the observations of output dim d
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, pimg, 0, (const _Float16 *)xpair, (const _Float16 *)cobs, 1, r1,
-                               n_row_tiles, n_col_tiles, groups, NTb);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, pimg, 0, (const _Float16 *)xpair, (const _Float16 *)cobs, 1, r1, L.PT,
+                           L.NT, groups, NTb, po);
         DPGP_LAUNCH_CHECK();
     }
     const int dcp = dpgp_ceil_div(D, PG_DC_PAIRS), ncp = dpgp_ceil_div(D, dcp);
@@ -816,19 +914,28 @@ static int launch_pgrad_ks(int D, int N, int M, int Q, const unsigned char *cons
     if (rc != DPGP_OK) return rc;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_poison_kernel, dim3(1), dim3(1), 0, st, (const int *)flag, dmu, ds, dz, dgamma);
     DPGP_LAUNCH_CHECK();
-    (void)stage;
     return DPGP_OK;
 }
 
 // Psi2 part of stage B, ADDED to dmu [N,Q], ds [N,Q], dz [M,Q], dgamma [D,Q]; GP [D][Mp][Mp]: the adjoint of Psi2 (lower
 // triangle read); consts: psi2_consts (launch_psi2_consts); ws: psi2_pgrad_ws_bytes.
 // A range-guard hit (see psi2_pairs.hip) poisons the outputs with NaN (the caller's trouble flag sees it).
+// which: 1 = part 1 only (images of the observations, pass 1; with psi2_part / scale also Psi2 into slab 0 of the forward's
+// partial slabs), 2 = part 2 only (after part 1 on the same ws), 3 = both.
 int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
-                      double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+                      double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st, int which,
+                      float *psi2_part, const float *scale) {
     if (!psi2_pgrad_supported(M, Q)) return -4;
+    (void)stage;
+    int rc = DPGP_OK;
     switch (psi2_pairs_ksteps(Q)) {
-#define CASE(k) case k: return launch_pgrad_ks<k>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, ws, stage, dmu, ds, dz, dgamma, st);
+#define CASE(k)                                                                                                                  \
+    case k:                                                                                                                      \
+        if (which & 1) rc = launch_pgrad_part1<k>(D, N, M, Q, consts, mu, s, gamma, ws, psi2_part, scale, st);                  \
+        if (rc == DPGP_OK && (which & 2))                                                                                        \
+            rc = launch_pgrad_part2<k>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, scale, ws, dmu, ds, dz, dgamma, st);    \
+        return rc;
         CASE(2) CASE(4) CASE(6) CASE(8)
 #undef CASE
     }

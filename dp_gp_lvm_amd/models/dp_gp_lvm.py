@@ -153,7 +153,13 @@ def dp_gp_lvm(y_train,
     workspace = ops.ElboWorkspace(d_local, num_samples, num_inducing_points, num_latent_dims, precision, device)
     s_1, s_2 = dp_model.prior
 
-    def evaluate(events=None, out=None, _local_part_only=False):
+    # one training step through dpgp_elbo_step (mixed precision, M <= 128, Q <= 20: DESIGN.md section 7.1): the forward's psi2 dispatch is
+    # replaced by the first pass of stage B (DPGP_FUSED_STEP=0: the three separate calls, e.g. for bench.py's per-stage breakdown)
+    fused_step = (precision == 'mixed' and stage_b_precision == 'mixed' and psi_algo == 'auto' and
+                  ops.elbo_step_supported(num_inducing_points, num_latent_dims) and os.environ.get('DPGP_FUSED_STEP', '1') != '0')
+    step_state = {}
+
+    def evaluate(events=None, out=None, _local_part_only=False, _step=False):
         """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior).
         Five launches: prepare, front (KL, y'y, K_uu tiles, operand constants, pair factors), psi1T_y,
         psi2 (+ the K_uu tasks), chain_b (+ the final reduction: sum, pack, finalize); D sharded: the all-reduce and the
@@ -169,9 +175,16 @@ def dp_gp_lvm(y_train,
             buf['phi'].data_ptr(), buf['scal'].data_ptr(), st), 'dpgp_model_prepare')
         red = buf['red']
         # single GPU: the last kernel of the fused ELBO also packs and finalises; sharded: it packs, then one all-reduce
-        ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
-                      jitter=GP_DEFAULT_JITTER, prec=precision, algo=psi_algo, workspace=workspace, events=events,
-                      model_tail=(buf['scal'], red, None if sharded else out))
+        if _step:
+            if 'buf' not in step_state:
+                step_state['buf'] = ops.ElboStepBuffers(d_local, num_samples, num_inducing_points, num_latent_dims, device)
+            step_state['grads'] = ops.elbo_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'], workspace,
+                                                step_state['buf'], jitter=GP_DEFAULT_JITTER,
+                                                model_tail=(buf['scal'], red, None if sharded else out))[1]
+        else:
+            ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
+                          jitter=GP_DEFAULT_JITTER, prec=precision, algo=psi_algo, workspace=workspace, events=events,
+                          model_tail=(buf['scal'], red, None if sharded else out))
         if sharded and not _local_part_only:
             _exchange_and_finalise(out)
         return out
@@ -212,23 +225,28 @@ def dp_gp_lvm(y_train,
 
     def _gradients(events=None):
         """d objective / d (raw trainable variables) — what tf.gradients(objective, trainable variables) gives the
-        reference's optimiser (test/synthetic_data_hard_test.py:143-155).  First version of the backward pass: one forward
-        evaluation, then dpgp_elbo_grad_chain, dpgp_elbo_grad_psi and dpgp_model_backward; sharded over D, the per-GPU
+        reference's optimiser (test/synthetic_data_hard_test.py:143-155).  dpgp_elbo_step (one call: forward, stage A, stage B;
+        mixed precision, M <= 128, Q <= 20) or one forward evaluation, then dpgp_elbo_grad_chain and dpgp_elbo_grad_psi; then
+        dpgp_model_backward; sharded over D, the per-GPU
         partial gradients are packed into one buffer and sum-all-reduced.  Returns {name: tensor} keyed like ``raw``.
         events: optional list of 4 torch.cuda.Event(enable_timing=True), recorded after the forward evaluation, stage A,
         stage B and the chain rule to the raw variables (bench.py's breakdown)."""
         assert precision in ('mixed', 'f64'), 'the backward pass exists for precision mixed and f64'
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
         mark = (lambda i: events[i].record()) if events is not None else (lambda i: None)
-        evaluate()
-        mark(0)
         r = dp_model.raw
-        gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER, z=x_u,
-                                                 gamma=buf['gamma'])
-        mark(1)
-        dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
-                                            prec=stage_b_precision)
-        mark(2)
+        if fused_step and events is None:
+            evaluate(_step=True)
+            dmu, ds, dz, dg, dab, _ = step_state['grads']
+        else:
+            evaluate()
+            mark(0)
+            gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER, z=x_u,
+                                                     gamma=buf['gamma'])
+            mark(1)
+            dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
+                                                prec=stage_b_precision)
+            mark(2)
         rows = r['logits'].shape[0]
         sizes = [num_samples * num_latent_dims, num_samples * num_latent_dims, num_inducing_points * num_latent_dims,
                  rows * truncation_level, max(truncation_level - 1, 1), max(truncation_level - 1, 1), 2,

@@ -372,6 +372,53 @@ def elbo_fhat_t(y, yy, z, mu, s, gamma_atoms, alpha_atoms, beta_atoms, phit, jit
     return w.per_t, w.quad, w.sums, w.info
 
 
+def elbo_step_supported(m, q):
+    """dpgp_elbo_step: B_d in LDS (M <= 128) and the pair-tile form of stage B (Q <= 20)."""
+    return 16 * ((int(m) + 15) // 16) <= 128 and int(q) <= 20
+
+
+class ElboStepBuffers:
+    """Outputs and stage-B workspace of ``elbo_step`` for one problem shape (allocated once: the workspace holds the operand images
+    and the results of the two passes, ~1.6 GB at N=2000, D=512, M=128, Q=10)."""
+
+    def __init__(self, d, n, m, q, device):
+        f64 = torch.float64
+        mp = 16 * ((m + 15) // 16)
+        self.shape = (d, n, m, q)
+        self.gp = torch.empty((d, mp, mp), dtype=f64, device=device)
+        self.wk = torch.empty((d, mp, mp), dtype=f64, device=device)
+        self.gv = torch.empty((d, mp), dtype=f64, device=device)
+        self.dab = torch.empty((d, 2), dtype=f64, device=device)
+        self.info = torch.empty(d, dtype=torch.int32, device=device)
+        self.nbytes = int(_lib.lib().dpgp_elbo_grad_psi_workspace_bytes_ex(d, n, m, q, _lib.PREC['mixed']))
+        self.ws = _ws(self.nbytes, device)
+        self.dmu, self.ds = torch.empty((n, q), dtype=f64, device=device), torch.empty((n, q), dtype=f64, device=device)
+        self.dz, self.dg = torch.empty((m, q), dtype=f64, device=device), torch.empty((d, q), dtype=f64, device=device)
+
+
+def elbo_step(y, z, mu, s, gamma, alpha, beta, workspace, buffers, jitter=1e-8, model_tail=None):
+    """One training step's worth of the fused reduction in mixed precision (dpgp_elbo_step): the f_hat terms of ``elbo_fhat``
+    and the gradients of ``elbo_grad_chain`` + ``elbo_grad_psi`` from ONE call, the Psi2 exponentials evaluated twice instead of
+    three times (dp_gp_lvm.py:108-145 and its tf.gradients, test/synthetic_data_hard_test.py:143-155).
+    workspace: ElboWorkspace(..., 'mixed'); buffers: ElboStepBuffers.  All inputs fp64 device tensors (as ``elbo_fhat``).
+    Returns (terms, sums, info), (d_mu, d_s, d_z, d_gamma, d_alpha_beta, info_grad) — tensors of the two buffer objects."""
+    import ctypes
+    w, b = workspace, buffers
+    d, n, m, q = w.shape
+    assert b.shape == w.shape and w.prec == 'mixed', 'buffers were sized for another problem'
+    assert y.is_cuda and y.dtype == torch.float64 and y.stride(1) == 1 and y.shape == (n, d)
+    w.exec.ev_psi2_begin, w.exec.ev_psi2_end = None, None
+    w.exec.model_scal, w.exec.model_pack, w.exec.model_out = (
+        (None, None, None) if model_tail is None else tuple(None if t_ is None else t_.data_ptr() for t_ in model_tail))
+    _lib.check(_lib.lib().dpgp_elbo_step(
+        d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(),
+        beta.data_ptr(), float(jitter), w.terms.data_ptr(), w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes,
+        b.gp.data_ptr(), b.wk.data_ptr(), b.gv.data_ptr(), b.dab.data_ptr(), b.info.data_ptr(), b.ws.data_ptr(), b.nbytes,
+        b.dmu.data_ptr(), b.ds.data_ptr(), b.dz.data_ptr(), b.dg.data_ptr(), _stream(),
+        ctypes.cast(ctypes.pointer(w.exec), ctypes.c_void_p)), 'dpgp_elbo_step')
+    return (w.terms, w.sums, w.info), (b.dmu, b.ds, b.dz, b.dg, b.dab, b.info)
+
+
 def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None):
     """Backward pass, stage A: adjoints of the per-output dense algebra from the workspace of a finished ``elbo_fhat`` call
     (dp_gp_lvm.py:108-145 differentiated; prec mixed / f64).  M <= 128: one HIP kernel per output dim with B in LDS
@@ -464,7 +511,7 @@ def elbo_grad_psi(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, prec='mixed', g
             raise ValueError('a full Psi1 adjoint is taken in mixed precision only')
         return _elbo_grad_psi_f64_blocks(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v)
     l = _lib.lib()
-    wsb = l.dpgp_elbo_grad_psi_workspace_bytes(d, n, m, q)
+    wsb = l.dpgp_elbo_grad_psi_workspace_bytes_ex(d, n, m, q, _lib.PREC[prec])
     ws = _ws(wsb, dev)
     dmu, ds = torch.empty((n, q), dtype=f64, device=dev), torch.empty((n, q), dtype=f64, device=dev)
     dz, dg = torch.empty((m, q), dtype=f64, device=dev), torch.empty((d, q), dtype=f64, device=dev)

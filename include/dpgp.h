@@ -200,8 +200,11 @@ int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *alpha, const 
  *     (psi2_grad_kernel: the forward's f16-split exponent tiles, a second MFMA product for the z-weighted column sums), the
  *     Psi1 term by two reduction-free kernels, the K_uu term without a pass over the observations;
  *   DPGP_PREC_F64: one plain kernel, M <= 128 (-30 otherwise).
- * M may exceed N (prediction evaluates few test points).  ws: dpgp_elbo_grad_psi_workspace_bytes(D,N,M,Q).                   */
+ * M may exceed N (prediction evaluates few test points).  ws: dpgp_elbo_grad_psi_workspace_bytes_ex(D,N,M,Q,prec) — the
+ * images and results of the pair-tile form (the bulk: ~1.6 GB at N=2000, D=512, M=128, Q=10) are only part of it for
+ * DPGP_PREC_MIXED; dpgp_elbo_grad_psi_workspace_bytes(D,N,M,Q) = the largest of the three (works for every prec).            */
 size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q);
+size_t dpgp_elbo_grad_psi_workspace_bytes_ex(int D, int N, int M, int Q, int prec);
 int dpgp_elbo_grad_psi(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                        const double *s, const double *gamma, const double *alpha, const double *g_psi2,
                        const double *w_kuu, const double *g_v, int prec, void *ws, size_t ws_bytes, double *d_mu,
@@ -213,6 +216,22 @@ int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, 
                           const double *s, const double *gamma, const double *alpha, const double *g_psi2,
                           const double *w_kuu, const double *g_v, const double *g_psi1, int prec, void *ws,
                           size_t ws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream);
+
+/* ---- Training step: the f_hat terms AND their gradients with respect to mu, s, z, gamma (stage B) and alpha, beta (stage A) in
+ * one call — what one Adam iteration of every training script of the reference evaluates (objective + tf.gradients,
+ * test/synthetic_data_hard_test.py:143-155; forward src/models/dp_gp_lvm.py:108-145, src/kernels/rbf_kernel.py:135-199).
+ * Mixed precision (as DPGP_PREC_MIXED of the three calls it replaces: dpgp_elbo_fhat_ex + dpgp_elbo_grad_chain +
+ * dpgp_elbo_grad_psi), M <= 128 (-3), Q <= 20 (-4).  Same results as the three calls within the mixed-precision tolerance; the
+ * Psi2 statistic comes out of the first pass of stage B (same exponentials, constant feature), so its exponentials are
+ * evaluated twice per step instead of three times.
+ *   terms / sums / info / ws: as dpgp_elbo_fhat (ws: dpgp_elbo_workspace_bytes(D,N,M,Q,DPGP_PREC_MIXED));
+ *   g_psi2 / w_kuu / g_v / d_alpha_beta / info_grad: as dpgp_elbo_grad_chain (outputs, caller-allocated);
+ *   gws: dpgp_elbo_grad_psi_workspace_bytes_ex(D,N,M,Q,DPGP_PREC_MIXED);  d_mu / d_s / d_z / d_gamma: as dpgp_elbo_grad_psi.   */
+int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
+                   const double *gamma, const double *alpha, const double *beta, double jitter, double *terms, double *sums,
+                   int *info, void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v, double *d_alpha_beta,
+                   int *info_grad, void *gws, size_t gws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma,
+                   void *stream, const dpgp_exec_t *exec);
 
 /* ---- f_hat of the over-T model dp_gp_lvm_t (reference: src/models/dp_gp_lvm.py:608-676; the [T,M,N] x [N,D] contraction at
  * :657-658): T atoms with their own kernel hyper-parameters, every atom coupled to all D columns of y through phit[T,D].

@@ -398,3 +398,69 @@ def test_pair_tile_stage_b_range_guard_poisons_the_gradients(dev):
     out = ops.elbo_grad_psi(t(rng.standard_normal((n, d))), t(z), t(mu), t(s), t(gamma), t(alpha), t(g), t(np.zeros((d, mp, mp))),
                             t(np.zeros((d, mp))), prec='mixed')
     assert all(bool(torch.isnan(o).any()) for o in out)
+
+
+@pytest.mark.parametrize('shape', [(300, 16, 100, 10), (500, 8, 128, 12), (200, 6, 70, 4), (200, 6, 64, 20), (150, 4, 96, 17),
+                                   (257, 9, 33, 15), (64, 3, 16, 3)])
+def test_training_step_equals_the_three_calls(dev, shape):
+    """dpgp_elbo_step (Psi2 from the first pass of stage B, stage A, the rest of stage B in one call) against dpgp_elbo_fhat_ex +
+    dpgp_elbo_grad_chain + dpgp_elbo_grad_psi on the same inputs, mixed precision: the f_hat terms to the mixed tolerance of the
+    forward tests (2e-5 of the largest term; the two Psi2 kernels round differently), the gradients of BOTH paths to the stated
+    mixed-precision gradient tolerance (5e-4 of the largest entry) of the all-fp64 gradients."""
+    n, d, m, q = shape
+    args = _stage_b_problem(dev, shape)
+    args[1] = args[1] * 0.6                                      # (inducing inputs inside the cloud of latent means: well-conditioned K_uu)
+    w3 = ops.ElboWorkspace(d, n, m, q, 'mixed', dev)
+    terms3, sums3, info3 = [a.clone() for a in ops.elbo_fhat(*args, prec='mixed', workspace=w3)]
+    gp, wk, gv, dab3, infog3 = ops.elbo_grad_chain(args[5], args[6], w3)
+    g3 = [a.cpu().numpy() for a in ops.elbo_grad_psi(args[0], args[1], args[2], args[3], args[4], args[5], gp, wk, gv, prec='mixed')]
+    w1 = ops.ElboWorkspace(d, n, m, q, 'mixed', dev)
+    b1 = ops.ElboStepBuffers(d, n, m, q, dev)
+    assert ops.elbo_step_supported(m, q)
+    for rep in range(2):                                         # (twice: the buffers are reused by every step)
+        (terms1, sums1, info1), (dmu, ds, dz, dg, dab1, infog1) = ops.elbo_step(*args, workspace=w1, buffers=b1)
+    # output dims that the conditioning guard flags (info = -2: the fp32 rounding of Psi2 is amplified beyond the mixed tolerance by a
+    # nearly singular K_uu — random inducing inputs in few latent dims) are exempt in both paths, as in the forward tests
+    ok = ((info1 == 0) & (info3 == 0)).cpu().numpy()
+    assert int(info1.clamp(min=0).max()) == 0 and int(info3.clamp(min=0).max()) == 0
+    assert torch.equal(info1, info3), 'the two paths flag different output dims'
+    t3 = terms3.cpu().numpy()
+    assert np.isfinite(terms1.cpu().numpy()).all()
+    if ok.any():
+        np.testing.assert_allclose(terms1.cpu().numpy()[ok], t3[ok], rtol=0, atol=2e-5 * np.abs(t3[ok]).max())
+    if ok.all():
+        np.testing.assert_allclose(sums1.cpu().numpy(), sums3.cpu().numpy(), rtol=2e-6)
+        assert int(infog1.abs().max()) == 0 and int(infog3.abs().max()) == 0
+        w64 = ops.ElboWorkspace(d, n, m, q, 'f64', dev)
+        ops.elbo_fhat(*args, prec='f64', workspace=w64)
+        gp, wk, gv, dab64, _ = ops.elbo_grad_chain(args[5], args[6], w64)
+        g64 = [a.cpu().numpy() for a in ops.elbo_grad_psi(args[0], args[1], args[2], args[3], args[4], args[5], gp, wk, gv, prec='f64')]
+        for path, dab, grads in (('step', dab1, [a.cpu().numpy() for a in (dmu, ds, dz, dg)]), ('three calls', dab3, g3)):
+            np.testing.assert_allclose(dab.cpu().numpy(), dab64.cpu().numpy(), rtol=0, atol=5e-4 * float(dab64.abs().max()), err_msg=path)
+            for name, got, want in zip(('d mu', 'd S', 'd z', 'd gamma'), grads, g64):
+                np.testing.assert_allclose(got, want, rtol=0, atol=5e-4 * np.abs(want).max(), err_msg='%s, %s' % (name, path))
+
+
+def test_model_gradients_fused_step_equals_separate_calls(dev, monkeypatch):
+    """dp_gp_lvm.gradients() through dpgp_elbo_step (default) and through the three separate calls (DPGP_FUSED_STEP=0): same
+    objective (2e-6) and gradients (2e-4 of the largest entry) of all raw variables."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    from dp_gp_lvm_amd.utils.synthetic import make_problem
+    p = make_problem(1)
+    def build():
+        return dp_gp_lvm(p['y'], num_latent_dims=p['mu'].shape[1], num_inducing_points=p['z'].shape[0],
+                         truncation_level=p['phi'].shape[1], alpha_prior_params=np.array([p['s1'], p['s2']]), device=dev,
+                         precision='mixed',
+                         initial_values=dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']),
+                                             gamma_atoms=p['gamma_atoms'], alpha_atoms=p['alpha_atoms'], beta_atoms=p['beta_atoms'],
+                                             gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'], w_2=p['w2']))
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('DPGP_FUSED_STEP', mode)
+        mdl = build()
+        g = mdl.gradients()
+        out[mode] = ({k: v.cpu().numpy().copy() for k, v in g.items()}, mdl.objective_terms.cpu().numpy())
+    np.testing.assert_allclose(out['1'][1], out['0'][1], rtol=2e-6)
+    for k in out['0'][0]:
+        want = out['0'][0][k]
+        np.testing.assert_allclose(out['1'][0][k], want, rtol=0, atol=2e-4 * max(np.abs(want).max(), 1e-12), err_msg=k)
