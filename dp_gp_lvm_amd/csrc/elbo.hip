@@ -185,7 +185,8 @@ static GradPsiWs grad_psi_ws(int D, int N, int M, int Q, unsigned char *ws) {
 static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
                           const double *gamma, const double *alpha, const double *g_psi2, const double *w_kuu, const double *g_v,
                           const double *g_psi1, bool patch_form, unsigned char *ws, double *d_mu, double *d_s, double *d_z,
-                          double *d_gamma, hipStream_t st, const unsigned char *fwd_consts, const float *fwd_scale) {
+                          double *d_gamma, hipStream_t st, const unsigned char *fwd_consts, const float *fwd_scale,
+                          const float *fwd_psi2 = nullptr) {
     // K_uu term by the plain kernel (no pass over the observations), Psi1 by the reduction-free kernels, Psi2 (nearly all
     // of the work) on the matrix pipe -- where those apply; otherwise everything by the plain kernel
     const bool fast = psi2_grad_supported(M, Q) && !getenv("DPGP_GRAD_PLAIN");
@@ -205,12 +206,18 @@ static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, 
         rc = launch_kuu_grad(D, M, Q, consts, gamma, w_kuu, (double *)ws, W.stage, d_z, d_gamma, st);
         if (rc != DPGP_OK) return rc;
     }
-    rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, g_psi1, W.ws1, W.stage, d_mu, d_s, d_z, d_gamma, st);
-    if (rc != DPGP_OK) return rc;
-    // the Psi2 term: pair-tile form (psi2_pairs_grad.hip) where it exists, else the per-observation patch form
-    if (psi2_pgrad_supported(M, Q) && !patch_form && !getenv("DPGP_GRAD_PATCH"))      // (DPGP_GRAD_PATCH: experiments)
+    // the Psi2 term: pair-tile form (psi2_pairs_grad.hip) where it exists, else the per-observation patch form; the Psi1 term: the
+    // pair-tile form's passes on the diagonal pairs (rank-1 adjoint), else the reduction-free kernels of grad.hip
+    const bool pair_form = psi2_pgrad_supported(M, Q) && !patch_form && !getenv("DPGP_GRAD_PATCH");      // (DPGP_GRAD_PATCH: experiments)
+    const bool psi1_pairs = pair_form && !g_psi1 && y && g_v && !getenv("DPGP_PSI1_PLAIN");
+    if (!psi1_pairs) {
+        rc = launch_psi1_grad(D, N, M, Q, y, ldy, consts, mu, s, gamma, alpha, g_v, g_psi1, W.ws1, W.stage, d_mu, d_s, d_z, d_gamma, st);
+        if (rc != DPGP_OK) return rc;
+    }
+    if (pair_form)
         return launch_psi2_pgrad(D, N, M, Q, consts, z, mu, s, gamma, alpha, g_psi2, W.pgws, W.stage, d_mu, d_s, d_z, d_gamma, st,
-                                 fwd_consts ? 2 : 3, nullptr, fwd_scale);
+                                 fwd_consts ? 2 : 3, const_cast<float *>(fwd_psi2), fwd_scale, psi1_pairs ? y : nullptr, ldy,
+                                 psi1_pairs ? g_v : nullptr);
     if (fwd_consts) return -30;
     return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, W.part, W.stage, d_mu, d_s, d_z, d_gamma, st);
 }
@@ -382,7 +389,8 @@ extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int l
                                   g_psi2, w_kuu, g_v, d_alpha_beta, info_grad, st);
     if (rc != DPGP_OK) return rc;
     return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, nullptr, false, (unsigned char *)gws, d_mu,
-                          d_s, d_z, d_gamma, st, w + L.off_pc, reinterpret_cast<const float *>(w + L.off_sc));
+                          d_s, d_z, d_gamma, st, w + L.off_pc, reinterpret_cast<const float *>(w + L.off_sc),
+                          reinterpret_cast<const float *>(w + L.off_p2));
 }
 
 // ---- f_hat of the over-T model (dp_gp_lvm_t, reference dp_gp_lvm.py:608-676): the T atoms play the part of the output dims in

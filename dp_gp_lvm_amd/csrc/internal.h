@@ -148,4 +148,6 @@ size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q);
 int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
                       double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st, int which = 3,
-                      float *psi2_part = nullptr, const float *scale = nullptr);
+                      float *psi2_part = nullptr, const float *scale = nullptr, const double *y = nullptr, int ldy = 0,
+                      const double *Gv = nullptr);
+// (y, Gv != nullptr: the Psi1 term with the rank-1 adjoint g_v[d][a] y[n][d] through the same passes: dmu, ds overwritten)

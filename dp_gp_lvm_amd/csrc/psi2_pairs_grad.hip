@@ -39,12 +39,19 @@ typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 //   NFB  feature blocks of 32 rows of the second product (2Q + 1 features: Q <= 15 one block, Q <= 20 two)
 //   G    resident column tiles per wave;  NW waves per workgroup, ONE workgroup per compute unit (two waves per SIMD, 256
 //        registers per lane, the whole LDS): with G = 4 and four waves (round 3) the new loop spilled its column operands
+//   WPS  waves per SIMD the register allocation allows (workgroups per compute unit = 4 WPS / NW, each with its share of the LDS)
 #ifndef PG_G4
 #define PG_G4 2
 #endif
-template <int KS> struct PgCfg { static constexpr int NFB = 1, G = PG_G4, NW = 8; };
-template <> struct PgCfg<6> { static constexpr int NFB = 1, G = 2, NW = 8; };
-template <> struct PgCfg<8> { static constexpr int NFB = 2, G = 2, NW = 8; };
+#ifndef PG_NW4
+#define PG_NW4 8
+#endif
+#ifndef PG_WPS4
+#define PG_WPS4 2
+#endif
+template <int KS> struct PgCfg { static constexpr int NFB = 1, G = PG_G4, NW = PG_NW4, WPS = PG_WPS4; };
+template <> struct PgCfg<6> { static constexpr int NFB = 1, G = 2, NW = 8, WPS = 2; };
+template <> struct PgCfg<8> { static constexpr int NFB = 2, G = 1, NW = 8, WPS = 2; };   // (G = 2 spills 130 registers)
 __host__ __device__ inline int pg_nfb(int KS) { return KS >= 8 ? 2 : 1; }
 
 // position of (feature f < 32 of a block, row rr of a 32-row tile) in the transposed feature image of one (row tile, block,
@@ -68,7 +75,8 @@ __device__ __forceinline__ void pg_put(_Float16 *xt, int f, int rr, float v) {
 // this row (rr within its tile) into the transposed images of its row tile
 template <int KS>
 __device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const double *__restrict__ mu, const double *__restrict__ s,
-                                           const float *gq, const float *zc, unsigned *dst, _Float16 *xt, int rr) {
+                                           const float *gq, const float *zc, unsigned *dst, _Float16 *xt, int rr,
+                                           float denfac = 2.0f, float half = 1.0f, float xw = 1.0f) {
     constexpr int SLP = 16 * KS;
     bool oor = false;
     float cc = -60000.0f;
@@ -76,9 +84,11 @@ __device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const doubl
         cc = 0.0f;
         for (int q = 0; q < Q; ++q) {
             const float g = gq[q], sv = (float)s[(size_t)n * Q + q], mc = (float)mu[(size_t)n * Q + q] - zc[q];
-            const float den = 2.0f * g * sv + 1.0f, w = g / den;
-            const float a = dpgp_pin((float)(-0.25 * DPGP_LOG2E / PSI2_PAIR_S2_SCALE) * w);
-            const float bb = dpgp_pin((float)DPGP_LOG2E * w * mc);
+            // Psi2: denfac = 2, half = 1.  Psi1 on the DIAGONAL pairs (s = 2 z', see launch_psi1_pgrad): den = g s + 1 and half the
+            // coefficients — log2 psi1 / alpha = c + sum_q (-8 log2e w1) (s^2 / 64) + (1/2 log2e w1 mu') s
+            const float den = denfac * g * sv + 1.0f, w = g / den;
+            const float a = dpgp_pin(half * (float)(-0.25 * DPGP_LOG2E / PSI2_PAIR_S2_SCALE) * w);
+            const float bb = dpgp_pin(half * (float)DPGP_LOG2E * w * mc);
             cc -= bb * mc + 0.5f * __builtin_amdgcn_logf(den);
             const _Float16 ah = (_Float16)a, alo = (_Float16)(a - (float)ah);
             const _Float16 bh = (_Float16)bb, blo = (_Float16)(bb - (float)bh);
@@ -86,9 +96,9 @@ __device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const doubl
             dst[3 * q] = __builtin_bit_cast(unsigned, w0);
             dst[3 * q + 1] = __builtin_bit_cast(unsigned, w1);
             dst[3 * q + 2] = __builtin_bit_cast(unsigned, w2);
-            if (xt) {
-                pg_put(xt, 2 * q, rr, (float)ah + (float)alo);
-                pg_put(xt, 2 * q + 1, rr, (float)bh + (float)blo);
+            if (xt) {                                             // (xw: a per-row weight of the features — y_nd for the Psi1 term)
+                pg_put(xt, 2 * q, rr, xw * ((float)ah + (float)alo));
+                pg_put(xt, 2 * q + 1, rr, xw * ((float)bh + (float)blo));
             }
         }
         oor = !(cc >= -8192.0f);                                  // range guard of the f16-split exponent (psi2_pairs.hip)
@@ -155,19 +165,39 @@ __global__ __launch_bounds__(256) void pg_u_kernel(int M, int Q, int Mp, const d
 }
 
 // the same from the forward's per-pair factors scale[d][p] = alpha_d^2 exp2(beta_dp) (training step: the table exists)
-__global__ __launch_bounds__(256) void pg_u_scale_kernel(int Ppad, int Mp, const unsigned *__restrict__ pmap,
+__global__ __launch_bounds__(256) void pg_u_scale_kernel(int Ppad, int Mp, int Q, const unsigned *__restrict__ pmap,
                                                          const float *__restrict__ scale, const double *__restrict__ GP,
-                                                         float *__restrict__ u, float *__restrict__ kap) {
+                                                         float *__restrict__ u, float *__restrict__ kap,
+                                                         const float *__restrict__ psi2, const double *__restrict__ z,
+                                                         double *__restrict__ dgamma) {
+    // psi2 != nullptr ([D][Mp][Mp], slab 0 of the forward's partial slabs = the column sums of pass 1 with their per-pair factors):
+    // the derivative through beta_dp = -1/4 log2e sum_q gamma_dq delta_pq^2 needs only g_dp psi2_dp per pair,
+    //     dgamma[d][q] += sum_p -1/4 delta_pq^2 g_dp psi2_dp        (what pg_dgamma_pairs_kernel forms from u_dp and R2's constant feature)
     __shared__ float red[256];
+    __shared__ double redd[256];
     const int d = blockIdx.x, t = threadIdx.x;
     const double *Gd = GP + (size_t)d * Mp * Mp;
+    const float *Pd = psi2 ? psi2 + (size_t)d * Mp * Mp : nullptr;
     float mx = 0.0f;
+    double a[DPGP_MAX_Q];
+#pragma unroll
+    for (int q = 0; q < DPGP_MAX_Q; ++q) a[q] = 0.0;
     for (int p = t; p < Ppad; p += 256) {
         const unsigned pm = pmap[p];
         float val = 0.0f;
         if (pm != 0xffffffffu) {
             const int m = pm >> 16, mp = pm & 0xffffu;
-            val = (float)Gd[(size_t)m * Mp + mp] * (m == mp ? 1.0f : 2.0f) * scale[(size_t)d * Ppad + p];
+            const float g = (float)Gd[(size_t)m * Mp + mp] * (m == mp ? 1.0f : 2.0f);
+            val = g * scale[(size_t)d * Ppad + p];
+            if (Pd && m != mp) {
+                const double gp2 = -0.25 * (double)g * (double)Pd[(size_t)m * Mp + mp];
+#pragma unroll
+                for (int q = 0; q < DPGP_MAX_Q; ++q)
+                    if (q < Q) {
+                        const double dd = z[(size_t)m * Q + q] - z[(size_t)mp * Q + q];
+                        a[q] += dd * dd * gp2;
+                    }
+            }
         }
         u[(size_t)d * Ppad + p] = val;
         mx = fmaxf(mx, fabsf(val));
@@ -189,6 +219,20 @@ __global__ __launch_bounds__(256) void pg_u_scale_kernel(int Ppad, int Mp, const
         }
         kap[d] = k;
     }
+    if (Pd) {
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q) {
+            if (q >= Q) break;
+            __syncthreads();
+            redd[t] = a[q];
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (t < o) redd[t] += redd[t + o];
+                __syncthreads();
+            }
+            if (t == 0) dgamma[(size_t)d * Q + q] += redd[0];
+        }
+    }
 }
 
 // ---- precomputed images -----------------------------------------------------------------------------------------------
@@ -203,7 +247,9 @@ template <int KS>
 __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const unsigned char *__restrict__ consts,
                                                             const double *__restrict__ mu, const double *__restrict__ s,
                                                             const double *__restrict__ gamma, _Float16 *__restrict__ cimg,
-                                                            _Float16 *__restrict__ ximg, int NT, int *__restrict__ flag) {
+                                                            _Float16 *__restrict__ ximg, int NT, int *__restrict__ flag,
+                                                            const double *__restrict__ y, int ldy) {
+    // y != nullptr: the images of the Psi1 term (den = g s + 1, half coefficients, features weighted by y_nd)
     constexpr int SLP = 16 * KS, RW = SLP / 2 + 4, NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *gq = reinterpret_cast<float *>(smem_raw), *zc = gq + 32;
@@ -218,8 +264,9 @@ __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const 
     {
         _Float16 *xr = xt + (size_t)(t >> 5) * 2048 * NFB;
         const bool valid = n0 + t < N;
-        const bool oor = pg_obs_row<KS>(valid, n0 + t, Q, mu, s, gq, zc, rows + t * RW, xr, t & 31);
-        pg_put(xr, 2 * Q, t & 31, valid ? 1.0f : 0.0f);
+        const float xw = (y && valid) ? (float)y[(size_t)(n0 + t) * ldy + d] : 1.0f;
+        const bool oor = pg_obs_row<KS>(valid, n0 + t, Q, mu, s, gq, zc, rows + t * RW, xr, t & 31, y ? 1.0f : 2.0f, y ? 0.5f : 1.0f, xw);
+        pg_put(xr, 2 * Q, t & 31, valid ? xw : 0.0f);
         for (int f = 2 * Q + 1; f < NF; ++f) pg_put(xr, f, t & 31, 0.0f);
         if (oor) atomicOr(flag, 1);
     }
@@ -235,15 +282,15 @@ __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const 
     for (int e = t; e < ntl * 256 * NFB; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
 }
 
-// pair side: thread = pair; ximg per output dim (features x kap_d u_dp)
+// pair side: thread = pair; ximg per output dim (features x kap_d u_dp).  pimg: an operand-order image of Ppad rows (the pair image
+// of psi2_consts, or its diagonal pairs for the Psi1 term: pg_diag_image_kernel), u: [D][Ppad]
 template <int KS>
-__global__ __launch_bounds__(256) void pg_pair_images_kernel(int M, int Q, const unsigned char *__restrict__ consts,
+__global__ __launch_bounds__(256) void pg_pair_images_kernel(int Ppad, int Q, const _Float16 *__restrict__ pimg,
                                                              const float *__restrict__ u, const float *__restrict__ kap,
                                                              _Float16 *__restrict__ ximg) {
     constexpr int SLP = 16 * KS, NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
     __shared__ __align__(16) _Float16 xt[8 * 2048 * NFB];
-    const Psi2Consts C = psi2_consts_layout(M, Q);
-    const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
+    struct { int Ppad; } C = {Ppad};
     const int d = blockIdx.y, t = threadIdx.x, p0 = 256 * blockIdx.x, p = p0 + t, PT = C.Ppad / 32;
     const int tile0 = p0 / 32, ntl = min(8, PT - tile0);
     if (p < C.Ppad) {
@@ -275,6 +322,87 @@ __global__ __launch_bounds__(256) void pg_pair_images_kernel(int M, int Q, const
     __syncthreads();
     pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * PT + tile0) * 256 * NFB;
     for (int e = t; e < ntl * 256 * NFB; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
+}
+
+// ---- Psi1 term through the same passes --------------------------------------------------------------------------------------
+// psi1[n, m] = alpha exp2(c_n + sum_q a_nq z'_mq^2 + b_nq z'_mq) is the exponent product of the pair form on the DIAGONAL pairs
+// p = (m, m): s = 2 z'_m, s^2 / 64 = z'^2 / 16, with half the observation-side coefficients and den = g s + 1 (pg_obs_row).
+// dimg: the diagonal pairs' rows of the pair image, regathered in operand order (Mpad = 32 ceil(M / 32) rows, rows >= M zero).
+template <int KS>
+__global__ __launch_bounds__(256) void pg_diag_image_kernel(int M, int Mpad, const _Float16 *__restrict__ pimg, _Float16 *__restrict__ dimg) {
+    const int e = blockIdx.x * 256 + threadIdx.x;               // (point m, K-step ks, lane half hf)
+    if (e >= Mpad * KS * 2) return;
+    const int hf = e & 1, ks = (e >> 1) % KS, m = e / (2 * KS);
+    pg_u4 w = {0u, 0u, 0u, 0u};
+    if (m < M) {
+        const long long p = (long long)m * (m + 1) / 2 + m;
+        w = reinterpret_cast<const pg_u4 *>(pimg)[((size_t)(p >> 5) * KS + ks) * 64 + 32 * hf + (int)(p & 31)];
+    }
+    reinterpret_cast<pg_u4 *>(dimg)[((size_t)(m >> 5) * KS + ks) * 64 + 32 * hf + (m & 31)] = w;
+}
+// u1[d][m] = alpha_d g_v[d][m] (the adjoint of (Psi1^T y)_dm with psi1's factor alpha), kap1[d]: the power of two that brings
+// max_m |u1| into [2^7, 2^8)
+__global__ __launch_bounds__(64) void pg_u1_kernel(int M, int Mp, int Mpad, const double *__restrict__ alpha, const double *__restrict__ Gv,
+                                                   float *__restrict__ u1, float *__restrict__ kap1) {
+    const int d = blockIdx.x, t = threadIdx.x;
+    const float al = (float)alpha[d];
+    float mx = 0.0f;
+    for (int m = t; m < Mpad; m += 64) {
+        const float v = m < M ? al * (float)Gv[(size_t)d * Mp + m] : 0.0f;
+        u1[(size_t)d * Mpad + m] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (t == 0) {
+        float k = 1.0f;
+        if (mx > 0.0f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);
+            ex = max(-100, min(100, ex));
+            k = ldexpf(1.0f, 8 - ex);
+        }
+        kap1[d] = k;
+    }
+}
+// d/dz of the Psi1 term: block = inducing point m, threads over the output dims:
+//   dz[m][q] += 2 ln2 2^-12 sum_d u1_dm (2 S2 s_mq R[d][m][2q] + R[d][m][2q + 1]),  s = 2 z'
+// (R: pass "rows = observations, columns = inducing points" with the y-weighted features; the 2: d s / d z')
+template <int NF, int QP>
+__global__ __launch_bounds__(256) void pg_finish_m1_kernel(int M, int Mpad, int Q, int D, const double *__restrict__ z,
+                                                           const unsigned char *__restrict__ consts, const float *__restrict__ u1,
+                                                           const float *__restrict__ r, double *__restrict__ dz) {
+    __shared__ double red[4][2 * QP];
+    const int m = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    double ta[QP], tb[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) { ta[q] = 0.0; tb[q] = 0.0; }
+    for (int d = t; d < D; d += 256) {
+        const double ud = (double)u1[(size_t)d * Mpad + m];
+        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r + ((size_t)d * Mpad + m) * NF);
+        float rv[NF];
+#pragma unroll
+        for (int k = 0; k < NF / 4; ++k) {
+            const pg_f4 v = row[k];
+            rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
+        }
+#pragma unroll
+        for (int q = 0; q < QP; ++q)
+            if (q < Q && 2 * q + 1 < NF) { ta[q] += ud * (double)rv[2 * q]; tb[q] += ud * (double)rv[2 * q + 1]; }
+    }
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        if (q >= Q) break;
+        const double va = wave_sum(ta[q]), vb = wave_sum(tb[q]);
+        if (lane == 0) { red[wv][2 * q] = va; red[wv][2 * q + 1] = vb; }
+    }
+    __syncthreads();
+    if (t < Q) {
+        const double sq = 2.0 * (z[(size_t)m * Q + t] - (double)reinterpret_cast<const float *>(consts)[t]);
+        const double sa = red[0][2 * t] + red[1][2 * t] + red[2][2 * t] + red[3][2 * t];
+        const double sb = red[0][2 * t + 1] + red[1][2 * t + 1] + red[2][2 * t + 1] + red[3][2 * t + 1];
+        dz[(size_t)m * Q + t] += 2.0 * 0.6931471805599453 * (1.0 / 4096.0) * (2.0 * (double)PSI2_PAIR_S2_SCALE * sq * sa + sb);
+    }
 }
 
 // ---- one pass: rows (LDS ring, LDS-DMA copies of an operand-order image and of ximg) x resident column tiles (cimg) --------
@@ -426,7 +554,7 @@ __device__ __forceinline__ void pg_step(pg_f16v &c_nxt, const pg_f16v &c_cur, co
 }
 
 template <int KS>
-__global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::NW / 4) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
+__global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
                                                                    const _Float16 *__restrict__ ximg,
                                                                    const _Float16 *__restrict__ cimg, int col_per_d,
                                                                    float *__restrict__ out, int n_row_tiles, int n_col_tiles,
@@ -434,7 +562,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::NW / 4) void pg_pass
     constexpr int NFB = PgCfg<KS>::NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW, NF = PG_FB * NFB;
     constexpr int PIECES = KS + 4 * NFB, TILE_BYTES = 1024 * PIECES;   // LDS bytes of one row tile: K-steps of the exponent operand, then the features
     typedef PgSched<KS, NFB> S;
-    static_assert((G & 1) == 0, "the two exponent tiles alternate");
+    constexpr int LA = G == 1 ? 2 : 1;                         // row tiles between an LDS read of the exponent operand and its row tile
     extern __shared__ __align__(16) unsigned char smem_raw[];
     typedef __attribute__((address_space(3))) void lds_void;
     // same-d workgroups on one XCD (blocks are dealt round-robin over the 8 XCDs: speed only): they re-read the same row images
@@ -498,6 +626,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::NW / 4) void pg_pass
     pg_h8 wh1 = pg_quad(0u, 0u, 0u, 0u), wl1 = wh1;             // (the first step's "previous" products add zero)
     pg_f16v c[2];
     load_a(a_0, 0);
+    if constexpr (G == 1) load_a(a_1, n_row_tiles > 1 ? 1 : 0);
     load_x(x1h, x1l, 0, 1);
     {
         const pg_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -507,43 +636,56 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::NW / 4) void pg_pass
     }
     int pos = 0, in_chunk = 0, chunk = 0;                         // ring slot of row tile rt, its index in its chunk, its chunk
     // one row tile: G steps against the resident column tiles; a_cur / a_nxt swap roles from one row tile to the next
-    auto row_tile = [&](const pg_h8 (&a_cur)[KS], pg_h8 (&a_nxt)[KS], int rt) __attribute__((always_inline)) {
-        if (in_chunk == NTb - 1 && chunk + 1 < n_chunks) {
-            // in front of the chunk's last row tile: the next chunk is complete in LDS (own pieces: vmcnt, everybody's: barrier), and
-            // everybody has left the previous chunk, whose ring slots take the chunk after the next
+    // G >= 2: a_cur holds this row tile's exponent operand, a_nxt receives the next one's (read one step ahead of its first use);
+    // G == 1: a_nxt holds the NEXT row tile's (the chain issued in this step), a_cur receives the one after it.  PAR: parity of the
+    // steps in front of this row tile (the two exponent tiles alternate from step to step).
+    auto row_tile = [&](auto par, pg_h8 (&a_cur)[KS], pg_h8 (&a_nxt)[KS], int rt) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+        if (in_chunk == NTb - LA && chunk + 1 < n_chunks) {
+            // LA row tiles in front of the chunk's end: the next chunk is complete in LDS (own pieces: vmcnt, everybody's: barrier),
+            // and everybody has left the previous chunk, whose ring slots take the chunk after the next
             __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0)
             __syncthreads();
             if (chunk + 2 < n_chunks) fill(chunk + 2);
         }
-        const int pos_n = (rt + 1 < n_row_tiles) ? (pos + 1 == RING ? 0 : pos + 1) : pos;   // (behind the last row tile: one surplus chain)
+        // ring slot of the row tile LA ahead (behind the last row tile: surplus chains on the last one)
+        int pos_n = pos;
+        if (rt + LA < n_row_tiles) { pos_n = pos + LA; if (pos_n >= RING) pos_n -= RING; }
+        else if (LA == 2 && rt + 1 < n_row_tiles) { pos_n = pos + 1 == RING ? 0 : pos + 1; }
         pg_unroll(std::make_integer_sequence<int, G>{}, [&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value;
+            constexpr int g = decltype(gc)::value, st = PAR * G + g;
             auto hook = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 // LDS reads of the row tile, each behind the last matrix instruction that reads the registers it replaces and a
                 // few slots ahead of its first use (a read issued just in front of a wait for an OLDER one is waited for as well:
                 // lgkmcnt counts in order).  Step 0: this row tile's K-step-0 features behind the first product of the previous
                 // step (the previous step's K-step-0 products are all issued), its K-step-1 features behind the first K-step-0
-                // product (the previous row tile's K-step-1 products are all issued); the next row tile's exponent operand one
-                // step ahead of its first use.
+                // product (the previous row tile's K-step-1 products are all issued); the exponent operand one step ahead of
+                // its first use.
                 if constexpr (g == 0 && j == S::first_of(1)) load_x(x0h, x0l, pos, 0);
-                if constexpr (g == (G >= 2 ? G - 2 : 0) && j == S::first_of(1)) load_a(a_nxt, pos_n);
+                if constexpr (G == 1) {
+                    if constexpr (j == S::first_of(1)) load_a(a_cur, pos_n);
+                } else {
+                    if constexpr (g == G - 2 && j == S::first_of(1)) load_a(a_nxt, pos_n);
+                }
                 if constexpr (g == 0 && j == S::J0) load_x(x1h, x1l, pos, 1);
             };
             if constexpr (g + 1 < G)
-                pg_step<KS, NFB>(c[(g + 1) & 1], c[g & 1], a_cur, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
+                pg_step<KS, NFB>(c[(st + 1) & 1], c[st & 1], a_cur, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
             else
-                pg_step<KS, NFB>(c[(g + 1) & 1], c[g & 1], a_nxt, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
+                pg_step<KS, NFB>(c[(st + 1) & 1], c[st & 1], a_nxt, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
         });
-        pos = pos_n;
+        pos = pos + 1 == RING ? 0 : pos + 1;
         if (++in_chunk == NTb) { in_chunk = 0; ++chunk; }
     };
+    typedef std::integral_constant<int, 0> P0;
+    typedef std::integral_constant<int, G & 1> P1;
 #pragma unroll 1
     for (int rt = 0; rt + 1 < n_row_tiles; rt += 2) {          // (pairs: the two operand buffers swap roles without register moves;
-        row_tile(a_0, a_1, rt);                                   //  a break between the two made the compiler copy the accumulators)
-        row_tile(a_1, a_0, rt + 1);
+        row_tile(P0{}, a_0, a_1, rt);                             //  a break between the two made the compiler copy the accumulators)
+        row_tile(P1{}, a_1, a_0, rt + 1);
     }
-    if (n_row_tiles & 1) row_tile(a_0, a_1, n_row_tiles - 1);
+    if (n_row_tiles & 1) row_tile(P0{}, a_0, a_1, n_row_tiles - 1);
     // the last step's K-step-1 half
 #pragma unroll
     for (int i = 0; i < 3 * NFB; ++i) {
@@ -587,16 +729,16 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::NW / 4) void pg_pass
 // ---- finishing, pair side -----------------------------------------------------------------------------------------------
 // thread = pair p, block row = chunk of output dims: partial sums over the chunk's d of
 //   tp[c][0][p][q] = sum_d u_dp R2[2q],  tp[c][1][p][q] = sum_d u_dp R2[2q+1],  tp[c][2][p][q] = sum_d u_dp C_dp gamma_dq  (C = R2[2Q])
-template <int NF>
+template <int NF, int QP>
 __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int D, int Ppad, int dchunk,
                                                               const double *__restrict__ gamma, const float *__restrict__ u,
                                                               const float *__restrict__ r2, double *__restrict__ tp) {
     const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     const int P = (int)((long long)M * (M + 1) / 2);
     if (p >= P) return;
-    double a1[DPGP_MAX_Q], a2[DPGP_MAX_Q], a3[DPGP_MAX_Q];
+    double a1[QP], a2[QP], a3[QP];
 #pragma unroll
-    for (int q = 0; q < DPGP_MAX_Q; ++q) { a1[q] = 0.0; a2[q] = 0.0; a3[q] = 0.0; }
+    for (int q = 0; q < QP; ++q) { a1[q] = 0.0; a2[q] = 0.0; a3[q] = 0.0; }
     const int d1 = min(D, (c + 1) * dchunk);
     for (int d = c * dchunk; d < d1; ++d) {
         const float ud = u[(size_t)d * Ppad + p] * (1.0f / 4096.0f);          // (x 2^-PG_WSHIFT)
@@ -612,7 +754,7 @@ __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int 
         for (int k = 0; k < NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
         const double uc = (double)ud * (double)cc;
 #pragma unroll
-        for (int q = 0; q < DPGP_MAX_Q; ++q)
+        for (int q = 0; q < QP; ++q)
             if (q < Q && 2 * q + 1 < NF) {
                 a1[q] += (double)ud * (double)rv[2 * q];
                 a2[q] += (double)ud * (double)rv[2 * q + 1];
@@ -621,7 +763,7 @@ __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int 
     }
     double *o = tp + (size_t)c * 3 * P * Q;
 #pragma unroll
-    for (int q = 0; q < DPGP_MAX_Q; ++q)
+    for (int q = 0; q < QP; ++q)
         if (q < Q) {
             o[(size_t)p * Q + q] = a1[q];
             o[((size_t)P + p) * Q + q] = a2[q];
@@ -687,69 +829,121 @@ __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int 
     }
 }
 
-// ---- finishing, observation side: thread = observation n, block row = chunk of output dims ---------------------------------
-// dmu_part / ds_part [chunk][N][Q]: partial sums over the chunk's d;  dg_part[n-block][d][q]: this block's share of dgamma
-template <int NF>
-__global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D, int NT, int dchunk,
-                                                            const unsigned char *__restrict__ consts,
-                                                            const double *__restrict__ mu, const double *__restrict__ s,
-                                                            const double *__restrict__ gamma, const float *__restrict__ kap,
-                                                            const float *__restrict__ r1, double *__restrict__ dmu_part,
-                                                            double *__restrict__ ds_part, double *__restrict__ dg_part) {
-    __shared__ double red[4][DPGP_MAX_Q + 2];
-    const int t = threadIdx.x, n = blockIdx.x * 256 + t, lane = t & 63, wv = t >> 6, c = blockIdx.y;
+// ---- finishing, observation side ------------------------------------------------------------------------------------------
+// The chain rule of one (output dim d, observation n) from its row of a pass with rows = pairs / inducing points and columns =
+// observations: (ra, rb, rc) = the a-, b- and constant-feature sums, scaled.  src 0: the Psi2 term (den = 2 g s + 1); src 1: the Psi1
+// term on the diagonal pairs (den = g s + 1, half the coefficients — carried by `ik` —, the row weighted by y_nd).
+// one latent dim q of that chain rule: adds to d/dmu', d/dS and d/dgamma_q
+__device__ __forceinline__ void pg_obs_chain_q(double ra, double rb, double rc, double g, double mc, double sv, int src, double &am,
+                                               double &as_, double &dg) {
+    const double df = src ? 1.0 : 2.0;
+    // (one fp32 reciprocal: three fp64 divisions per (d, n, q) were most of this kernel's time — ~40 instructions each)
+    const double id = (double)(1.0f / (float)(df * g * sv + 1.0)), w = g * id;
+    const double dw = (-0.25 / (double)PSI2_PAIR_S2_SCALE) * ra + mc * rb - mc * mc * rc;
+    const double dmc = w * (rb - 2.0 * mc * rc);
+    // (the 1/2 log2 den of the row constant carries no "half": undo it for the Psi1 rows, whose scale holds it)
+    const double dden = -0.5 * rc * (src ? 2.0 : 1.0) * id - w * id * dw;
+    am += dmc;
+    as_ += df * g * dden;
+    dg += dw * id + df * sv * dden;
+}
+// thread = observation n, block row = chunk of output dims: dmu_part / ds_part [chunk][N][Q] = partial sums over the chunk's d
+// (no cross-thread reduction).  r1p / kap1 / y (optional): the Psi1 term's rows in the same sweep.
+template <int NF, int QP>
+__global__ __launch_bounds__(256) void pg_finish_obs_n_kernel(int N, int Q, int D, int NT, int dchunk,
+                                                              const unsigned char *__restrict__ consts,
+                                                              const double *__restrict__ mu, const double *__restrict__ s,
+                                                              const double *__restrict__ gamma, const float *__restrict__ kap,
+                                                              const float *__restrict__ r1, const float *__restrict__ kap1,
+                                                              const float *__restrict__ r1p, const double *__restrict__ y, int ldy,
+                                                              double *__restrict__ dmu_part, double *__restrict__ ds_part) {
+    __shared__ double gsh[QP];
+    const int t = threadIdx.x, n = blockIdx.x * 256 + t, c = blockIdx.y;
     const bool ok = n < N;
-    double mc[DPGP_MAX_Q], sv[DPGP_MAX_Q], am[DPGP_MAX_Q], as_[DPGP_MAX_Q];
+    const int nn = ok ? n : N - 1;
+    float mc[QP], sv[QP];
+    double am[QP], as_[QP];
 #pragma unroll
-    for (int q = 0; q < DPGP_MAX_Q; ++q) {
-        const bool on = ok && q < Q;
-        mc[q] = on ? mu[(size_t)n * Q + q] - (double)reinterpret_cast<const float *>(consts)[q] : 0.0;
-        sv[q] = on ? s[(size_t)n * Q + q] : 1.0;
-        am[q] = 0.0;
-        as_[q] = 0.0;
+    for (int q = 0; q < QP; ++q) {
+        mc[q] = q < Q ? (float)(mu[(size_t)nn * Q + q] - (double)reinterpret_cast<const float *>(consts)[q]) : 0.0f;
+        sv[q] = q < Q ? (float)s[(size_t)nn * Q + q] : 1.0f;
+        am[q] = 0.0; as_[q] = 0.0;
     }
     const int d1 = min(D, (c + 1) * dchunk);
     for (int d = c * dchunk; d < d1; ++d) {
-        const double ik = 1.0 / ((double)kap[d] * 4096.0);            // (kap_d and 2^PG_WSHIFT)
-        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r1 + ((size_t)d * NT * 32 + (ok ? n : 0)) * NF);
-        float rv[NF];
-#pragma unroll
-        for (int k = 0; k < NF / 4; ++k) {
-            const pg_f4 v = row[k];
-            rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
-        }
-        float cc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
-        const double rc = ok ? (double)cc * ik : 0.0;
-#pragma unroll
-        for (int q = 0; q < DPGP_MAX_Q; ++q) {
-            if (q >= Q || 2 * q + 1 >= NF) break;
-            const double g = gamma[(size_t)d * Q + q];
-            const double ra = ok ? (double)rv[2 * q] * ik : 0.0, rb = ok ? (double)rv[2 * q + 1] * ik : 0.0;
-            const double den = 2.0 * g * sv[q] + 1.0, w = g / den;
-            const double dw = (-0.25 / (double)PSI2_PAIR_S2_SCALE) * ra + mc[q] * rb - mc[q] * mc[q] * rc;
-            const double dmc = w * (rb - 2.0 * mc[q] * rc);
-            const double dden = -0.5 * rc / den - (g / (den * den)) * dw;
-            am[q] += dmc;
-            as_[q] += 2.0 * g * dden;
-            double dgq = dw / den + 2.0 * sv[q] * dden;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) dgq += __shfl_xor(dgq, o, 64);
-            if (lane == 0) red[wv][q] = dgq;
-        }
         __syncthreads();
-        if (t < Q) dg_part[((size_t)blockIdx.x * D + d) * Q + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        if (t < QP) gsh[t] = t < Q ? gamma[(size_t)d * Q + t] : 0.0;
         __syncthreads();
+#pragma unroll
+        for (int src = 0; src < 2; ++src) {
+            if (src && !r1p) break;
+            const float *row = (src ? r1p : r1) + ((size_t)d * NT * 32 + nn) * NF;
+            const double ik = (src ? 0.5 * y[(size_t)nn * ldy + d] : 1.0) / ((double)(src ? kap1 : kap)[d] * 4096.0);
+            const double rc = (double)row[2 * Q] * ik;
+            double dg = 0.0;
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                if (q >= Q) break;
+                const float2 ab = *reinterpret_cast<const float2 *>(row + 2 * q);
+                pg_obs_chain_q((double)ab.x * ik, (double)ab.y * ik, rc, gsh[q], (double)mc[q], (double)sv[q], src, am[q], as_[q], dg);
+            }
+        }
     }
     if (ok) {
 #pragma unroll
-        for (int q = 0; q < DPGP_MAX_Q; ++q)
+        for (int q = 0; q < QP; ++q)
             if (q < Q) {
                 dmu_part[((size_t)c * N + n) * Q + q] = am[q];
                 ds_part[((size_t)c * N + n) * Q + q] = as_[q];
             }
     }
+}
+// block = output dim d, threads over the observations: dgamma[d][q] += sum_n (...), ONE block reduction per output dim
+template <int NF, int QP>
+__global__ __launch_bounds__(256) void pg_finish_obs_d_kernel(int N, int Q, int NT, const unsigned char *__restrict__ consts,
+                                                              const double *__restrict__ mu, const double *__restrict__ s,
+                                                              const double *__restrict__ gamma, const float *__restrict__ kap,
+                                                              const float *__restrict__ r1, const float *__restrict__ kap1,
+                                                              const float *__restrict__ r1p, const double *__restrict__ y, int ldy,
+                                                              double *__restrict__ dgamma) {
+    __shared__ double gsh[QP];
+    __shared__ float zc[QP];
+    __shared__ double red[4][QP];
+    const int t = threadIdx.x, d = blockIdx.x, lane = t & 63, wv = t >> 6;
+    if (t < QP) {
+        gsh[t] = t < Q ? gamma[(size_t)d * Q + t] : 0.0;
+        zc[t] = t < Q ? reinterpret_cast<const float *>(consts)[t] : 0.0f;
+    }
+    __syncthreads();
+    double dgq[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) dgq[q] = 0.0;
+    const double ik0 = 1.0 / ((double)kap[d] * 4096.0), ik1 = r1p ? 0.5 / ((double)kap1[d] * 4096.0) : 0.0;
+    for (int n = t; n < N; n += 256) {
+#pragma unroll
+        for (int src = 0; src < 2; ++src) {
+            if (src && !r1p) break;
+            const float *row = (src ? r1p : r1) + ((size_t)d * NT * 32 + n) * NF;
+            const double ik = src ? ik1 * y[(size_t)n * ldy + d] : ik0;
+            const double rc = (double)row[2 * Q] * ik;
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                if (q >= Q) break;
+                const float2 ab = *reinterpret_cast<const float2 *>(row + 2 * q);
+                double am = 0.0, as_ = 0.0;
+                pg_obs_chain_q((double)ab.x * ik, (double)ab.y * ik, rc, gsh[q], mu[(size_t)n * Q + q] - (double)zc[q], s[(size_t)n * Q + q],
+                               src, am, as_, dgq[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        if (q >= Q) break;
+        const double v = wave_sum(dgq[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (t < Q) dgamma[(size_t)d * Q + t] += red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
 // a range-guard hit anywhere: the outputs become NaN (never a silently wrong gradient)
@@ -769,19 +963,29 @@ bool psi2_pgrad_supported(int M, int Q) {
 }
 
 template <int KS> static int pg_ring_tiles() {                   // row tiles per chunk of the pass kernel's LDS ring
-    // three chunks of NTb row tiles (KS + 4 NFB KB each) in the 160 KB of the one workgroup per CU
-    int NTb = (int)((size_t)(160 * 1024 * PgCfg<KS>::NW / 8) / ((size_t)3 * 1024 * (KS + 4 * PgCfg<KS>::NFB)));
+    // three chunks of NTb row tiles (KS + 4 NFB KB each) in the workgroup's share of the 160 KB
+    int NTb = (int)((size_t)(160 * 1024 * PgCfg<KS>::NW / (4 * PgCfg<KS>::WPS)) / ((size_t)3 * 1024 * (KS + 4 * PgCfg<KS>::NFB)));
     if (const char *e = getenv("DPGP_PG_NTB")) {                 // (experiments only)
         const int v = atoi(e);
-        if (v >= 1 && v <= NTb) NTb = v;
+        if (v >= (PgCfg<KS>::G == 1 ? 2 : 1) && v <= NTb) NTb = v;
     }
     return NTb;
 }
+// finishing kernels: per-thread arrays of QP = 4 ceil(Q / 4) entries (Q <= 20 here; arrays of DPGP_MAX_Q doubles spill)
+#define PG_QP_SWITCH(Q, CALL)                                   \
+    switch (((Q) + 3) / 4) {                                    \
+        case 1: { constexpr int QP_ = 4; CALL; } break;         \
+        case 2: { constexpr int QP_ = 8; CALL; } break;         \
+        case 3: { constexpr int QP_ = 12; CALL; } break;        \
+        case 4: { constexpr int QP_ = 16; CALL; } break;        \
+        default: { constexpr int QP_ = 20; CALL; } break;       \
+    }
 #define PG_DC_PAIRS 16               // chunks of output dims of the finishing kernels
 #define PG_DC_OBS 64
 struct PgLayout {
-    int KS, NF, P, Ppad, NT, PT, nblk_obs;
-    size_t off_u, off_kap, off_flag, off_cobs, off_xobs, off_xpair, off_r2, off_r1, off_tp, off_tt, off_dgp, off_dmup, off_dsp, total;
+    int KS, NF, P, Ppad, NT, PT, nblk_obs, MT;
+    size_t off_u, off_kap, off_flag, off_cobs, off_xobs, off_xpair, off_r2, off_r1, off_tp, off_tt, off_dmup, off_dsp,
+        off_cobs1, off_xobs1, off_dimg, off_xm1, off_r1p, off_r2p, off_u1, off_kap1, total;   // (..1 / ..p: the Psi1 term)
 };
 static PgLayout pg_layout(int D, int N, int M, int Q) {
     PgLayout L;
@@ -801,9 +1005,17 @@ static PgLayout pg_layout(int D, int N, int M, int Q) {
     L.off_r1 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * L.NF);
     L.off_tp = o;    o += dpgp_align256(sizeof(double) * (size_t)PG_DC_PAIRS * 3 * L.P * Q);
     L.off_tt = o;    o += dpgp_align256(sizeof(double) * (size_t)3 * L.P * Q);
-    L.off_dgp = o;   o += dpgp_align256(sizeof(double) * (size_t)L.nblk_obs * D * Q);
     L.off_dmup = o;  o += dpgp_align256(sizeof(double) * (size_t)PG_DC_OBS * N * Q);
     L.off_dsp = o;   o += dpgp_align256(sizeof(double) * (size_t)PG_DC_OBS * N * Q);
+    L.MT = dpgp_ceil_div(M, 32);
+    L.off_cobs1 = o; o += dpgp_align256(h * (size_t)D * L.NT * L.KS * 64 * 8);
+    L.off_xobs1 = o; o += dpgp_align256(h * (size_t)D * L.NT * 2048 * nfb);
+    L.off_dimg = o;  o += dpgp_align256(h * (size_t)L.MT * L.KS * 64 * 8);
+    L.off_xm1 = o;   o += dpgp_align256(h * (size_t)D * L.MT * 2048 * nfb);
+    L.off_r1p = o;   o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * L.NF);
+    L.off_r2p = o;   o += dpgp_align256(sizeof(float) * (size_t)D * L.MT * 32 * L.NF);
+    L.off_u1 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.MT * 32);
+    L.off_kap1 = o;  o += dpgp_align256(sizeof(float) * (size_t)D);
     L.total = o;
     return L;
 }
@@ -827,7 +1039,7 @@ static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *c
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
         DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(dpgp_ceil_div(N, 256), D), dim3(256), lds, st, N, Q, consts, mu, s, gamma, cobs, xobs, L.NT,
-                           flag);
+                           flag, (const double *)nullptr, 0);
         DPGP_LAUNCH_CHECK();
     }
     const int NTb = pg_ring_tiles<KS>();
@@ -852,7 +1064,8 @@ static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *c
 template <int KS>
 static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                               const double *s, const double *gamma, const double *alpha, const double *GP, const float *scale,
-                              unsigned char *ws, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st) {
+                              const float *psi2, unsigned char *ws, double *dmu, double *ds, double *dz, double *dgamma,
+                              hipStream_t st, const double *y, int ldy, const double *Gv) {
     constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
     const PgLayout L = pg_layout(D, N, M, Q);
     const Psi2Consts C = psi2_consts_layout(M, Q);
@@ -862,17 +1075,17 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     _Float16 *cobs = reinterpret_cast<_Float16 *>(ws + L.off_cobs), *xpair = reinterpret_cast<_Float16 *>(ws + L.off_xpair);
     float *r2 = reinterpret_cast<float *>(ws + L.off_r2), *r1 = reinterpret_cast<float *>(ws + L.off_r1);
     double *tp = reinterpret_cast<double *>(ws + L.off_tp), *tt = reinterpret_cast<double *>(ws + L.off_tt);
-    double *dgp = reinterpret_cast<double *>(ws + L.off_dgp), *dmup = reinterpret_cast<double *>(ws + L.off_dmup),
+    double *dmup = reinterpret_cast<double *>(ws + L.off_dmup),
            *dsp = reinterpret_cast<double *>(ws + L.off_dsp);
     const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
     DPGP_PRELAUNCH();
     if (scale)
-        hipLaunchKernelGGL(pg_u_scale_kernel, dim3(D), dim3(256), 0, st, L.Ppad, Mp, reinterpret_cast<const unsigned *>(consts + C.off_pmap),
-                           scale, GP, u, kap);
+        hipLaunchKernelGGL(pg_u_scale_kernel, dim3(D), dim3(256), 0, st, L.Ppad, Mp, Q, reinterpret_cast<const unsigned *>(consts + C.off_pmap),
+                           scale, GP, u, kap, psi2, z, dgamma);
     else
         hipLaunchKernelGGL(pg_u_kernel, dim3(D), dim3(256), 0, st, M, Q, Mp, z, gamma, alpha, GP, u, kap);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(L.Ppad, 256), D), dim3(256), 0, st, M, Q, consts,
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(L.Ppad, 256), D), dim3(256), 0, st, L.Ppad, Q, pimg,
                        (const float *)u, (const float *)kap, xpair);
     DPGP_LAUNCH_CHECK();
     {
@@ -892,25 +1105,80 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
         DPGP_LAUNCH_CHECK();
     }
     const int dcp = dpgp_ceil_div(D, PG_DC_PAIRS), ncp = dpgp_ceil_div(D, dcp);
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_finish_pairs_kernel<NF>), dim3(dpgp_ceil_div(L.P, 256), ncp), dim3(256), 0, st, M, Q, D, L.Ppad, dcp, gamma,
-                       (const float *)u, (const float *)r2, tp);
+    DPGP_PRELAUNCH();
+    PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_pairs_kernel<NF, QP_>), dim3(dpgp_ceil_div(L.P, 256), ncp), dim3(256), 0, st, M, Q, D, L.Ppad, dcp,
+                                       gamma, (const float *)u, (const float *)r2, tp));
     DPGP_LAUNCH_CHECK();
     const size_t n3 = (size_t)3 * L.P * Q;
     int rc = launch_reduce_rows<double>(n3, n3, ncp, tp, tt, 0, nullptr, st);
     if (rc != DPGP_OK) return rc;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_gather_dz_kernel, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, z, consts, (const double *)tt, dz);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_dgamma_pairs_kernel<NF>), dim3(D), dim3(256), 0, st, M, Q, L.Ppad, z, (const float *)u, (const float *)r2,
-                       dgamma);
-    DPGP_LAUNCH_CHECK();
+    if (!(scale && psi2)) {          // (training step: formed by pg_u_scale_kernel from Psi2 itself)
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_dgamma_pairs_kernel<NF>), dim3(D), dim3(256), 0, st, M, Q, L.Ppad, z, (const float *)u,
+                           (const float *)r2, dgamma);
+        DPGP_LAUNCH_CHECK();
+    }
+    // ---- the Psi1 term (y != nullptr) through the same pass kernel, on the diagonal pairs: its own observation images (den = g s + 1,
+    // half coefficients, features weighted by y_nd), the pair image's diagonal rows, features alpha_d g_v[d][m] (s^2 / 64, s, 1)
+    float *r1p = reinterpret_cast<float *>(ws + L.off_r1p), *kap1 = reinterpret_cast<float *>(ws + L.off_kap1);
+    if (y) {
+        _Float16 *cobs1 = reinterpret_cast<_Float16 *>(ws + L.off_cobs1), *xobs1 = reinterpret_cast<_Float16 *>(ws + L.off_xobs1),
+                 *dimg = reinterpret_cast<_Float16 *>(ws + L.off_dimg), *xm1 = reinterpret_cast<_Float16 *>(ws + L.off_xm1);
+        float *r2p = reinterpret_cast<float *>(ws + L.off_r2p), *u1 = reinterpret_cast<float *>(ws + L.off_u1);
+        const int Mpad = 32 * L.MT;
+        {
+            const size_t lds = 256 + sizeof(unsigned) * 256 * (8 * KS + 4) + sizeof(_Float16) * 8 * 2048 * NFB;
+            auto kern = pg_obs_images_kernel<KS>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return DPGP_ERR_LAUNCH;
+            DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(dpgp_ceil_div(N, 256), D), dim3(256), lds, st, N, Q, consts, mu, s, gamma, cobs1, xobs1,
+                               L.NT, flag, y, ldy);
+            DPGP_LAUNCH_CHECK();
+        }
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_diag_image_kernel<KS>), dim3(dpgp_ceil_div(Mpad * KS * 2, 256)), dim3(256), 0, st, M, Mpad, pimg, dimg);
+        DPGP_LAUNCH_CHECK();
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_u1_kernel, dim3(D), dim3(64), 0, st, M, Mp, Mpad, alpha, Gv, u1, kap1);
+        DPGP_LAUNCH_CHECK();
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(Mpad, 256), D), dim3(256), 0, st, Mpad, Q,
+                           (const _Float16 *)dimg, (const float *)u1, (const float *)kap1, xm1);
+        DPGP_LAUNCH_CHECK();
+        const int NTb = pg_ring_tiles<KS>();
+        const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
+        auto kern = pg_pass_kernel<KS>;
+        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        // rows: the inducing points (dimg, features xm1 of output dim d); columns: the observations of output dim d -> R1' [d][n][.]
+        int groups = dpgp_ceil_div(L.NT, NW * G);
+        DPGP_PRELAUNCH();
+        hipLaunchKernelGGL(kern, dim3((unsigned)(D * groups)), dim3(64 * NW), lds, st, (const _Float16 *)dimg, 0, (const _Float16 *)xm1,
+                           (const _Float16 *)cobs1, 1, r1p, L.MT, L.NT, groups, NTb, po);
+        DPGP_LAUNCH_CHECK();
+        // rows: the observations of output dim d (cobs1, y-weighted features xobs1); columns: the inducing points -> R2' [d][m][.]
+        groups = dpgp_ceil_div(L.MT, NW * G);
+        DPGP_PRELAUNCH();
+        hipLaunchKernelGGL(kern, dim3((unsigned)(D * groups)), dim3(64 * NW), lds, st, (const _Float16 *)cobs1, 1, (const _Float16 *)xobs1,
+                           (const _Float16 *)dimg, 0, r2p, L.NT, L.MT, groups, NTb, po);
+        DPGP_LAUNCH_CHECK();
+        DPGP_PRELAUNCH();
+        PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_m1_kernel<NF, QP_>), dim3(M), dim3(256), 0, st, M, Mpad, Q, D, z, consts, (const float *)u1,
+                                           (const float *)r2p, dz));
+        DPGP_LAUNCH_CHECK();
+    }
     const int dco = dpgp_ceil_div(D, PG_DC_OBS), nco = dpgp_ceil_div(D, dco);
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_finish_obs_kernel<NF>), dim3(L.nblk_obs, nco), dim3(256), 0, st, N, Q, D, L.NT, dco, consts, mu, s, gamma,
-                       (const float *)kap, (const float *)r1, dmup, dsp, dgp);
+    const float *r1p_ = y ? (const float *)r1p : (const float *)nullptr;
+    DPGP_PRELAUNCH();
+    PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_obs_n_kernel<NF, QP_>), dim3(L.nblk_obs, nco), dim3(256), 0, st, N, Q, D, L.NT, dco, consts, mu, s,
+                                       gamma, (const float *)kap, (const float *)r1, (const float *)kap1, r1p_, y, ldy, dmup, dsp));
     DPGP_LAUNCH_CHECK();
-    const size_t dq = (size_t)D * Q, nq = (size_t)N * Q;
-    rc = launch_reduce_rows<double>(dq, dq, L.nblk_obs, dgp, dgamma, 1, nullptr, st);
-    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dmup, dmu, 1, nullptr, st);
-    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dsp, ds, 1, nullptr, st);
+    DPGP_PRELAUNCH();
+    PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_obs_d_kernel<NF, QP_>), dim3(D), dim3(256), 0, st, N, Q, L.NT, consts, mu, s, gamma,
+                                       (const float *)kap, (const float *)r1, (const float *)kap1, r1p_, y, ldy, dgamma));
+    DPGP_LAUNCH_CHECK();
+    const size_t nq = (size_t)N * Q;
+    rc = DPGP_OK;
+    // (with the Psi1 term in the sweep nothing has written dmu, ds before: overwrite; otherwise launch_psi1_grad has: add)
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dmup, dmu, y ? 0 : 1, nullptr, st);
+    if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dsp, ds, y ? 0 : 1, nullptr, st);
     if (rc != DPGP_OK) return rc;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_poison_kernel, dim3(1), dim3(1), 0, st, (const int *)flag, dmu, ds, dz, dgamma);
     DPGP_LAUNCH_CHECK();
@@ -922,10 +1190,12 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
 // A range-guard hit (see psi2_pairs.hip) poisons the outputs with NaN (the caller's trouble flag sees it).
 // which: 1 = part 1 only (images of the observations, pass 1; with psi2_part / scale also Psi2 into slab 0 of the forward's
 // partial slabs), 2 = part 2 only (after part 1 on the same ws), 3 = both.
+// y != nullptr (with Gv [D][Mp] = d f_hat / d (Psi1^T y)): the Psi1 term as well, through the same pass kernel; dmu and ds are then
+// OVERWRITTEN (nothing else has written them), dz and dgamma added to.
 int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
                       double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st, int which,
-                      float *psi2_part, const float *scale) {
+                      float *psi2_part, const float *scale, const double *y, int ldy, const double *Gv) {
     if (!psi2_pgrad_supported(M, Q)) return -4;
     (void)stage;
     int rc = DPGP_OK;
@@ -934,7 +1204,8 @@ int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, c
     case k:                                                                                                                      \
         if (which & 1) rc = launch_pgrad_part1<k>(D, N, M, Q, consts, mu, s, gamma, ws, psi2_part, scale, st);                  \
         if (rc == DPGP_OK && (which & 2))                                                                                        \
-            rc = launch_pgrad_part2<k>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, scale, ws, dmu, ds, dz, dgamma, st);    \
+            rc = launch_pgrad_part2<k>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, scale, (which & 1) ? nullptr : psi2_part, ws, dmu, ds, \
+                                       dz, dgamma, st, y, ldy, Gv);                                                              \
         return rc;
         CASE(2) CASE(4) CASE(6) CASE(8)
 #undef CASE
