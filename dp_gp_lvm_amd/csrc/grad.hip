@@ -876,8 +876,15 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
         DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)ds_part, ds);
         DPGP_LAUNCH_CHECK();
     }
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((mq + 255) / 256)), dim3(256), 0, st, mq, D * ns, (const double *)dz_part, dz);
-    DPGP_LAUNCH_CHECK();
+    if (!do_psi2 && (size_t)D * N >= (size_t)64 * M) {
+        // K_uu term only: M Q sums over D rows — side by side in 64 chunks through the (unused) dmu partial region instead of
+        // five workgroups walking 512 rows each (69 -> ~10 us at D = 512)
+        const int rc = launch_reduce_rows<double>(mq, mq, D * ns, dz_part, dz, 0, dmu_part, st);
+        if (rc != DPGP_OK) return rc;
+    } else {
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((mq + 255) / 256)), dim3(256), 0, st, mq, D * ns, (const double *)dz_part, dz);
+        DPGP_LAUNCH_CHECK();
+    }
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, dq, ns, (const double *)dg_part, dgamma);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
