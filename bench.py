@@ -156,13 +156,14 @@ def secondary(dev, shape, p):
         fl = bb * mm ** 3 / 3.0
         out[key] = {'kernel_ms': ms, 'flops': fl, 'tflops': fl / ms / 1e9, 'peak_tflops': 78.6, 'frac': fl / ms / 1e9 / 78.6,
                     'what': 'dpgp_potrf_batched_f64 B=%d M=%d (M^3/3 flops each), copy of the input subtracted' % (bb, mm)}
-    # counter-derived figures of the same workloads (scratch/prof_r03.sh: WRITE_SIZE / FETCH_SIZE in separate --pmc passes,
+    # counter-derived figures of the same workloads (scratch/prof_r04.sh: WRITE_SIZE / FETCH_SIZE in separate --pmc passes,
     # SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 flops, kernel-trace durations), committed with the build they were taken on
     try:
-        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03', 'linalg_pmc.json')))
-        sha = open(os.path.join(REPO, 'profiles', 'r03', 'GIT_SHA_OF_PROFILED_BUILD.txt')).read().split()[0]
+        rnd = 'r04' if os.path.exists(os.path.join(REPO, 'profiles', 'r04', 'linalg_pmc.json')) else 'r03'
+        pmc = json.load(open(os.path.join(REPO, 'profiles', rnd, 'linalg_pmc.json')))
+        sha = open(os.path.join(REPO, 'profiles', rnd, 'GIT_SHA_OF_PROFILED_BUILD.txt')).read().split()[0]
         pick = lambda k: {a: b for a, b in pmc[k].items() if a != 'counters'} if k in pmc else None
-        out['rocprof'] = {'source': 'profiles/r03/linalg_pmc.json @ ' + sha,
+        out['rocprof'] = {'source': 'profiles/%s/linalg_pmc.json @ ' % rnd + sha,
                           'gram_kuu': pick('void gram_kernel<double, double>'), 'gram_large': pick('void gram_kernel<float, float>'),
                           'cholesky_m128_b512': pick('void potrf_batched_lds_kernel<double>'),
                           'cholesky_m512_b256': pick('pleft_persistent_kernel') or pick('pbig_persistent_kernel')}
@@ -182,10 +183,12 @@ def git_sha():
 def profiled_traffic(cfg, prec, world):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): read from
-    profiles/r03/traffic.json (r02 as fall-back), which records the build it was measured on; null when this configuration was not profiled."""
-    path = os.path.join(REPO, 'profiles', 'r03', 'traffic.json')
-    if not os.path.exists(path):
-        path = os.path.join(REPO, 'profiles', 'r02', 'traffic.json')
+    profiles/r04/traffic.json (older rounds as fall-back), which records the build it was measured on; null when this configuration
+    was not profiled."""
+    path = os.path.join(REPO, 'profiles', 'r04', 'traffic.json')
+    for older in ('r03', 'r02'):
+        if not os.path.exists(path):
+            path = os.path.join(REPO, 'profiles', older, 'traffic.json')
     if world != 1 or not os.path.exists(path):
         return None, None
     try:
@@ -265,10 +268,11 @@ def main():
     # One step = one evaluation from the device-resident raw parameters to the objective IN HOST MEMORY: the scalar is copied
     # to a pinned host buffer on the stream in every step (no host synchronisation per step; one at the end of the region).
     # Launch mode: eager kernel launches, or (--graph on; default when D is sharded) the evaluation replayed from a HIP graph.
-    # HIP events around the psi2 kernel on every EV_EVERY-th step only (each recorded event costs ~6 us of stream time);
+    # HIP events around the psi2 kernel on every EV_EVERY-th step only (each recorded event costs ~6 us of stream time; a 20-step
+    # run has five samples);
     # those steps are always eager launches.
     use_graph = (a.graph == 'on')          # ('auto' = eager: measured, the graph replay is no faster at D = 64 per GPU and slower at D = 512)
-    EV_EVERY = 8
+    EV_EVERY = 4
     ev = {i: (lib.dpgp_event_create(), lib.dpgp_event_create()) for i in range(0, a.steps, EV_EVERY)}
 
     def barrier():
@@ -378,6 +382,11 @@ def main():
             v64, o64 = rate(m64, ks)
             res['value_fp32_exact'] = v32
             res['value_f64'] = v64
+            # `value` is measured with precision='mixed' (bench.py's --prec default); a model built WITHOUT a precision argument
+            # runs the reference's arithmetic: fp64 forward (and fp64 dense adjoints + the matrix-pipe stage B in its gradients)
+            res['default_constructed_model'] = {'precision': 'f64', 'backward_precision': 'mixed', 'value': v64,
+                                                'unit': 'ELBO evals/s', 'note': 'dp_gp_lvm(...) with no precision argument; '
+                                                'the headline `value` needs precision="mixed"'}
             res['precision_check'] = {'objective_mixed': float(objs[0]), 'objective_fp32_exact': o32, 'objective_f64': o64,
                                       'rel_err_mixed_vs_f64': abs(float(objs[0]) - o64) / abs(o64),
                                       'rel_err_fp32_exact_vs_f64': abs(o32 - o64) / abs(o64)}
@@ -396,13 +405,17 @@ def main():
                 return 1e3 * (time.perf_counter() - t1) / reps
             reps = 10
             res['objective_and_gradients'] = {'ms': grad_ms(model, reps), 'reps': reps,
-                                              'note': 'stage B of the backward pass on the matrix pipe in mixed precision: '
-                                                      'Psi2 term in the pair-tile form (psi2_pairs_grad.hip, Q <= 10; patch form '
-                                                      'psi2_grad_kernel otherwise and behind an fp64 forward pass), plain kernel '
+                                              'note': 'one training step: dpgp_elbo_step where it applies (mixed, M <= 128, Q <= 20: Psi2 out '
+                                                      'of the first pass of stage B, stage A, stage B incl. the Psi1 term through the same '
+                                                      'pass kernel) + dpgp_model_backward; otherwise forward + stage A + stage B as separate '
+                                                      'calls (patch form of the Psi2 term for Q > 20 and behind an fp64 forward); plain kernel '
                                                       'in f64; DESIGN.md 7.1'}
-            # breakdown of one more iteration (torch events on the launch stream): forward, stage A, stage B, chain rule; and
-            # the exponential rate of stage B (its Psi2 term evaluates the FULL M x M square of every (d, n))
+            # breakdown of one more iteration THROUGH THE SEPARATE CALLS (torch events on the launch stream): forward, stage A,
+            # stage B, chain rule — the one-call step above has no stage boundaries to put events on and saves the forward's psi2
+            # dispatch (so ms < the sum below); and the exponential rate of stage B over its two passes
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            model.gradients(events=evs[:4])                      # (warm-up of the separate-call path)
+            torch.cuda.synchronize()
             evs[4].record()
             model.gradients(events=evs[:4])
             torch.cuda.synchronize()
@@ -411,10 +424,10 @@ def main():
             # exponentials of the Psi2 term: two passes over the M (M + 1) / 2 pairs (pair-tile form), or the full square of
             # 64 x 64 patches (patch form)
             mp64 = 64 * ((m + 63) // 64)
-            pair_form = a.prec == 'mixed' and q <= 10
+            pair_form = a.prec == 'mixed' and q <= 20
             exps_b = float(n) * (d_hi - d_lo) * (2.0 * (m * (m + 1) // 2) if pair_form else mp64 * mp64)
             res['objective_and_gradients'].update({
-                'forward_ms': t_fwd, 'stage_a_ms': t_a, 'stage_b_ms': t_b, 'chain_rule_ms': t_c,
+                'separate_calls': {'forward_ms': t_fwd, 'stage_a_ms': t_a, 'stage_b_ms': t_b, 'chain_rule_ms': t_c},
                 'stage_b_exp_per_s': exps_b / (t_b * 1e-3), 'stage_b_exp_frac_of_v_exp_rate': exps_b / (t_b * 1e-3) / exp_peak})
             if a.prec == 'mixed' and m <= 128:
                 # the training configuration that follows the reference's fp64 arithmetic through an Adam run (DESIGN.md

@@ -442,9 +442,11 @@ template <int KS, int NFB> struct PgSched {
         const int i = (u - 6) / 5 + 1, r = (u - 6) % 5;
         return r < 2 ? PgUnit{0, 2 * (i + 1) + r} : (r == 4 ? PgUnit{3, i - 1} : PgUnit{r - 1, i});
     }
-    static constexpr int cost(int u) { return (unit(u).kind & 1) ? 4 : 8; }    // issue cycles (MI355X guide; v_fma_mixlo/hi_f16 would
-    static constexpr int cum(int u) { int c = 0; for (int k = 0; k < u; ++k) c += cost(k); return c; }   // save the second conversion but cost 8-9 each: measured)
     static constexpr int U_D3 = 25;                               // unit D_3: behind it the words 0-3 are complete
+    // issue cycles (MI355X guide).  (v_fma_mixlo_f16 + v_fma_mixhi_f16 into one register would save the second conversion: measured
+    // slower, adjacent (the second waits for the first) as well as spaced apart (the compiler pads each asm statement))
+    static constexpr int cost(int u) { return (unit(u).kind & 1) ? 4 : 8; }
+    static constexpr int cum(int u) { int c = 0; for (int k = 0; k < u; ++k) c += cost(k); return c; }
     static_assert(unit(U_D3).kind == 3 && unit(U_D3).i == 3, "unit table");
     // the first J0 slots hold the KS-step exponent chain of the next step (NE1 of its instructions) and the NK products of the
     // previous step's K-step-1 half; the others the products of this step's K-step-0 half, which need the words 0-3
