@@ -823,8 +823,8 @@ def dp_gp_lvm_t(y_train,
             return _finish_fused().clone()
         return _exchange(graph['out'].clone())              # (the all-reduce of a sharded model runs eagerly behind the replay)
 
-    def _gradients():
-        """d objective / d raw variable for all raw variables: torch autograd around the library-backed f_hat (above)."""
+    def _local_flat():
+        """This rank's packed gradient (all raw variables, then the trouble flag) — everything in front of the exchange."""
         leaves = {k: v.detach().clone().requires_grad_(True) for k, v in raw_vars.items()}
         terms = _objective_of(leaves)
         # sharded: this rank's share of the objective = -(local f_hat) + (replicated terms) / world; the shares sum to it
@@ -834,11 +834,38 @@ def dp_gp_lvm_t(y_train,
         flat = torch.cat([g.reshape(-1) for g in grads] + [torch.zeros(1, dtype=TORCH_DTYPE, device=device)])
         # trouble flag (failed factorisation / non-finite local gradient), reduced with the gradients: a collective decision
         flat[-1] = ((last_info[0] != 0) | ~torch.isfinite(flat[:-1]).all()).to(TORCH_DTYPE)
+        return flat
+
+    grad_graph = {}
+
+    def _gradients(graph=None):
+        """d objective / d raw variable for all raw variables: torch autograd around the library-backed f_hat (above).
+        graph=True (the default of optimise(); DPGP_GRAPH_T=0 turns it off): the local part — ~250 launches of library operators,
+        element-wise kernels and their autograd, host-bound at ~4.6 ms per call whatever the problem size — is captured ONCE into a
+        HIP graph (torch.cuda.CUDAGraph) and replayed; the raw variables are read in place, so optimiser updates are seen."""
+        use_graph = bool(graph) and os.environ.get('DPGP_GRAPH_T', '1') != '0'
+        if use_graph:
+            if 'g' not in grad_graph:
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        _local_flat()
+                cur.wait_stream(side)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    grad_graph['flat'] = _local_flat()
+                grad_graph['g'] = g_
+            grad_graph['g'].replay()
+            flat = grad_graph['flat'].clone()
+        else:
+            flat = _local_flat()
         if sharded:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)       # ONE packed exchange
         grad_flag[0] = flat[-1]
         out, o = {}, 0
-        for (k, v) in leaves.items():
+        for (k, v) in raw_vars.items():
             out[k] = flat[o:o + v.numel()].reshape(v.shape)
             o += v.numel()
         return out
@@ -849,7 +876,7 @@ def dp_gp_lvm_t(y_train,
         """Adam on the raw variables (the reference: tf.train.AdamOptimizer(...).minimize(objective))."""
         opt = torch.optim.Adam(list(raw_vars.values()), lr=learning_rate)
         for it in range(num_iterations):
-            g = _gradients()
+            g = _gradients(graph=True)
             # potrf replaces a failing pivot by 1 and goes on: a failed factorisation would give finite, meaningless
             # gradients.  The reference's tf.cholesky raises; so does this.
             bad = (grad_flag[0] != 0) | ~torch.stack([torch.isfinite(v).all() for v in g.values()]).all()
