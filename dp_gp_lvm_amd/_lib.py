@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('DPGP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libdpg
 
 FLAG_NOISE, FLAG_JITTER = 1, 2
 ALGO = {'auto': 0, 'plain': 1, 'mfma_f32': 2, 'patch_f16': 3}
-PREC = {'f32': 0, 'mixed': 1, 'f64': 2, 'mixed_patch': 3}
+PREC = {'f32': 0, 'mixed': 1, 'f64': 2, 'mixed_patch': 3, 'mixed_fast': 4}
 
 _vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
 _ll = ctypes.c_longlong
@@ -38,7 +38,7 @@ SIGNATURES = {
     'dpgp_elbo_grad_chain': (_i, [_i, _i, _i, _i, _vp, _vp, _d, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dpgp_elbo_grad_psi_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'dpgp_elbo_grad_psi_workspace_bytes_ex': (_sz, [_i, _i, _i, _i, _i]),
-    'dpgp_elbo_step': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp,
+    'dpgp_elbo_step': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp,
                             _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dpgp_elbo_grad_psi': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp,
                                 _vp, _vp]),

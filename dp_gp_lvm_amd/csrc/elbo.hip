@@ -186,7 +186,7 @@ static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, 
                           const double *gamma, const double *alpha, const double *g_psi2, const double *w_kuu, const double *g_v,
                           const double *g_psi1, bool patch_form, unsigned char *ws, double *d_mu, double *d_s, double *d_z,
                           double *d_gamma, hipStream_t st, const unsigned char *fwd_consts, const float *fwd_scale,
-                          const float *fwd_psi2 = nullptr) {
+                          const float *fwd_psi2 = nullptr, int w11 = 0) {
     // K_uu term by the plain kernel (no pass over the observations), Psi1 by the reduction-free kernels, Psi2 (nearly all
     // of the work) on the matrix pipe -- where those apply; otherwise everything by the plain kernel
     const bool fast = psi2_grad_supported(M, Q) && !getenv("DPGP_GRAD_PLAIN");
@@ -217,7 +217,7 @@ static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, 
     if (pair_form)
         return launch_psi2_pgrad(D, N, M, Q, consts, z, mu, s, gamma, alpha, g_psi2, W.pgws, W.stage, d_mu, d_s, d_z, d_gamma, st,
                                  fwd_consts ? 2 : 3, const_cast<float *>(fwd_psi2), fwd_scale, psi1_pairs ? y : nullptr, ldy,
-                                 psi1_pairs ? g_v : nullptr);
+                                 psi1_pairs ? g_v : nullptr, w11);
     if (fwd_consts) return -30;
     return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, W.part, W.stage, d_mu, d_s, d_z, d_gamma, st);
 }
@@ -270,8 +270,8 @@ extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y
     if (!g_psi2) return -12;
     if (!w_kuu) return -13;
     if (!g_v && !g_psi1) return -14;
-    const bool patch_form = (prec == DPGP_PREC_MIXED_PATCH);
-    if (patch_form) prec = DPGP_PREC_MIXED;
+    const bool patch_form = (prec == DPGP_PREC_MIXED_PATCH), fast = (prec == DPGP_PREC_MIXED_FAST);
+    if (patch_form || fast) prec = DPGP_PREC_MIXED;
     if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_F64) return -15;
     if (g_psi1 && (prec != DPGP_PREC_MIXED || !psi2_grad_supported(M, Q))) return -15;
     if (!ws) return -16;
@@ -282,7 +282,7 @@ extern "C" int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y
     if (!d_gamma) return -21;
     if (prec == DPGP_PREC_MIXED)
         return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, g_psi1, patch_form, (unsigned char *)ws,
-                              d_mu, d_s, d_z, d_gamma, (hipStream_t)stream, nullptr, nullptr);
+                              d_mu, d_s, d_z, d_gamma, (hipStream_t)stream, nullptr, nullptr, nullptr, fast ? 1 : 0);
     if (dpgp_round_up(M, 16) > 128) return -30;
     return launch_psi_grad<double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, (double *)ws, d_mu, d_s,
                                    d_z, d_gamma, 1, (hipStream_t)stream);
@@ -343,7 +343,7 @@ extern "C" int dpgp_elbo_fhat(int D, int N, int M, int Q, const double *y, int l
 // adjoints, holds the constant 1 among its features and therefore yields Psi2 itself — the forward's psi2 dispatch is dropped.
 extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                               const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
-                              double *terms, double *sums, int *info, void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu,
+                              int prec, double *terms, double *sums, int *info, void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu,
                               double *g_v, double *d_alpha_beta, int *info_grad, void *gws, size_t gws_bytes, double *d_mu,
                               double *d_s, double *d_z, double *d_gamma, void *stream, const dpgp_exec_t *exec) {
     if (D <= 0) return -1;
@@ -359,23 +359,24 @@ extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int l
     if (!alpha) return -11;
     if (!beta) return -12;
     if (!(jitter >= 0.0)) return -13;
-    if (!terms) return -14;
-    if (!sums) return -15;
-    if (!info) return -16;
-    if (!ws) return -17;
+    if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_MIXED_FAST) return -14;
+    if (!terms) return -15;
+    if (!sums) return -16;
+    if (!info) return -17;
+    if (!ws) return -18;
     const ElboLayout L = elbo_layout(D, N, M, Q, DPGP_PREC_MIXED);
-    if (ws_bytes < L.total) return -18;
-    if (!g_psi2) return -19;
-    if (!w_kuu) return -20;
-    if (!g_v) return -21;
-    if (!d_alpha_beta) return -22;
-    if (!info_grad) return -23;
-    if (!gws) return -24;
-    if (gws_bytes < dpgp_elbo_grad_psi_workspace_bytes(D, N, M, Q)) return -25;
-    if (!d_mu) return -26;
-    if (!d_s) return -27;
-    if (!d_z) return -28;
-    if (!d_gamma) return -29;
+    if (ws_bytes < L.total) return -19;
+    if (!g_psi2) return -20;
+    if (!w_kuu) return -21;
+    if (!g_v) return -22;
+    if (!d_alpha_beta) return -23;
+    if (!info_grad) return -24;
+    if (!gws) return -25;
+    if (gws_bytes < dpgp_elbo_grad_psi_workspace_bytes(D, N, M, Q)) return -26;
+    if (!d_mu) return -27;
+    if (!d_s) return -28;
+    if (!d_z) return -29;
+    if (!d_gamma) return -30;
     hipStream_t st = (hipStream_t)stream;
     unsigned char *w = (unsigned char *)ws;
     const GradPsiWs W = grad_psi_ws(D, N, M, Q, (unsigned char *)gws);
@@ -390,7 +391,7 @@ extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int l
     if (rc != DPGP_OK) return rc;
     return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, nullptr, false, (unsigned char *)gws, d_mu,
                           d_s, d_z, d_gamma, st, w + L.off_pc, reinterpret_cast<const float *>(w + L.off_sc),
-                          reinterpret_cast<const float *>(w + L.off_p2));
+                          reinterpret_cast<const float *>(w + L.off_p2), prec == DPGP_PREC_MIXED_FAST ? 1 : 0);
 }
 
 // ---- f_hat of the over-T model (dp_gp_lvm_t, reference dp_gp_lvm.py:608-676): the T atoms play the part of the output dims in

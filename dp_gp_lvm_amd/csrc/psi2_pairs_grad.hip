@@ -30,9 +30,6 @@ typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 #define PG_HDR 512
 #define PG_WSHIFT 12.0f              // the exponent tiles carry + PG_WSHIFT: W = 2^12 exp2(E) <= 4096 uses the f16 range downwards
                                      // (f16 pairs resolve W / max W down to ~2^-36 instead of 2^-24); undone in the finishing kernels
-#ifndef PG_WLO
-#define PG_WLO 1                     // 0 (diagnostic builds only): no lo half of the exponentials (11-bit W in the second product)
-#endif
 #define PG_FB 32                     // feature rows of one block of the second product (one 32-row matrix instruction)
 
 // Kernel configuration by the K-steps of the exponent product (KS = psi2_pairs_ksteps(Q)):
@@ -428,13 +425,27 @@ struct PgPsi2Out {                    // Psi2 as a by-product of pass 1 (see the
 };
 struct PgSlot { int kind, i; };      // kind 0: exponent chain K-step i; 1: product i of the previous step's K-step-1 half; 2: of this step's K-step-0 half
 struct PgUnit { int kind, i; };      // kind 0: v_exp_f32 of element i; 1: v_cvt_pk_f16_f32 (hi) of element pair i; 2: the two v_fma_mix_f32 (e - hi) of pair i; 3: v_cvt_pk_f16_f32 (lo)
-template <int KS, int NFB> struct PgSched {
+// WLO = false (DPGP_PREC_MIXED_FAST): the exponentials enter the second product as their f16 roundings alone — no residuals, no lo
+// words, no (X_hi, W_lo) products: 24 vector units and KS + 4 NFB matrix instructions per step.
+template <int KS, int NFB, bool WLO> struct PgSched;
+template <int KS, int NFB> struct PgSchedUnits1 {
+    //   E0 E1 | (E_{2i+2} E_{2i+3} C_i) for i = 0 .. 6 | C7
+    static constexpr int NU = 24, CYC = 160, U_D3 = 13, NPR = 2;
+    static constexpr PgUnit unit(int u) {
+        if (u < 2) return PgUnit{0, u};
+        if (u == 23) return PgUnit{1, 7};
+        const int i = (u - 2) / 3, r = (u - 2) % 3;
+        return r < 2 ? PgUnit{0, 2 * (i + 1) + r} : PgUnit{1, i};
+    }
+    static constexpr int done_kind = 1;
+};
+template <int KS, int NFB> struct PgSchedUnits2 {
     // vector units of a step, in order (E: exponential, C: hi words, L: the two residuals, D: lo words)
     //   E0 E1 | E2 E3 C0 L0 | (E_{2i+2} E_{2i+3} C_i L_i D_{i-1}) for i = 1 .. 6 | C7 L7 D6 D7
     // the exponentials of pair i + 1 sit between those of pair i and their conversion (no wait state behind a transcendental), and
     // the lo conversion of a pair follows the NEXT pair's residuals (the compiler pads an asm statement whose result is read by
     // the very next instruction with an s_nop)
-    static constexpr int NU = 40, CYC = 256, NM = KS + 6 * NFB, NK = 3 * NFB;
+    static constexpr int NU = 40, CYC = 256, U_D3 = 25, NPR = 3;  // (U_D3: unit D_3: behind it the words 0-3 are complete)
     static constexpr PgUnit unit(int u) {
         if (u < 2) return PgUnit{0, u};
         if (u < 6) return u < 4 ? PgUnit{0, u} : PgUnit{u - 3, 0};
@@ -442,12 +453,17 @@ template <int KS, int NFB> struct PgSched {
         const int i = (u - 6) / 5 + 1, r = (u - 6) % 5;
         return r < 2 ? PgUnit{0, 2 * (i + 1) + r} : (r == 4 ? PgUnit{3, i - 1} : PgUnit{r - 1, i});
     }
-    static constexpr int U_D3 = 25;                               // unit D_3: behind it the words 0-3 are complete
+    static constexpr int done_kind = 3;
+};
+template <int KS, int NFB, bool WLO> struct PgSched : std::conditional<WLO, PgSchedUnits2<KS, NFB>, PgSchedUnits1<KS, NFB>>::type {
+    typedef typename std::conditional<WLO, PgSchedUnits2<KS, NFB>, PgSchedUnits1<KS, NFB>>::type U;
+    using U::NU; using U::CYC; using U::U_D3; using U::NPR; using U::unit;
+    static constexpr int NM = KS + 2 * NPR * NFB, NK = NPR * NFB;
     // issue cycles (MI355X guide).  (v_fma_mixlo_f16 + v_fma_mixhi_f16 into one register would save the second conversion: measured
     // slower, adjacent (the second waits for the first) as well as spaced apart (the compiler pads each asm statement))
     static constexpr int cost(int u) { return (unit(u).kind & 1) ? 4 : 8; }
     static constexpr int cum(int u) { int c = 0; for (int k = 0; k < u; ++k) c += cost(k); return c; }
-    static_assert(unit(U_D3).kind == 3 && unit(U_D3).i == 3, "unit table");
+    static_assert(unit(U_D3).kind == U::done_kind && unit(U_D3).i == 3, "unit table");
     // the first J0 slots hold the KS-step exponent chain of the next step (NE1 of its instructions) and the NK products of the
     // previous step's K-step-1 half; the others the products of this step's K-step-0 half, which need the words 0-3
     static constexpr int J0raw = (cum(U_D3 + 1) * NM + CYC - 1) / CYC;
@@ -491,12 +507,12 @@ __device__ __forceinline__ pg_h8 pg_quad(unsigned a, unsigned b, unsigned c, uns
 // acc_p / x1h, x1l / (wh1, wl1): accumulators, K-step-1 feature operands and K-step-1 words of the PREVIOUS step (wh1, wl1 are
 // replaced by this step's on return); acc_c / x0h, x0l: this step's accumulators and K-step-0 feature operands.
 // hook(j): called behind matrix slot j (the caller's LDS reads ride there).
-template <int KS, int NFB, typename HOOK>
+template <int KS, int NFB, bool WLO, typename HOOK>
 __device__ __forceinline__ void pg_step(pg_f16v &c_nxt, const pg_f16v &c_cur, const pg_h8 (&a_n)[KS], const pg_h8 (&b_n)[KS],
                                         pg_f16v (&acc_p)[NFB], pg_f16v (&acc_c)[NFB], const pg_h8 (&x0h)[NFB],
                                         const pg_h8 (&x0l)[NFB], const pg_h8 (&x1h)[NFB], const pg_h8 (&x1l)[NFB], pg_h8 &wh1,
                                         pg_h8 &wl1, HOOK &&hook) {
-    typedef PgSched<KS, NFB> S;
+    typedef PgSched<KS, NFB, WLO> S;
     float ex[16];
     unsigned hw[8], lw[8];
     const pg_h8 wh1p = wh1, wl1p = wl1;
@@ -511,8 +527,9 @@ __device__ __forceinline__ void pg_step(pg_f16v &c_nxt, const pg_f16v &c_cur, co
             } else {
                 c_nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_n[sl.i], b_n[sl.i], c_nxt, 0, 0, 0);
             }
-        } else if constexpr (PG_WLO || sl.i / NFB != 1) {
-            constexpr int fb = sl.i % NFB, pr = sl.i / NFB;       // products (X_hi, W_hi), (X_hi, W_lo), (X_lo, W_hi), blocks interleaved
+        } else {
+            // products (X_hi, W_hi), (X_hi, W_lo), (X_lo, W_hi) [WLO] or (X_hi, W_hi), (X_lo, W_hi), blocks interleaved
+            constexpr int fb = sl.i % NFB, pr = WLO ? sl.i / NFB : 2 * (sl.i / NFB);
             if constexpr (sl.kind == 1)
                 acc_p[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? x1l[fb] : x1h[fb], pr == 1 ? wl1p : wh1p, acc_p[fb], 0, 0, 0);
             else
@@ -534,7 +551,6 @@ __device__ __forceinline__ void pg_step(pg_f16v &c_nxt, const pg_f16v &c_cur, co
             const pg_h2 hi = {(_Float16)ex[2 * i], (_Float16)ex[2 * i + 1]};
             hw[i] = __builtin_bit_cast(unsigned, hi);
             if constexpr (i == 3) wh0 = pg_quad(hw[0], hw[1], hw[2], hw[3]);
-        } else if constexpr (!PG_WLO) {
         } else if constexpr (un.kind == 2) {
             // e - hi in place, from the f16 halves (one instruction each instead of v_cvt_f32_f16 + v_sub_f32).  The registers were
             // written by the compiler-visible v_exp_f32 just before, so the hazard recognizer (which does not see inside asm) has
@@ -555,7 +571,7 @@ __device__ __forceinline__ void pg_step(pg_f16v &c_nxt, const pg_f16v &c_cur, co
     wl1 = pg_quad(lw[4], lw[5], lw[6], lw[7]);
 }
 
-template <int KS>
+template <int KS, bool WLO>
 __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
                                                                    const _Float16 *__restrict__ ximg,
                                                                    const _Float16 *__restrict__ cimg, int col_per_d,
@@ -563,7 +579,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
                                                                    int groups_per_d, int NTb, PgPsi2Out po) {
     constexpr int NFB = PgCfg<KS>::NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW, NF = PG_FB * NFB;
     constexpr int PIECES = KS + 4 * NFB, TILE_BYTES = 1024 * PIECES;   // LDS bytes of one row tile: K-steps of the exponent operand, then the features
-    typedef PgSched<KS, NFB> S;
+    typedef PgSched<KS, NFB, WLO> S;
     constexpr int LA = G == 1 ? 2 : 1;                         // row tiles between an LDS read of the exponent operand and its row tile
     extern __shared__ __align__(16) unsigned char smem_raw[];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -673,9 +689,9 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
                 if constexpr (g == 0 && j == S::J0) load_x(x1h, x1l, pos, 1);
             };
             if constexpr (g + 1 < G)
-                pg_step<KS, NFB>(c[(st + 1) & 1], c[st & 1], a_cur, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
+                pg_step<KS, NFB, WLO>(c[(st + 1) & 1], c[st & 1], a_cur, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
             else
-                pg_step<KS, NFB>(c[(st + 1) & 1], c[st & 1], a_nxt, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
+                pg_step<KS, NFB, WLO>(c[(st + 1) & 1], c[st & 1], a_nxt, bop[(g + 1) % G], acc[(g + G - 1) % G], acc[g], x0h, x0l, x1h, x1l, wh1, wl1, hook);
         });
         pos = pos + 1 == RING ? 0 : pos + 1;
         if (++in_chunk == NTb) { in_chunk = 0; ++chunk; }
@@ -692,7 +708,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
 #pragma unroll
     for (int i = 0; i < 3 * NFB; ++i) {
         const int fb = i % NFB, pr = i / NFB;
-        if (!PG_WLO && pr == 1) continue;
+        if (!WLO && pr == 1) continue;
         acc[G - 1][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? x1l[fb] : x1h[fb], pr == 1 ? wl1 : wh1, acc[G - 1][fb], 0, 0, 0);
     }
     // ---- out[d][column][f]: register v of lane (column l5, half) of block fb is feature 32 fb + 8 (v / 4) + 4 half + v % 4 ----
@@ -1026,7 +1042,7 @@ size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q) { return psi2_pgrad_suppo
 // part 1 (does not depend on the adjoints): observation images, pass 1 -> R2 [and Psi2: psi2_part != nullptr]
 template <int KS>
 static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
-                              const double *gamma, unsigned char *ws, float *psi2_part, const float *scale, hipStream_t st) {
+                              const double *gamma, unsigned char *ws, float *psi2_part, const float *scale, hipStream_t st, bool wlo) {
     constexpr int NFB = PgCfg<KS>::NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
     const PgLayout L = pg_layout(D, N, M, Q);
     const Psi2Consts C = psi2_consts_layout(M, Q);
@@ -1046,7 +1062,8 @@ static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *c
     }
     const int NTb = pg_ring_tiles<KS>();
     const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
-    auto kern = pg_pass_kernel<KS>;
+    // (the pass that also yields Psi2 keeps the lo half of the exponentials whatever the mode: the objective is not a "fast" quantity)
+    auto kern = (wlo || psi2_part) ? pg_pass_kernel<KS, true> : pg_pass_kernel<KS, false>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DPGP_ERR_LAUNCH;
     const int groups = dpgp_ceil_div(L.PT, NW * G);
@@ -1067,7 +1084,7 @@ template <int KS>
 static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                               const double *s, const double *gamma, const double *alpha, const double *GP, const float *scale,
                               const float *psi2, unsigned char *ws, double *dmu, double *ds, double *dz, double *dgamma,
-                              hipStream_t st, const double *y, int ldy, const double *Gv) {
+                              hipStream_t st, const double *y, int ldy, const double *Gv, bool wlo) {
     constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
     const PgLayout L = pg_layout(D, N, M, Q);
     const Psi2Consts C = psi2_consts_layout(M, Q);
@@ -1093,7 +1110,7 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     {
         const int NTb = pg_ring_tiles<KS>();
         const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
-        auto kern = pg_pass_kernel<KS>;
+        auto kern = wlo ? pg_pass_kernel<KS, true> : pg_pass_kernel<KS, false>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
         const int groups = dpgp_ceil_div(L.NT, NW * G);
@@ -1147,7 +1164,9 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
         DPGP_LAUNCH_CHECK();
         const int NTb = pg_ring_tiles<KS>();
         const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
-        auto kern = pg_pass_kernel<KS>;
+        auto kern = wlo ? pg_pass_kernel<KS, true> : pg_pass_kernel<KS, false>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
         PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
         // rows: the inducing points (dimg, features xm1 of output dim d); columns: the observations of output dim d -> R1' [d][n][.]
         int groups = dpgp_ceil_div(L.NT, NW * G);
@@ -1194,20 +1213,22 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
 // partial slabs), 2 = part 2 only (after part 1 on the same ws), 3 = both.
 // y != nullptr (with Gv [D][Mp] = d f_hat / d (Psi1^T y)): the Psi1 term as well, through the same pass kernel; dmu and ds are then
 // OVERWRITTEN (nothing else has written them), dz and dgamma added to.
+// fast != 0 (DPGP_PREC_MIXED_FAST): the second products take the exponentials as their f16 roundings alone (11 bits; the pass that
+// also yields Psi2 keeps both halves).
 int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
                       double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st, int which,
-                      float *psi2_part, const float *scale, const double *y, int ldy, const double *Gv) {
+                      float *psi2_part, const float *scale, const double *y, int ldy, const double *Gv, int fast) {
     if (!psi2_pgrad_supported(M, Q)) return -4;
     (void)stage;
     int rc = DPGP_OK;
     switch (psi2_pairs_ksteps(Q)) {
 #define CASE(k)                                                                                                                  \
     case k:                                                                                                                      \
-        if (which & 1) rc = launch_pgrad_part1<k>(D, N, M, Q, consts, mu, s, gamma, ws, psi2_part, scale, st);                  \
+        if (which & 1) rc = launch_pgrad_part1<k>(D, N, M, Q, consts, mu, s, gamma, ws, psi2_part, scale, st, !fast);           \
         if (rc == DPGP_OK && (which & 2))                                                                                        \
             rc = launch_pgrad_part2<k>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, scale, (which & 1) ? nullptr : psi2_part, ws, dmu, ds, \
-                                       dz, dgamma, st, y, ldy, Gv);                                                              \
+                                       dz, dgamma, st, y, ldy, Gv, !fast);                                                       \
         return rc;
         CASE(2) CASE(4) CASE(6) CASE(8)
 #undef CASE

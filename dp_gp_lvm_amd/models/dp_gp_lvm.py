@@ -75,7 +75,7 @@ def dp_gp_lvm(y_train,
         # precision='mixed' (fp32 psi-statistics) is the fast scoring mode: its conditioning guard stops a long Adam run.
         precision, backward_precision = 'f64', (backward_precision or 'mixed')
     assert precision in ('f32', 'mixed', 'f64'), "precision must be one of 'f32', 'mixed', 'f64'"
-    assert backward_precision in (None, 'mixed', 'f64'), "backward_precision must be None, 'mixed' or 'f64'"
+    assert backward_precision in (None, 'mixed', 'f64', 'mixed_fast'), "backward_precision must be None, 'mixed', 'mixed_fast' or 'f64'"
     # stage B behind an fp64 forward pass (the training configuration): the patch form of the Psi2 term, which keeps its accuracy
     # where the adjoints cancel (include/dpgp.h, DPGP_PREC_MIXED_PATCH); behind a mixed forward pass the faster pair-tile form
     stage_b_precision = backward_precision or precision
@@ -155,7 +155,7 @@ def dp_gp_lvm(y_train,
 
     # one training step through dpgp_elbo_step (mixed precision, M <= 128, Q <= 20: DESIGN.md section 7.1): the forward's psi2 dispatch is
     # replaced by the first pass of stage B (DPGP_FUSED_STEP=0: the three separate calls, e.g. for bench.py's per-stage breakdown)
-    fused_step = (precision == 'mixed' and stage_b_precision == 'mixed' and psi_algo == 'auto' and
+    fused_step = (precision == 'mixed' and stage_b_precision in ('mixed', 'mixed_fast') and psi_algo == 'auto' and
                   ops.elbo_step_supported(num_inducing_points, num_latent_dims) and os.environ.get('DPGP_FUSED_STEP', '1') != '0')
     step_state = {}
 
@@ -180,7 +180,8 @@ def dp_gp_lvm(y_train,
                 step_state['buf'] = ops.ElboStepBuffers(d_local, num_samples, num_inducing_points, num_latent_dims, device)
             step_state['grads'] = ops.elbo_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'], workspace,
                                                 step_state['buf'], jitter=GP_DEFAULT_JITTER,
-                                                model_tail=(buf['scal'], red, None if sharded else out))[1]
+                                                model_tail=(buf['scal'], red, None if sharded else out),
+                                                stage_b=stage_b_precision)[1]
         else:
             ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
                           jitter=GP_DEFAULT_JITTER, prec=precision, algo=psi_algo, workspace=workspace, events=events,

@@ -396,11 +396,12 @@ class ElboStepBuffers:
         self.dz, self.dg = torch.empty((m, q), dtype=f64, device=device), torch.empty((d, q), dtype=f64, device=device)
 
 
-def elbo_step(y, z, mu, s, gamma, alpha, beta, workspace, buffers, jitter=1e-8, model_tail=None):
+def elbo_step(y, z, mu, s, gamma, alpha, beta, workspace, buffers, jitter=1e-8, model_tail=None, stage_b='mixed'):
     """One training step's worth of the fused reduction in mixed precision (dpgp_elbo_step): the f_hat terms of ``elbo_fhat``
     and the gradients of ``elbo_grad_chain`` + ``elbo_grad_psi`` from ONE call, the Psi2 exponentials evaluated twice instead of
     three times (dp_gp_lvm.py:108-145 and its tf.gradients, test/synthetic_data_hard_test.py:143-155).
     workspace: ElboWorkspace(..., 'mixed'); buffers: ElboStepBuffers.  All inputs fp64 device tensors (as ``elbo_fhat``).
+    stage_b: 'mixed', or 'mixed_fast' (DPGP_PREC_MIXED_FAST, include/dpgp.h: 11-bit exponentials in the second products of stage B).
     Returns (terms, sums, info), (d_mu, d_s, d_z, d_gamma, d_alpha_beta, info_grad) — tensors of the two buffer objects."""
     import ctypes
     w, b = workspace, buffers
@@ -412,8 +413,8 @@ def elbo_step(y, z, mu, s, gamma, alpha, beta, workspace, buffers, jitter=1e-8, 
         (None, None, None) if model_tail is None else tuple(None if t_ is None else t_.data_ptr() for t_ in model_tail))
     _lib.check(_lib.lib().dpgp_elbo_step(
         d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(),
-        beta.data_ptr(), float(jitter), w.terms.data_ptr(), w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes,
-        b.gp.data_ptr(), b.wk.data_ptr(), b.gv.data_ptr(), b.dab.data_ptr(), b.info.data_ptr(), b.ws.data_ptr(), b.nbytes,
+        beta.data_ptr(), float(jitter), _lib.PREC[stage_b], w.terms.data_ptr(), w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(),
+        w.nbytes, b.gp.data_ptr(), b.wk.data_ptr(), b.gv.data_ptr(), b.dab.data_ptr(), b.info.data_ptr(), b.ws.data_ptr(), b.nbytes,
         b.dmu.data_ptr(), b.ds.data_ptr(), b.dz.data_ptr(), b.dg.data_ptr(), _stream(),
         ctypes.cast(ctypes.pointer(w.exec), ctypes.c_void_p)), 'dpgp_elbo_step')
     return (w.terms, w.sums, w.info), (b.dmu, b.ds, b.dz, b.dg, b.dab, b.info)

@@ -45,6 +45,12 @@ extern "C" {
 #define DPGP_PREC_F32 0   /* psi-statistics fp32, Cholesky chain fp32                          */
 #define DPGP_PREC_MIXED 1 /* psi-statistics fp32 (MFMA), Cholesky chain + reductions fp64      */
 #define DPGP_PREC_F64 2   /* everything fp64                                                   */
+#define DPGP_PREC_MIXED_FAST 4  /* dpgp_elbo_grad_psi[_ex], dpgp_elbo_step only: as DPGP_PREC_MIXED, but the second products of the pair-tile
+                                 * stage B take the exponentials as their f16 roundings alone (11 significant bits instead of 22; the pass
+                                 * that also yields Psi2 keeps both halves).  The rounding errors are independent from element to element
+                                 * and average over the observations / pairs a sum runs over: measured <= 3e-6 of the largest gradient
+                                 * entry at N = 2000 (the default's 6e-7), beyond the 5e-4 gradient tolerance only for N of a few dozen
+                                 * (tests/test_gpu_grad.py).  Opt-in; never the default. */
 #define DPGP_PREC_MIXED_PATCH 3 /* dpgp_elbo_grad_psi[_ex] only: as DPGP_PREC_MIXED, the Psi2 term in the per-observation patch
                                  * form (psi2_grad_kernel) instead of the pair-tile form (psi2_pairs_grad.hip).  The pair-tile form
                                  * is faster (config 3: 6.7 vs 8.0 ms) but sums a' and b weighted exponentials SEPARATELY before
@@ -220,15 +226,15 @@ int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, 
 /* ---- Training step: the f_hat terms AND their gradients with respect to mu, s, z, gamma (stage B) and alpha, beta (stage A) in
  * one call — what one Adam iteration of every training script of the reference evaluates (objective + tf.gradients,
  * test/synthetic_data_hard_test.py:143-155; forward src/models/dp_gp_lvm.py:108-145, src/kernels/rbf_kernel.py:135-199).
- * Mixed precision (as DPGP_PREC_MIXED of the three calls it replaces: dpgp_elbo_fhat_ex + dpgp_elbo_grad_chain +
- * dpgp_elbo_grad_psi), M <= 128 (-3), Q <= 20 (-4).  Same results as the three calls within the mixed-precision tolerance; the
+ * Mixed precision (prec = DPGP_PREC_MIXED, as of the three calls it replaces: dpgp_elbo_fhat_ex + dpgp_elbo_grad_chain +
+ * dpgp_elbo_grad_psi; or DPGP_PREC_MIXED_FAST for stage B), M <= 128 (-3), Q <= 20 (-4).  Same results as the three calls within the mixed-precision tolerance; the
  * Psi2 statistic comes out of the first pass of stage B (same exponentials, constant feature), so its exponentials are
  * evaluated twice per step instead of three times.
  *   terms / sums / info / ws: as dpgp_elbo_fhat (ws: dpgp_elbo_workspace_bytes(D,N,M,Q,DPGP_PREC_MIXED));
  *   g_psi2 / w_kuu / g_v / d_alpha_beta / info_grad: as dpgp_elbo_grad_chain (outputs, caller-allocated);
  *   gws: dpgp_elbo_grad_psi_workspace_bytes_ex(D,N,M,Q,DPGP_PREC_MIXED);  d_mu / d_s / d_z / d_gamma: as dpgp_elbo_grad_psi.   */
 int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
-                   const double *gamma, const double *alpha, const double *beta, double jitter, double *terms, double *sums,
+                   const double *gamma, const double *alpha, const double *beta, double jitter, int prec, double *terms, double *sums,
                    int *info, void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v, double *d_alpha_beta,
                    int *info_grad, void *gws, size_t gws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma,
                    void *stream, const dpgp_exec_t *exec);

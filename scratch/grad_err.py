@@ -18,7 +18,8 @@ def build(prec, bprec=None):
                                          gamma_atoms=p['gamma_atoms'], alpha_atoms=p['alpha_atoms'], beta_atoms=p['beta_atoms'],
                                          gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'], w_2=p['w2']))
 ref = {k: v.cpu().numpy() for k, v in build('f64', 'f64').gradients().items()} if m <= 128 else None
-for name, (prec, bprec) in {'mixed': ('mixed', None), 'f64 fwd + mixed stage B': ('f64', 'mixed')}.items():
+for name, (prec, bprec) in {'mixed': ('mixed', None), 'mixed + fast stage B': ('mixed', 'mixed_fast'),
+                            'f64 fwd + mixed stage B': ('f64', 'mixed')}.items():
     mdl = build(prec, bprec)
     for _ in range(2): g = mdl.gradients()
     torch.cuda.synchronize()

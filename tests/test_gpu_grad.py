@@ -464,3 +464,42 @@ def test_model_gradients_fused_step_equals_separate_calls(dev, monkeypatch):
     for k in out['0'][0]:
         want = out['0'][0][k]
         np.testing.assert_allclose(out['1'][0][k], want, rtol=0, atol=2e-4 * max(np.abs(want).max(), 1e-12), err_msg=k)
+
+
+@pytest.mark.parametrize('shape', [(300, 16, 100, 10), (500, 8, 128, 12), (200, 6, 64, 20), (150, 4, 96, 17)])
+def test_fast_stage_b_within_its_stated_tolerance(dev, shape):
+    """DPGP_PREC_MIXED_FAST (opt-in: the second products of the pair-tile stage B take 11-bit exponentials, include/dpgp.h): against
+    the fp64 stage B on the same fp64 adjoints — 2e-3 of the largest entry at these small N (a few hundred observations per sum;
+    the default mixed mode: 2e-4), where its rounding errors average least."""
+    n, d, m, q = shape
+    args = _stage_b_problem(dev, shape)
+    w = ops.ElboWorkspace(d, n, m, q, 'f64', dev)
+    ops.elbo_fhat(*args, prec='f64', workspace=w)
+    gp, wk, gv, _, info = ops.elbo_grad_chain(args[5], args[6], w)
+    assert int(info.abs().max()) == 0
+    want = [a.cpu().numpy() for a in ops.elbo_grad_psi(args[0], args[1], args[2], args[3], args[4], args[5], gp, wk, gv, prec='f64')]
+    got = [a.cpu().numpy() for a in ops.elbo_grad_psi(args[0], args[1], args[2], args[3], args[4], args[5], gp, wk, gv, prec='mixed_fast')]
+    for name, a, b in zip(('d mu', 'd S', 'd z', 'd gamma'), got, want):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-3 * np.abs(b).max(), err_msg=name)
+
+
+def test_fast_stage_b_at_a_baseline_shape(dev):
+    """The same mode where it is meant to be used — BASELINE config 2 (N = 2000, D = 64, M = 128, Q = 10): the gradients of all raw
+    variables through dpgp_elbo_step with backward_precision='mixed_fast' against the default mixed step: 5e-5 of the largest
+    entry of each (measured ~3e-6; the stated mixed-precision gradient tolerance is 5e-4), same objective."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    from dp_gp_lvm_amd.utils.synthetic import make_problem
+    p = make_problem(2)
+    out = {}
+    for bp in ('mixed', 'mixed_fast'):
+        mdl = dp_gp_lvm(p['y'], num_latent_dims=p['mu'].shape[1], num_inducing_points=p['z'].shape[0],
+                        truncation_level=p['phi'].shape[1], alpha_prior_params=np.array([p['s1'], p['s2']]), device=dev,
+                        precision='mixed', backward_precision=bp,
+                        initial_values=dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']),
+                                            gamma_atoms=p['gamma_atoms'], alpha_atoms=p['alpha_atoms'], beta_atoms=p['beta_atoms'],
+                                            gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'], w_2=p['w2']))
+        g = mdl.gradients()
+        out[bp] = ({k: v.cpu().numpy().copy() for k, v in g.items()}, float(mdl.objective))
+    assert out['mixed'][1] == out['mixed_fast'][1]                 # (the pass that yields Psi2 keeps both halves)
+    for k, want in out['mixed'][0].items():
+        np.testing.assert_allclose(out['mixed_fast'][0][k], want, rtol=0, atol=5e-5 * max(np.abs(want).max(), 1e-12), err_msg=k)
