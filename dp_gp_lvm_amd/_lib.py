@@ -55,6 +55,7 @@ SIGNATURES = {
                                   _vp, _vp]),
     'dpgp_model_scal_count': (_i, [_i]),
     'dpgp_model_backward': (_i, [_i] * 8 + [_vp] * 10 + [_d, _d, _i] + [_vp] * 15 + [_vp]),
+    'dpgp_model_backward_t': (_i, [_i] * 8 + [_vp] * 10 + [_d, _d, _i] + [_vp] * 16 + [_vp]),
     'dpgp_model_pack': (_i, [_i, _vp, _vp, _vp, _vp]),
     'dpgp_model_finalize': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'dpgp_gemm_strided_f64': (_i, [_i, _i, _i, _i, _d, _vp, _ll, _ll, _ll, _vp, _ll, _ll, _ll, _d, _vp, _ll, _ll, _ll, _vp]),

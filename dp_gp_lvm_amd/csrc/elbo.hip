@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
     const double *__restrict__ w_raw, const double *__restrict__ x_mean, const double *__restrict__ phi, double s1,
     double s2, int add_constants, const double *__restrict__ df_dmu, const double *__restrict__ df_ds,
     const double *__restrict__ df_dz, const double *__restrict__ df_dgamma, const double *__restrict__ df_dab,
-    double *__restrict__ d_x_mean, double *__restrict__ d_s_raw, double *__restrict__ d_x_u,
+    const double *__restrict__ df_dphi, double *__restrict__ d_x_mean, double *__restrict__ d_s_raw, double *__restrict__ d_x_u,
     double *__restrict__ d_logits, double *__restrict__ d_g1_raw, double *__restrict__ d_g2_raw,
     double *__restrict__ d_w_raw, double *__restrict__ d_gat_raw, double *__restrict__ d_aat_raw,
     double *__restrict__ d_bat_raw) {
@@ -801,6 +801,8 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
         c2cum[T] = cum;
     }
     __syncthreads();
+    // df_dphi != nullptr: the over-T model (dp_gp_lvm_t, reference dp_gp_lvm.py:513-676) — the kernel hyper-parameters ARE the atoms, so
+    // df_dgamma [T][Q] and df_dab [T][2] are d f_hat / d (softplus'd atoms) themselves, and phi enters f_hat directly: df_dphi [D][T]
     if (blockIdx.x == 0) {
         // A[k][j] = sum_d phi[d,k] X[d,j], X = [df/dgamma (Q) | df/dalpha | df/dbeta | 1]: output dims staged through LDS in
         // chunks of 32 (coalesced loads, fixed summation order) instead of one serial pass over D per thread
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
                 }
                 for (int i = t; i < 32 * cols; i += 256) {
                     const int dd = i / cols, jj = i - dd * cols, d = dc + dd;
-                    x_s[dd][jj] = (d < D) ? (jj < Q ? df_dgamma[(size_t)d * Q + jj] : (jj == Q ? df_dab[2 * d] : (jj == Q + 1 ? df_dab[2 * d + 1] : 1.0))) : 0.0;
+                    x_s[dd][jj] = (d < D) ? (jj > Q + 1 ? 1.0 : (df_dphi ? 0.0 : (jj < Q ? df_dgamma[(size_t)d * Q + jj] : (jj == Q ? df_dab[2 * d] : df_dab[2 * d + 1])))) : 0.0;
                 }
                 __syncthreads();
                 if (e < T * cols)
@@ -825,6 +827,7 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
             }
             if (e < T * cols) {
                 if (j <= Q + 1) {
+                    if (df_dphi) acc = j < Q ? df_dgamma[(size_t)k * Q + j] : (j == Q ? df_dab[2 * k] : df_dab[2 * k + 1]);
                     const double raw = j < Q ? gat_raw[k * Q + j] : (j == Q ? aat_raw[k] : bat_raw[k]);
                     const double x = softplus_d(raw);
                     const double hyp = add_constants ? (1.0 / x + log(x) / x) : 0.0;               // -d/dx log_normal.log_pdf(x)
@@ -875,11 +878,13 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
     for (int k = 0; k < T; ++k) d_logits[(size_t)r * T + k] = 0.0;
     for (int d = dlo; d < dhi; ++d) {
         const double *ph = phi + (size_t)d * T;
-        const double *dg = df_dgamma + (size_t)d * Q;
-        const double da = df_dab[2 * d], db = df_dab[2 * d + 1];
+        const double *dg = df_dgamma + (size_t)(df_dphi ? 0 : d) * Q;
+        const double da = df_dphi ? 0.0 : df_dab[2 * d], db = df_dphi ? 0.0 : df_dab[2 * d + 1];
         auto gk = [&](int k) {
             double mix = da * aat[k] + db * bat[k];
-            for (int q = 0; q < Q; ++q) mix += dg[q] * gat[k * Q + q];
+            if (df_dphi) mix = df_dphi[(size_t)d * T + k];
+            else
+                for (int q = 0; q < Q; ++q) mix += dg[q] * gat[k * Q + q];
             // d DP objective / d phi = -( [k < T-1] c1_k + sum_{k' < k} c2_k' - log phi - 1 )
             return -mix - (c1[k] + c2cum[k] - log(ph[k]) - 1.0);
         };
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
     }
 }
 
-extern "C" int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offset, int mask_size, int logits_rows,
+static int model_backward_run(int D, int T, int Q, int N, int M, int d_offset, int mask_size, int logits_rows,
                                    const double *logits, const double *gamma_atoms_raw, const double *alpha_atoms_raw,
                                    const double *beta_atoms_raw, const double *s_raw, const double *g1_raw,
                                    const double *g2_raw, const double *w_raw, const double *x_mean, const double *phi,
@@ -897,7 +902,7 @@ extern "C" int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offs
                                    const double *df_dz, const double *df_dgamma, const double *df_dalpha_beta,
                                    double *d_x_mean, double *d_s_raw, double *d_x_u, double *d_logits, double *d_g1_raw,
                                    double *d_g2_raw, double *d_w_raw, double *d_gamma_atoms_raw,
-                                   double *d_alpha_atoms_raw, double *d_beta_atoms_raw, void *stream) {
+                                   double *d_alpha_atoms_raw, double *d_beta_atoms_raw, void *stream, const double *df_dphi) {
     if (D <= 0) return -1;
     if (T <= 0 || T > PREP_MAX_T) return -2;
     if (Q <= 0 || Q > DPGP_MAX_Q) return -3;
@@ -925,10 +930,43 @@ extern "C" int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offs
     if (neb > 1024) neb = 1024;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(model_backward_kernel, dim3(1 + nlb + neb), dim3(256), 0, st, D, T, Q, N, M, d_offset, mask_size, nlb,
                        logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw, s_raw, g1_raw, g2_raw, w_raw, x_mean, phi, s1, s2,
-                       add_constants, df_dmu, df_ds, df_dz, df_dgamma, df_dalpha_beta, d_x_mean, d_s_raw, d_x_u, d_logits,
+                       add_constants, df_dmu, df_ds, df_dz, df_dgamma, df_dalpha_beta, df_dphi, d_x_mean, d_s_raw, d_x_u, d_logits,
                        d_g1_raw, d_g2_raw, d_w_raw, d_gamma_atoms_raw, d_alpha_atoms_raw, d_beta_atoms_raw);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
+}
+
+extern "C" int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offset, int mask_size, int logits_rows,
+                                   const double *logits, const double *gamma_atoms_raw, const double *alpha_atoms_raw,
+                                   const double *beta_atoms_raw, const double *s_raw, const double *g1_raw,
+                                   const double *g2_raw, const double *w_raw, const double *x_mean, const double *phi,
+                                   double s1, double s2, int add_constants, const double *df_dmu, const double *df_ds,
+                                   const double *df_dz, const double *df_dgamma, const double *df_dalpha_beta,
+                                   double *d_x_mean, double *d_s_raw, double *d_x_u, double *d_logits, double *d_g1_raw,
+                                   double *d_g2_raw, double *d_w_raw, double *d_gamma_atoms_raw,
+                                   double *d_alpha_atoms_raw, double *d_beta_atoms_raw, void *stream) {
+    return model_backward_run(D, T, Q, N, M, d_offset, mask_size, logits_rows, logits, gamma_atoms_raw, alpha_atoms_raw, beta_atoms_raw,
+                              s_raw, g1_raw, g2_raw, w_raw, x_mean, phi, s1, s2, add_constants, df_dmu, df_ds, df_dz, df_dgamma,
+                              df_dalpha_beta, d_x_mean, d_s_raw, d_x_u, d_logits, d_g1_raw, d_g2_raw, d_w_raw, d_gamma_atoms_raw,
+                              d_alpha_atoms_raw, d_beta_atoms_raw, stream, nullptr);
+}
+// the same for the over-T model dp_gp_lvm_t: df_dgamma_atoms [T][Q] / df_dalpha_beta_atoms [T][2] = d f_hat / d (softplus'd atoms) and
+// df_dphi [D][T] = d f_hat / d phi (both direct: no mixing between them)
+extern "C" int dpgp_model_backward_t(int D, int T, int Q, int N, int M, int d_offset, int mask_size, int logits_rows,
+                                     const double *logits, const double *gamma_atoms_raw, const double *alpha_atoms_raw,
+                                     const double *beta_atoms_raw, const double *s_raw, const double *g1_raw, const double *g2_raw,
+                                     const double *w_raw, const double *x_mean, const double *phi, double s1, double s2,
+                                     int add_constants, const double *df_dmu, const double *df_ds, const double *df_dz,
+                                     const double *df_dgamma_atoms, const double *df_dalpha_beta_atoms, const double *df_dphi,
+                                     double *d_x_mean, double *d_s_raw, double *d_x_u, double *d_logits, double *d_g1_raw,
+                                     double *d_g2_raw, double *d_w_raw, double *d_gamma_atoms_raw, double *d_alpha_atoms_raw,
+                                     double *d_beta_atoms_raw, void *stream) {
+    if (!df_dphi) return -27;
+    const int rc = model_backward_run(D, T, Q, N, M, d_offset, mask_size, logits_rows, logits, gamma_atoms_raw, alpha_atoms_raw,
+                                      beta_atoms_raw, s_raw, g1_raw, g2_raw, w_raw, x_mean, phi, s1, s2, add_constants, df_dmu, df_ds,
+                                      df_dz, df_dgamma_atoms, df_dalpha_beta_atoms, d_x_mean, d_s_raw, d_x_u, d_logits, d_g1_raw,
+                                      d_g2_raw, d_w_raw, d_gamma_atoms_raw, d_alpha_atoms_raw, d_beta_atoms_raw, stream, df_dphi);
+    return rc <= -27 ? rc - 1 : rc;                 // (argument indices behind df_dphi move by one)
 }
 
 extern "C" int dpgp_model_scal_count(int D) { return D > 0 ? 2 + dpgp_ceil_div(D, PREP_ROWS) : 0; }

@@ -775,9 +775,12 @@ int launch_kuu_grad(int D, int M, int Q, const unsigned char *consts, const doub
 
 // workspace (doubles) of launch_psi1_grad: d/dmu, d/dS partials [DC][N][Q] float; d/dgamma [NB][D][Q]; d/dz [DC ns][M][Q]
 static void psi1_grad_shape(int D, int N, int *dpw, int *DC, int *NB, int *ns, int *nper) {
-    *dpw = 8;
-    *DC = dpgp_ceil_div(D, *dpw);
     *NB = dpgp_ceil_div(N, 256);
+    // output dims per workgroup: 8, fewer when few output dims (the over-T model: D = T atoms) would leave the GPU to NB workgroups
+    *dpw = (int)((long long)D * *NB / 512);
+    if (*dpw > 8) *dpw = 8;
+    if (*dpw < 1) *dpw = 1;
+    *DC = dpgp_ceil_div(D, *dpw);
     int k = dpgp_ceil_div(1024, *DC);
     if (k > dpgp_ceil_div(N, 128)) k = dpgp_ceil_div(N, 128);
     if (k < 1) k = 1;

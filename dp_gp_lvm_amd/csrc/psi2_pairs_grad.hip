@@ -662,9 +662,13 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
         if (in_chunk == NTb - LA && chunk + 1 < n_chunks) {
             // LA row tiles in front of the chunk's end: the next chunk is complete in LDS (own pieces: vmcnt, everybody's: barrier),
             // and everybody has left the previous chunk, whose ring slots take the chunk after the next
+#ifndef PG_DIAG_NOBAR                                              // (timing experiments only: wrong results)
             __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0)
             __syncthreads();
+#endif
+#ifndef PG_DIAG_NOFILL                                             // (timing experiments only: wrong results)
             if (chunk + 2 < n_chunks) fill(chunk + 2);
+#endif
         }
         // ring slot of the row tile LA ahead (behind the last row tile: surplus chains on the last one)
         int pos_n = pos;
@@ -680,6 +684,9 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
                 // step (the previous step's K-step-0 products are all issued), its K-step-1 features behind the first K-step-0
                 // product (the previous row tile's K-step-1 products are all issued); the exponent operand one step ahead of
                 // its first use.
+#ifdef PG_DIAG_NOLDS                                               // (timing experiments only: wrong results)
+                if (rt > 1) return;
+#endif
                 if constexpr (g == 0 && j == S::first_of(1)) load_x(x0h, x0l, pos, 0);
                 if constexpr (G == 1) {
                     if constexpr (j == S::first_of(1)) load_a(a_cur, pos_n);

@@ -662,62 +662,80 @@ def dp_gp_lvm_t(y_train,
         last_info[0] = torch.maximum(info_k.abs().max(), info_b.abs().max())
         return psi_1, psi_2, k_uu, l_k, l_b
 
-    class _FHatT(torch.autograd.Function):
-        """f_hat of dp_gp_lvm.py:617-667 as a differentiable function of (x_mean, S, x_u, gamma/alpha/beta atoms, phi^T):
-        forward = the library's operators; backward = the adjoints of the per-atom dense algebra (torch, T small) and the
-        library's streaming stage B (dpgp_elbo_grad_psi_ex: Psi2 term on the matrix pipe, Psi1 term with the full adjoint
-        beta^2 Y diag(phi_t) W_t^T, K_uu term)."""
-
-        @staticmethod
-        def forward(ctx, x_mean_, s_, x_u_, gat, aat, bat, phit):
-            psi_1, psi_2, k_uu, l_k, l_b = _chain(x_u_, x_mean_, s_, gat, aat, bat)
-            h = ops.trsm_batched(l_k, psi_2)
-            tr = torch.diagonal(ops.trsm_batched(l_k, h.transpose(1, 2).contiguous()), dim1=-2, dim2=-1).sum(-1)
-            logdet = torch.log(torch.diagonal(l_b, dim1=-2, dim2=-1)).sum(-1) - \
-                torch.log(torch.diagonal(l_k, dim1=-2, dim2=-1)).sum(-1)
-            v = ops.matmul(psi_1.transpose(1, 2), y_dev)                       # [T x M x D]
-            c = ops.trsm_batched(l_b, v)
-            quad = bat[:, None] ** 2 * torch.sum(c * c, dim=1)                   # [T x D]
-            per_t = 0.5 * (n_ * torch.log(bat) + bat * (tr - n_ * aat)) - logdet
-            ctx.save_for_backward(x_mean_, s_, x_u_, gat, aat, bat, phit, psi_2, k_uu, l_k, l_b, v, per_t, quad, tr)
-            return -0.5 * n_ * d_ * np.log(2.0 * np.pi) + torch.sum(phit * per_t[:, None]) \
-                - 0.5 * torch.sum(phit * bat[:, None] * yy[None, :]) + 0.5 * torch.sum(phit * quad)
-
-        @staticmethod
-        def backward(ctx, g_out):
-            x_mean_, s_, x_u_, gat, aat, bat, phit, p2, k_uu, l_k, l_b, v, per_t, quad, tr = ctx.saved_tensors
-            t_ = gat.shape[0]
-            eye = torch.eye(m_, dtype=TORCH_DTYPE, device=device)
-            eyes = eye.expand(t_, m_, m_).contiguous()
+    def _fhat_forward(x_mean_, s_, x_u_, gat, aat, bat, phit, for_backward=True):
+        """f_hat of dp_gp_lvm.py:617-667 from the library's operators; returns (f_hat, what the backward pass needs).
+        for_backward: K^-1 and B^-1 are formed once here (two triangular solves on the identity + two products) and serve the trace,
+        the solve against V and the whole backward pass — six latency-bound batched solves of T small matrices otherwise."""
+        psi_1, psi_2, k_uu, l_k, l_b = _chain(x_u_, x_mean_, s_, gat, aat, bat)
+        v = ops.matmul(psi_1.transpose(1, 2), y_dev)                       # [T x M x D]
+        k_inv = b_inv = None
+        if for_backward:
+            eyes = torch.eye(m_, dtype=TORCH_DTYPE, device=device).expand(gat.shape[0], m_, m_).contiguous()
             li = ops.trsm_batched(l_k, eyes)
             k_inv = ops.matmul(li.transpose(1, 2), li)
             li = ops.trsm_batched(l_b, eyes)
             b_inv = ops.matmul(li.transpose(1, 2), li)
-            st = phit.sum(dim=1)[:, None, None]                                  # s_t = sum_d phi_td
-            be = bat[:, None, None]
-            w = ops.matmul(b_inv, v)                                           # [T x M x D]
-            wphi = w * phit[:, None, :]
-            vwphi = torch.sum(v * wphi, dim=(1, 2))                              # sum_d phi_td v_td^T B^-1 v_td
-            gb = -0.5 * st * b_inv - 0.5 * be * be * ops.matmul(wphi, w.transpose(1, 2))
-            x = ops.matmul(ops.matmul(k_inv, p2), k_inv)
-            gk = 0.5 * st * k_inv - 0.5 * st * be * x + gb
-            gp = 0.5 * st * be * k_inv + be * gb
-            wk = gk * (k_uu - GP_DEFAULT_JITTER * eye)
-            g1 = be * be * ops.matmul(y_dev, wphi.transpose(1, 2))             # [T x N x M] adjoint of Psi1
-            pad2 = (0, mp_ - m_, 0, mp_ - m_)
-            dmu, ds, dz, dgam = ops.elbo_grad_psi(None, x_u_, x_mean_, s_, gat, aat,
-                                                  torch.nn.functional.pad(gp, pad2).contiguous(),
-                                                  torch.nn.functional.pad(wk, pad2).contiguous(), None,
-                                                  prec='mixed_patch' if precision == 'f64' else 'mixed',
-                                                  g_psi1=torch.nn.functional.pad(g1, (0, mp_ - m_)).contiguous())
-            s_k, s_p = wk.sum(dim=(1, 2)), (gp * p2).sum(dim=(1, 2))
-            s_gbp = (gb * p2).sum(dim=(1, 2))
-            stv = st[:, 0, 0]
-            d_alpha = -0.5 * bat * n_ * stv + (s_k + 2.0 * s_p + bat * bat * vwphi) / aat
-            d_beta = stv * (0.5 * n_ / bat + 0.5 * (tr - aat * n_)) - 0.5 * torch.sum(phit * yy[None, :], dim=1) \
-                + bat * vwphi + s_gbp
-            d_phit = per_t[:, None] - 0.5 * bat[:, None] * yy[None, :] + 0.5 * quad
-            return (g_out * dmu, g_out * ds, g_out * dz, g_out * dgam, g_out * d_alpha, g_out * d_beta, g_out * d_phit)
+            tr = torch.sum(k_inv * psi_2, dim=(1, 2))                        # tr(L^-1 Psi2 L^-T) = <K^-1, Psi2>
+            c = ops.matmul(li, v)                                          # L_B^-1 V
+        else:
+            h = ops.trsm_batched(l_k, psi_2)
+            tr = torch.diagonal(ops.trsm_batched(l_k, h.transpose(1, 2).contiguous()), dim1=-2, dim2=-1).sum(-1)
+            c = ops.trsm_batched(l_b, v)
+        logdet = torch.log(torch.diagonal(l_b, dim1=-2, dim2=-1)).sum(-1) - \
+            torch.log(torch.diagonal(l_k, dim1=-2, dim2=-1)).sum(-1)
+        quad = bat[:, None] ** 2 * torch.sum(c * c, dim=1)                   # [T x D]
+        per_t = 0.5 * (n_ * torch.log(bat) + bat * (tr - n_ * aat)) - logdet
+        f_hat = -0.5 * n_ * d_ * np.log(2.0 * np.pi) + torch.sum(phit * per_t[:, None]) \
+            - 0.5 * torch.sum(phit * bat[:, None] * yy[None, :]) + 0.5 * torch.sum(phit * quad)
+        return f_hat, (x_mean_, s_, x_u_, gat, aat, bat, phit, psi_2, k_uu, k_inv, b_inv, v, per_t, quad, tr)
+
+    def _fhat_backward(saved):
+        """d f_hat / d (x_mean, S, x_u, gamma atoms, alpha atoms, beta atoms, phi^T): the adjoints of the per-atom dense algebra
+        (torch on [T, M, M] arrays, T small) and the library's streaming stage B (dpgp_elbo_grad_psi_ex: Psi2 term on the matrix
+        pipe, Psi1 term with the full adjoint beta^2 Y diag(phi_t) W_t^T, K_uu term)."""
+        x_mean_, s_, x_u_, gat, aat, bat, phit, p2, k_uu, k_inv, b_inv, v, per_t, quad, tr = saved
+        eye = torch.eye(m_, dtype=TORCH_DTYPE, device=device)
+        st = phit.sum(dim=1)[:, None, None]                                  # s_t = sum_d phi_td
+        be = bat[:, None, None]
+        w = ops.matmul(b_inv, v)                                           # [T x M x D]
+        wphi = w * phit[:, None, :]
+        vwphi = torch.sum(v * wphi, dim=(1, 2))                              # sum_d phi_td v_td^T B^-1 v_td
+        gb = -0.5 * st * b_inv - 0.5 * be * be * ops.matmul(wphi, w.transpose(1, 2))
+        x = ops.matmul(ops.matmul(k_inv, p2), k_inv)
+        gk = 0.5 * st * k_inv - 0.5 * st * be * x + gb
+        gp = 0.5 * st * be * k_inv + be * gb
+        wk = gk * (k_uu - GP_DEFAULT_JITTER * eye)
+        g1 = be * be * ops.matmul(y_dev, wphi.transpose(1, 2))             # [T x N x M] adjoint of Psi1
+        pad2 = (0, mp_ - m_, 0, mp_ - m_)
+        dmu, ds, dz, dgam = ops.elbo_grad_psi(None, x_u_, x_mean_, s_, gat, aat,
+                                              torch.nn.functional.pad(gp, pad2).contiguous(),
+                                              torch.nn.functional.pad(wk, pad2).contiguous(), None,
+                                              prec='mixed_patch' if precision == 'f64' else 'mixed',
+                                              g_psi1=torch.nn.functional.pad(g1, (0, mp_ - m_)).contiguous())
+        s_k, s_p = wk.sum(dim=(1, 2)), (gp * p2).sum(dim=(1, 2))
+        s_gbp = (gb * p2).sum(dim=(1, 2))
+        stv = st[:, 0, 0]
+        d_alpha = -0.5 * bat * n_ * stv + (s_k + 2.0 * s_p + bat * bat * vwphi) / aat
+        d_beta = stv * (0.5 * n_ / bat + 0.5 * (tr - aat * n_)) - 0.5 * torch.sum(phit * yy[None, :], dim=1) \
+            + bat * vwphi + s_gbp
+        d_phit = per_t[:, None] - 0.5 * bat[:, None] * yy[None, :] + 0.5 * quad
+        return dmu, ds, dz, dgam, d_alpha, d_beta, d_phit
+
+    class _FHatT(torch.autograd.Function):
+        """f_hat as a differentiable function of (x_mean, S, x_u, gamma / alpha / beta atoms, phi^T) for torch autograd (the
+        cross-check path of the gradients, DPGP_T_AUTOGRAD=1, and the objective's graph): _fhat_forward / _fhat_backward."""
+
+        @staticmethod
+        def forward(ctx, x_mean_, s_, x_u_, gat, aat, bat, phit):
+            f_hat, saved = _fhat_forward(x_mean_, s_, x_u_, gat, aat, bat, phit, for_backward=any(ctx.needs_input_grad))
+            ctx.save_for_backward(*[a for a in saved if a is not None])
+            ctx.with_inverses = saved[9] is not None
+            return f_hat
+
+        @staticmethod
+        def backward(ctx, g_out):
+            assert ctx.with_inverses
+            return tuple(g_out * g for g in _fhat_backward(ctx.saved_tensors))
 
     def _dp_objective(phi, g1, g2, w1, w2):
         """-ELBO of the DP (dirichlet_process.py:64-88) as a function of its arguments (for autograd)."""
@@ -824,8 +842,9 @@ def dp_gp_lvm_t(y_train,
             return _finish_fused().clone()
         return _exchange(graph['out'].clone())              # (the all-reduce of a sharded model runs eagerly behind the replay)
 
-    def _local_flat():
-        """This rank's packed gradient (all raw variables, then the trouble flag) — everything in front of the exchange."""
+    def _local_flat_autograd():
+        """This rank's packed gradient (all raw variables, then the trouble flag) — everything in front of the exchange — by torch
+        autograd over the whole objective (~540 launches: the DP / KL / prior terms and their derivatives are ~400 of them)."""
         leaves = {k: v.detach().clone().requires_grad_(True) for k, v in raw_vars.items()}
         terms = _objective_of(leaves)
         # sharded: this rank's share of the objective = -(local f_hat) + (replicated terms) / world; the shares sum to it
@@ -835,6 +854,53 @@ def dp_gp_lvm_t(y_train,
         flat = torch.cat([g.reshape(-1) for g in grads] + [torch.zeros(1, dtype=TORCH_DTYPE, device=device)])
         # trouble flag (failed factorisation / non-finite local gradient), reduced with the gradients: a collective decision
         flat[-1] = ((last_info[0] != 0) | ~torch.isfinite(flat[:-1]).all()).to(TORCH_DTYPE)
+        return flat
+
+    hbuf = {}
+
+    def _local_flat():
+        """The same with the model-level ends in the HIP library: dpgp_model_prepare_t (softplus / softmax transforms, phi), f_hat and
+        its derivatives with respect to (x_mean, S, x_u, atoms, phi) from the library's operators (_fhat_forward / _fhat_backward),
+        dpgp_model_backward_t (chain rule to the raw variables, KL, DP objective, hyper-prior): ~110 launches instead of ~540.
+        Sharded: the replicated terms are added on rank 0 only (add_constants); the ranks' packed gradients sum to the gradient."""
+        if os.environ.get('DPGP_T_AUTOGRAD', '0') == '1':
+            return _local_flat_autograd()
+        lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+        r = dp_model.raw
+        t_, q_ = truncation_level, num_latent_dims
+        if not hbuf:
+            f64 = dict(dtype=TORCH_DTYPE, device=device)
+            hbuf.update(s=torch.empty((n_, q_), **f64), phi=torch.empty((d_, t_), **f64), atoms=torch.empty(t_ * q_ + 2 * t_, **f64),
+                        scal=torch.zeros(_lib.lib().dpgp_model_scal_count(d_), **f64))
+        with torch.no_grad():
+            _lib.check(lib.dpgp_model_prepare_t(
+                d_, t_, q_, n_, d_lo, mask_size, r['logits'].data_ptr(), gamma_atoms_raw.data_ptr(), sig_var_atoms_raw.data_ptr(),
+                beta_atoms_raw.data_ptr(), x_var_raw.data_ptr(), r['gamma_1'].data_ptr(), r['gamma_2'].data_ptr(), r['w'].data_ptr(),
+                s_1, s_2, 1 if rank == 0 else 0, hbuf['s'].data_ptr(), hbuf['phi'].data_ptr(), hbuf['atoms'].data_ptr(),
+                hbuf['scal'].data_ptr(), st), 'dpgp_model_prepare_t')
+            at = hbuf['atoms']
+            gat, aat, bat = at[:t_ * q_].view(t_, q_), at[t_ * q_:t_ * q_ + t_], at[t_ * q_ + t_:]
+            _, saved = _fhat_forward(x_mean, hbuf['s'], x_u, gat, aat, bat, hbuf['phi'].t().contiguous())
+            dmu, ds, dz, dgam, d_alpha, d_beta, d_phit = _fhat_backward(saved)
+            dab = torch.stack([d_alpha, d_beta], dim=1).contiguous()
+            dphi = d_phit.t().contiguous()
+            sizes = {k: v.numel() for k, v in raw_vars.items()}
+            flat = torch.zeros(sum(sizes.values()) + 1, dtype=TORCH_DTYPE, device=device)
+            parts, o = {}, 0
+            for k, nel in sizes.items():
+                parts[k] = flat[o:o + nel]
+                o += nel
+            rows = r['logits'].shape[0]
+            _lib.check(lib.dpgp_model_backward_t(
+                d_, t_, q_, n_, m_, d_lo, mask_size, rows, r['logits'].data_ptr(), gamma_atoms_raw.data_ptr(),
+                sig_var_atoms_raw.data_ptr(), beta_atoms_raw.data_ptr(), x_var_raw.data_ptr(), r['gamma_1'].data_ptr(),
+                r['gamma_2'].data_ptr(), r['w'].data_ptr(), x_mean.data_ptr(), hbuf['phi'].data_ptr(), s_1, s_2, 1 if rank == 0 else 0,
+                dmu.contiguous().data_ptr(), ds.contiguous().data_ptr(), dz.contiguous().data_ptr(), dgam.contiguous().data_ptr(),
+                dab.data_ptr(), dphi.data_ptr(), parts['x_mean'].data_ptr(), parts['x_var'].data_ptr(), parts['x_u'].data_ptr(),
+                parts['dp_logits'].data_ptr(), parts['dp_gamma_1'].data_ptr(), parts['dp_gamma_2'].data_ptr(), parts['dp_w'].data_ptr(),
+                parts['gamma_atoms'].data_ptr(), parts['alpha_atoms'].data_ptr(), parts['beta_atoms'].data_ptr(), st),
+                'dpgp_model_backward_t')
+            flat[-1] = ((last_info[0] != 0) | ~torch.isfinite(flat[:-1]).all()).to(TORCH_DTYPE)
         return flat
 
     grad_graph = {}

@@ -307,6 +307,17 @@ int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offset, int mas
                         const double *df_dgamma, const double *df_dalpha_beta, double *d_x_mean, double *d_s_raw,
                         double *d_x_u, double *d_logits, double *d_g1_raw, double *d_g2_raw, double *d_w_raw,
                         double *d_gamma_atoms_raw, double *d_alpha_atoms_raw, double *d_beta_atoms_raw, void *stream);
+/* the same for the over-T model dp_gp_lvm_t (reference src/models/dp_gp_lvm.py:513-676: the kernel batch is the T atoms, phi enters f_hat
+ * directly): df_dgamma_atoms [T][Q] and df_dalpha_beta_atoms [T][2] are d f_hat / d (softplus'd atoms) themselves, df_dphi [D][T] is
+ * d f_hat / d phi of the D output dims on this GPU.  Everything else as dpgp_model_backward. */
+int dpgp_model_backward_t(int D, int T, int Q, int N, int M, int d_offset, int mask_size, int logits_rows, const double *logits,
+                          const double *gamma_atoms_raw, const double *alpha_atoms_raw, const double *beta_atoms_raw,
+                          const double *s_raw, const double *g1_raw, const double *g2_raw, const double *w_raw,
+                          const double *x_mean, const double *phi, double s1, double s2, int add_constants, const double *df_dmu,
+                          const double *df_ds, const double *df_dz, const double *df_dgamma_atoms,
+                          const double *df_dalpha_beta_atoms, const double *df_dphi, double *d_x_mean, double *d_s_raw,
+                          double *d_x_u, double *d_logits, double *d_g1_raw, double *d_g2_raw, double *d_w_raw,
+                          double *d_gamma_atoms_raw, double *d_alpha_atoms_raw, double *d_beta_atoms_raw, void *stream);
 int dpgp_model_pack(int D, const double *fhat, const double *scal, double *pack, void *stream);
 int dpgp_model_finalize(const double *pack, const double *kl, const double *hyper, double *out, void *stream);
 
