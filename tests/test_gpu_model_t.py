@@ -129,10 +129,11 @@ def test_over_t_trains_faster_than_over_d_where_t_is_much_smaller_than_d(dev):
     """The reference's only performance assertion (test/unittests/dpgplvm_unitttests.py:460-576): the over-T model's training loop
     is the faster one — checked there by wall-clock over 5 000 Adam iterations of both models from the same start, where the two
     objectives coincide (:547-548).  Here: BASELINE config 3 (N = 2000, D = 512, M = 128, Q = 10, T = 8), same start, objectives
-    equal, then optimise() iterations timed after a warm-up (mixed precision, the benchmark's arithmetic; measured 3.6 ms against
-    6.9 ms).  At the reference test's own tiny shape (N = 200, D = 22, T = 20: as many atoms as output dims) the order is the other
-    way round in this build — the over-T backward pass is still composed of ~540 short launches (2.4 ms from a HIP graph) while the
-    over-D step is one fused call (0.8 ms): scratch/time_t_vs_d.py, DESIGN.md section 7.2."""
+    equal, then optimise() iterations timed after a warm-up (mixed precision, the benchmark's arithmetic; measured 2.3 ms against
+    6.9 ms).  At the reference test's own tiny shape (N = 200, D = 22, T = 20: as many atoms as output dims, i.e. the same number of
+    Psi2 statistics in both models) the two are launch-latency-bound and level in the reference's fp64 (1.41 against 1.41 ms per
+    optimise() iteration), and the over-D model's one-call step is ahead in mixed precision (0.81 against 1.44 ms) — the over-T
+    backward pass is ~110 short launches of library operators: scratch/time_t_vs_d.py, DESIGN.md section 7.2."""
     import time
     from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm, dp_gp_lvm_t
     from dp_gp_lvm_amd.utils.synthetic import make_problem
