@@ -172,12 +172,17 @@ extern "C" int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *al
 // factors are used as they are, and part 1 of the pair-tile form (images of the observations, pass 1) has already run on this
 // workspace (elbo_run with pgws).
 struct GradPsiWs { unsigned char *consts; double *part, *ws1, *stage; unsigned char *pgws; };
-static GradPsiWs grad_psi_ws(int D, int N, int M, int Q, unsigned char *ws) {
+// patch-form partials of the Psi2 term: only where that form can run (asked for, or no pair-tile form: Q > 20)
+static bool grad_psi_needs_patch(int M, int Q, bool patch_form) {
+    return patch_form || !psi2_pgrad_supported(M, Q) || getenv("DPGP_GRAD_PATCH");
+}
+static GradPsiWs grad_psi_ws(int D, int N, int M, int Q, unsigned char *ws, bool patch_form) {
     GradPsiWs W;
     const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
-    W.consts = ws + dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
+    W.consts = ws + dpgp_align256(psi_grad_ws_bytes_kuu(D, M, Q));
     W.part = reinterpret_cast<double *>(W.consts + dpgp_align256(psi2_consts_bytes(M, Q)));
-    W.ws1 = reinterpret_cast<double *>((unsigned char *)W.part + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)));
+    W.ws1 = reinterpret_cast<double *>((unsigned char *)W.part +
+                                       (grad_psi_needs_patch(M, Q, patch_form) ? dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)) : 0));
     W.stage = reinterpret_cast<double *>((unsigned char *)W.ws1 + dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)));
     W.pgws = reinterpret_cast<unsigned char *>(W.stage) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
     return W;
@@ -199,7 +204,7 @@ static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, 
                                     d_mu, d_s, d_z, d_gamma, fast ? 0 : 1, st);
         if (rc != DPGP_OK || !fast) return rc;
     }
-    const GradPsiWs W = grad_psi_ws(D, N, M, Q, ws);
+    const GradPsiWs W = grad_psi_ws(D, N, M, Q, ws, patch_form);
     const unsigned char *consts = fwd_consts ? fwd_consts : W.consts;
     if (!fwd_consts && (rc = launch_psi2_consts<double>(z, M, Q, W.consts, st)) != DPGP_OK) return rc;
     if (big) {                                               // K_uu term for any M (partials in the plain kernel's workspace)
@@ -225,15 +230,17 @@ static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, 
 // Backward pass, stage B (grad.hip): the second streaming pass over the observations.
 extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes_ex(int D, int N, int M, int Q, int prec) {
     if (D <= 0 || N <= 0 || M <= 0 || Q <= 0) return 0;
-    size_t b = dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));
-    if (prec == DPGP_PREC_F64) return b;                             // the plain kernel only
-    if (psi2_grad_supported(M, Q)) {
-        const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
-        b += dpgp_align256(psi2_consts_bytes(M, Q)) + dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)) +
-             dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
-        // pair-tile form of the Psi2 term (Q <= 20): its images and the two passes' results — not when the patch form is asked for
-        if (prec != DPGP_PREC_MIXED_PATCH) b += dpgp_align256(psi2_pgrad_ws_bytes(D, N, M, Q));
-    }
+    if (prec == DPGP_PREC_F64 || !psi2_grad_supported(M, Q) || getenv("DPGP_GRAD_PLAIN"))
+        return dpgp_align256(psi_grad_ws_bytes(D, N, M, Q, nullptr));        // the plain kernel only (with its [D][N][Q] partials)
+    // mixed precisions: the plain kernel carries the K_uu term only; then the psi2 constants, the patch-form partials (where that form
+    // can run), the Psi1 term's partials, the reduction stage and the pair-tile form (Q <= 20: its images and the two passes' results —
+    // not when the patch form is asked for)
+    const bool patch = (prec == DPGP_PREC_MIXED_PATCH);
+    const size_t mx = (size_t)Q * (N > D ? (N > M ? N : M) : (D > M ? D : M));
+    size_t b = dpgp_align256(psi_grad_ws_bytes_kuu(D, M, Q)) + dpgp_align256(psi2_consts_bytes(M, Q)) +
+               (grad_psi_needs_patch(M, Q, patch) ? dpgp_align256(sizeof(double) * psi2_grad_part_elems(D, N, M, Q)) : 0) +
+               dpgp_align256(sizeof(double) * psi1_grad_ws_elems(D, N, M, Q)) + dpgp_align256(sizeof(double) * reduce_rows_stage_elems(mx));
+    if (!patch) b += dpgp_align256(psi2_pgrad_ws_bytes(D, N, M, Q));
     return b;
 }
 extern "C" size_t dpgp_elbo_grad_psi_workspace_bytes(int D, int N, int M, int Q) {
@@ -379,7 +386,7 @@ extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int l
     if (!d_gamma) return -30;
     hipStream_t st = (hipStream_t)stream;
     unsigned char *w = (unsigned char *)ws;
-    const GradPsiWs W = grad_psi_ws(D, N, M, Q, (unsigned char *)gws);
+    const GradPsiWs W = grad_psi_ws(D, N, M, Q, (unsigned char *)gws, false);
     int rc = elbo_run<float, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums, info, w,
                                      L, st, exec, nullptr, W.pgws);
     if (rc != DPGP_OK) return rc;

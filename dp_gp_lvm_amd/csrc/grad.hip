@@ -842,6 +842,13 @@ size_t psi_grad_ws_bytes(int D, int N, int M, int Q, int *nsplit_out) {
     const size_t kuu = (size_t)D * M * Q + (size_t)dpgp_ceil_div(M, 64) * D * Q;
     return sizeof(double) * (rows > kuu ? rows : kuu);
 }
+// the same region when only the K_uu term goes through launch_psi_grad (do_psi2 = 0: the mixed-precision stage B) or launch_kuu_grad:
+// no [D][N][Q] partials of dmu / ds (328 MB of the 545 at N = 2000, D = 512, Q = 10), the two-stage reduction of dz behind the partials
+size_t psi_grad_ws_bytes_kuu(int D, int M, int Q) {
+    const size_t a = (size_t)D * M * Q + (size_t)D * Q + reduce_rows_stage_elems((size_t)M * Q);
+    const size_t kuu = (size_t)D * M * Q + (size_t)dpgp_ceil_div(M, 64) * D * Q;
+    return sizeof(double) * (a > kuu ? a : kuu);
+}
 
 template <typename TC>
 int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
@@ -853,8 +860,9 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
     psi_grad_ws_bytes(D, N, M, Q, &ns);
     if (!do_psi2) ns = 1;
     const int nper = 2 * dpgp_ceil_div(dpgp_ceil_div(N, ns), 2);
-    double *dmu_part = ws, *ds_part = dmu_part + (size_t)D * N * Q, *dz_part = ds_part + (size_t)D * N * Q,
-           *dg_part = dz_part + (size_t)D * ns * M * Q;
+    // (K_uu term only: no dmu / ds partials, see psi_grad_ws_bytes_kuu)
+    double *dmu_part = ws, *ds_part = dmu_part + (do_psi2 ? (size_t)D * N * Q : 0), *dz_part = ds_part + (do_psi2 ? (size_t)D * N * Q : 0),
+           *dg_part = dz_part + (size_t)D * ns * M * Q, *kstage = dg_part + (size_t)ns * D * Q;
     const int QPr = 4 * dpgp_ceil_div(Q, 4);
     const size_t lds = sizeof(TC) * ((size_t)(Mp * Mp > 2 * Q * 128 ? Mp * Mp : 2 * Q * 128) + (size_t)Mp * QPr + PG_RED_ELEMS(Q) + (size_t)12 * Q + 256 + 32 + (size_t)2 * (7 * Q + 2));
     void (*kern)(int, int, int, int, int, const double *, int, const double *, const double *, const double *, const double *,
@@ -879,10 +887,10 @@ int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const 
         DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, D, (const double *)ds_part, ds);
         DPGP_LAUNCH_CHECK();
     }
-    if (!do_psi2 && (size_t)D * N >= (size_t)64 * M) {
-        // K_uu term only: M Q sums over D rows — side by side in 64 chunks through the (unused) dmu partial region instead of
-        // five workgroups walking 512 rows each (69 -> ~10 us at D = 512)
-        const int rc = launch_reduce_rows<double>(mq, mq, D * ns, dz_part, dz, 0, dmu_part, st);
+    if (!do_psi2) {
+        // K_uu term only: M Q sums over D rows — side by side in 64 chunks instead of five workgroups walking 512 rows each
+        // (69 -> ~10 us at D = 512)
+        const int rc = launch_reduce_rows<double>(mq, mq, D * ns, dz_part, dz, 0, kstage, st);
         if (rc != DPGP_OK) return rc;
     } else {
         DPGP_PRELAUNCH(); hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((mq + 255) / 256)), dim3(256), 0, st, mq, D * ns, (const double *)dz_part, dz);

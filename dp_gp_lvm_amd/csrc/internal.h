@@ -112,6 +112,7 @@ int launch_chain_grad(int D, int N, int M, const TP *psi2_part, int ns2, const d
 // second streaming pass: d f_hat / d mu [N,Q], d S [N,Q], d z [M,Q], d gamma [D,Q] from the stage-A adjoints (alpha is a
 // constant factor here: its derivative is complete in stage A).  ws: psi_grad_ws_bytes(D, N, M, Q, nullptr) bytes.
 size_t psi_grad_ws_bytes(int D, int N, int M, int Q, int *nsplit_out);
+size_t psi_grad_ws_bytes_kuu(int D, int M, int Q);     // (K_uu term only: do_psi2 = 0 / launch_kuu_grad)
 template <typename TC>
 int launch_psi_grad(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
                     const double *gamma, const double *alpha, const double *GP, const double *WK, const double *Gv,

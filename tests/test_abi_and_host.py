@@ -141,3 +141,19 @@ def test_synthetic_problem_recipe():
     np.testing.assert_array_equal(ps['y'], p['y'][:, 16:32])
     np.testing.assert_array_equal(ps['gamma'], p['gamma'][16:32])
     np.testing.assert_array_equal(ps['mu'], p['mu'])
+
+
+def test_stage_b_workspace_is_sized_for_the_form_that_runs():
+    """dpgp_elbo_grad_psi_workspace_bytes_ex (host-only): the images and results of the pair-tile form (~2 GB at BASELINE config 3)
+    are part of the workspace only for the precisions that run it; the patch form asked for explicitly (the training configuration
+    behind an fp64 forward pass) stays under 0.5 GB there; fp64 needs the plain kernel's partials only; the query without a precision
+    is the largest of them."""
+    from dp_gp_lvm_amd import _lib
+    l = _lib.lib()
+    n, d, m, q = 2000, 512, 128, 10
+    size = {p: int(l.dpgp_elbo_grad_psi_workspace_bytes_ex(d, n, m, q, _lib.PREC[p])) for p in ('mixed', 'mixed_patch', 'mixed_fast', 'f64')}
+    assert size['mixed_patch'] < 0.5e9 < size['mixed'] == size['mixed_fast']
+    assert size['f64'] < size['mixed_patch']
+    assert int(l.dpgp_elbo_grad_psi_workspace_bytes(d, n, m, q)) == max(size.values())
+    # BASELINE config 4 (M = 512, Q = 20: the pair-tile form with two feature blocks): no patch-form partials beside it
+    assert int(l.dpgp_elbo_grad_psi_workspace_bytes_ex(256, 10000, 512, 20, _lib.PREC['mixed'])) < 30e9
