@@ -38,6 +38,9 @@ SIGNATURES = {
     'dpgp_elbo_grad_chain': (_i, [_i, _i, _i, _i, _vp, _vp, _d, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dpgp_elbo_grad_psi_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'dpgp_elbo_grad_psi_workspace_bytes_ex': (_sz, [_i, _i, _i, _i, _i]),
+    'dpgp_elbo_fhat_step': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    'dpgp_elbo_grad_psi_step': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp, _vp,
+                                     _vp, _vp, _vp]),
     'dpgp_elbo_step': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp,
                             _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dpgp_elbo_grad_psi': (_i, [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp,

@@ -94,7 +94,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     // the same exponentials and does not depend on the adjoints (psi2_pairs_grad.hip) — no psi2 dispatch here, the K_uu branch is
     // a launch of its own, and the chain reads ONE slab
     const bool step = pgws != nullptr;
-    if (step && !(pairs_psi2 && psi2_pgrad_supported(M, Q) && dpgp_round_up(M, 16) <= 128)) return -30;
+    if (step && !(pairs_psi2 && psi2_pgrad_supported(M, Q))) return -30;
     const bool fused_k = !step && (algo != DPGP_ALGO_PLAIN) && (!f16_psi2 || la_chain_k_resident(M, (int)sizeof(TL))) &&
                          !getenv("DPGP_UNFUSED_K");      // (experiments only)
     // M > 128 in fp64 with a matrix per compute unit: the persistent-workgroup chain (chain_big.hip); its K_uu side runs here
@@ -124,7 +124,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     if (big && lb_out) return -30;
     if constexpr (sizeof(TL) == 8) {
         if (big)
-            return launch_chain_big_b<TP>(D, N, M, p2, L.ns2, vpart, L.ns1, alpha, beta, yy, ik, terms, info,
+            return launch_chain_big_b<TP>(D, N, M, p2, step ? 1 : L.ns2, vpart, L.ns1, alpha, beta, yy, ik, terms, info,
                                           reinterpret_cast<double *>(ws + L.off_guard), reinterpret_cast<double *>(la), st, klp,
                                           sums, ex ? (const double *)ex->model_scal : nullptr,
                                           ex ? (double *)ex->model_pack : nullptr, ex ? (double *)ex->model_out : nullptr);
@@ -398,6 +398,73 @@ extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int l
     if (rc != DPGP_OK) return rc;
     return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, nullptr, false, (unsigned char *)gws, d_mu,
                           d_s, d_z, d_gamma, st, w + L.off_pc, reinterpret_cast<const float *>(w + L.off_sc),
+                          reinterpret_cast<const float *>(w + L.off_p2), prec == DPGP_PREC_MIXED_FAST ? 1 : 0);
+}
+
+// The two halves of the step as entry points of their own (M > 128: stage A between them is composed on the host side):
+// dpgp_elbo_fhat_step = dpgp_elbo_fhat_ex in mixed precision with Psi2 out of pass 1 of stage B (gws: the stage-B workspace, which
+// keeps that pass's results); afterwards the forward workspace holds ONE Psi2 slab (dpgp_elbo_workspace_layout's count does not apply).
+extern "C" int dpgp_elbo_fhat_step(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                                   const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
+                                   double *terms, double *sums, int *info, void *ws, size_t ws_bytes, void *gws, size_t gws_bytes,
+                                   void *stream, const dpgp_exec_t *exec) {
+    if (D <= 0) return -1;
+    if (N <= 0) return -2;
+    if (M <= 0) return -3;
+    if (Q <= 0 || Q > DPGP_MAX_Q || !psi2_pgrad_supported(M, Q)) return -4;
+    if (!y) return -5;
+    if (ldy < D) return -6;
+    if (!z) return -7;
+    if (!mu) return -8;
+    if (!s) return -9;
+    if (!gamma) return -10;
+    if (!alpha) return -11;
+    if (!beta) return -12;
+    if (!(jitter >= 0.0)) return -13;
+    if (!terms) return -14;
+    if (!sums) return -15;
+    if (!info) return -16;
+    if (!ws) return -17;
+    const ElboLayout L = elbo_layout(D, N, M, Q, DPGP_PREC_MIXED);
+    if (ws_bytes < L.total) return -18;
+    if (!gws) return -19;
+    if (gws_bytes < dpgp_elbo_grad_psi_workspace_bytes(D, N, M, Q)) return -20;
+    const GradPsiWs W = grad_psi_ws(D, N, M, Q, (unsigned char *)gws, false);
+    return elbo_run<float, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums, info,
+                                   (unsigned char *)ws, L, (hipStream_t)stream, exec, nullptr, W.pgws);
+}
+// ... and the rest of stage B after dpgp_elbo_fhat_step on the same two workspaces (prec: DPGP_PREC_MIXED or DPGP_PREC_MIXED_FAST)
+extern "C" int dpgp_elbo_grad_psi_step(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
+                                       const double *s, const double *gamma, const double *alpha, const double *g_psi2,
+                                       const double *w_kuu, const double *g_v, int prec, void *ws, size_t ws_bytes, void *gws,
+                                       size_t gws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma, void *stream) {
+    if (D <= 0) return -1;
+    if (N <= 0) return -2;
+    if (M <= 0) return -3;
+    if (Q <= 0 || Q > DPGP_MAX_Q || !psi2_pgrad_supported(M, Q)) return -4;
+    if (!y) return -5;
+    if (ldy < D) return -6;
+    if (!z) return -7;
+    if (!mu) return -8;
+    if (!s) return -9;
+    if (!gamma) return -10;
+    if (!alpha) return -11;
+    if (!g_psi2) return -12;
+    if (!w_kuu) return -13;
+    if (!g_v) return -14;
+    if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_MIXED_FAST) return -15;
+    if (!ws) return -16;
+    const ElboLayout L = elbo_layout(D, N, M, Q, DPGP_PREC_MIXED);
+    if (ws_bytes < L.total) return -17;
+    if (!gws) return -18;
+    if (gws_bytes < dpgp_elbo_grad_psi_workspace_bytes(D, N, M, Q)) return -19;
+    if (!d_mu) return -20;
+    if (!d_s) return -21;
+    if (!d_z) return -22;
+    if (!d_gamma) return -23;
+    unsigned char *w = (unsigned char *)ws;
+    return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, nullptr, false, (unsigned char *)gws, d_mu,
+                          d_s, d_z, d_gamma, (hipStream_t)stream, w + L.off_pc, reinterpret_cast<const float *>(w + L.off_sc),
                           reinterpret_cast<const float *>(w + L.off_p2), prec == DPGP_PREC_MIXED_FAST ? 1 : 0);
 }
 

@@ -155,11 +155,13 @@ def dp_gp_lvm(y_train,
 
     # one training step through dpgp_elbo_step (mixed precision, M <= 128, Q <= 20: DESIGN.md section 7.1): the forward's psi2 dispatch is
     # replaced by the first pass of stage B (DPGP_FUSED_STEP=0: the three separate calls, e.g. for bench.py's per-stage breakdown)
-    fused_step = (precision == 'mixed' and stage_b_precision in ('mixed', 'mixed_fast') and psi_algo == 'auto' and
-                  ops.elbo_step_supported(num_inducing_points, num_latent_dims) and os.environ.get('DPGP_FUSED_STEP', '1') != '0')
+    step_ok = (precision == 'mixed' and stage_b_precision in ('mixed', 'mixed_fast') and psi_algo == 'auto' and
+               num_latent_dims <= 20 and os.environ.get('DPGP_FUSED_STEP', '1') != '0')
+    fused_step = step_ok and ops.elbo_step_supported(num_inducing_points, num_latent_dims)
+    split_step = step_ok and not fused_step            # (M > 128: the two halves of the step around the host-composed stage A)
     step_state = {}
 
-    def evaluate(events=None, out=None, _local_part_only=False, _step=False):
+    def evaluate(events=None, out=None, _local_part_only=False, _step=False, _half_step=False):
         """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior).
         Five launches: prepare, front (KL, y'y, K_uu tiles, operand constants, pair factors), psi1T_y,
         psi2 (+ the K_uu tasks), chain_b (+ the final reduction: sum, pack, finalize); D sharded: the all-reduce and the
@@ -175,9 +177,12 @@ def dp_gp_lvm(y_train,
             buf['phi'].data_ptr(), buf['scal'].data_ptr(), st), 'dpgp_model_prepare')
         red = buf['red']
         # single GPU: the last kernel of the fused ELBO also packs and finalises; sharded: it packs, then one all-reduce
-        if _step:
-            if 'buf' not in step_state:
-                step_state['buf'] = ops.ElboStepBuffers(d_local, num_samples, num_inducing_points, num_latent_dims, device)
+        if (_step or _half_step) and 'buf' not in step_state:
+            step_state['buf'] = ops.ElboStepBuffers(d_local, num_samples, num_inducing_points, num_latent_dims, device)
+        if _half_step:
+            ops.elbo_fhat_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'], workspace, step_state['buf'],
+                               jitter=GP_DEFAULT_JITTER, model_tail=(buf['scal'], red, None if sharded else out))
+        elif _step:
             step_state['grads'] = ops.elbo_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'], workspace,
                                                 step_state['buf'], jitter=GP_DEFAULT_JITTER,
                                                 model_tail=(buf['scal'], red, None if sharded else out),
@@ -239,6 +244,12 @@ def dp_gp_lvm(y_train,
         if fused_step and events is None:
             evaluate(_step=True)
             dmu, ds, dz, dg, dab, _ = step_state['grads']
+        elif split_step and events is None:
+            evaluate(_half_step=True)
+            gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER, z=x_u,
+                                                     gamma=buf['gamma'], psi2_slabs=1)
+            dmu, ds, dz, dg = ops.elbo_grad_psi_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv, workspace,
+                                                     step_state['buf'], stage_b=stage_b_precision)
         else:
             evaluate()
             mark(0)

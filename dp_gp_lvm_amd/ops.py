@@ -385,11 +385,12 @@ class ElboStepBuffers:
         f64 = torch.float64
         mp = 16 * ((m + 15) // 16)
         self.shape = (d, n, m, q)
-        self.gp = torch.empty((d, mp, mp), dtype=f64, device=device)
-        self.wk = torch.empty((d, mp, mp), dtype=f64, device=device)
-        self.gv = torch.empty((d, mp), dtype=f64, device=device)
-        self.dab = torch.empty((d, 2), dtype=f64, device=device)
-        self.info = torch.empty(d, dtype=torch.int32, device=device)
+        if mp <= 128:                                            # (stage A outputs of the one-call step; M > 128: the caller's)
+            self.gp = torch.empty((d, mp, mp), dtype=f64, device=device)
+            self.wk = torch.empty((d, mp, mp), dtype=f64, device=device)
+            self.gv = torch.empty((d, mp), dtype=f64, device=device)
+            self.dab = torch.empty((d, 2), dtype=f64, device=device)
+            self.info = torch.empty(d, dtype=torch.int32, device=device)
         self.nbytes = int(_lib.lib().dpgp_elbo_grad_psi_workspace_bytes_ex(d, n, m, q, _lib.PREC['mixed']))
         self.ws = _ws(self.nbytes, device)
         self.dmu, self.ds = torch.empty((n, q), dtype=f64, device=device), torch.empty((n, q), dtype=f64, device=device)
@@ -420,11 +421,42 @@ def elbo_step(y, z, mu, s, gamma, alpha, beta, workspace, buffers, jitter=1e-8, 
     return (w.terms, w.sums, w.info), (b.dmu, b.ds, b.dz, b.dg, b.dab, b.info)
 
 
-def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None):
+def elbo_fhat_step(y, z, mu, s, gamma, alpha, beta, workspace, buffers, jitter=1e-8, model_tail=None):
+    """The forward half of ``elbo_step`` as a call of its own (dpgp_elbo_fhat_step; any M): as ``elbo_fhat`` in mixed precision, Psi2
+    out of the first pass of stage B, whose results stay in ``buffers.ws`` for ``elbo_grad_psi_step``.  The forward workspace then
+    holds ONE Psi2 slab (``elbo_grad_chain(..., psi2_slabs=1)``)."""
+    import ctypes
+    w, b = workspace, buffers
+    d, n, m, q = w.shape
+    assert b.shape == w.shape and w.prec == 'mixed'
+    assert y.is_cuda and y.dtype == torch.float64 and y.stride(1) == 1 and y.shape == (n, d)
+    w.exec.ev_psi2_begin, w.exec.ev_psi2_end = None, None
+    w.exec.model_scal, w.exec.model_pack, w.exec.model_out = (
+        (None, None, None) if model_tail is None else tuple(None if t_ is None else t_.data_ptr() for t_ in model_tail))
+    _lib.check(_lib.lib().dpgp_elbo_fhat_step(
+        d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(),
+        beta.data_ptr(), float(jitter), w.terms.data_ptr(), w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(), w.nbytes,
+        b.ws.data_ptr(), b.nbytes, _stream(), ctypes.cast(ctypes.pointer(w.exec), ctypes.c_void_p)), 'dpgp_elbo_fhat_step')
+    return w.terms, w.sums, w.info
+
+
+def elbo_grad_psi_step(y, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, workspace, buffers, stage_b='mixed'):
+    """The rest of stage B after ``elbo_fhat_step`` on the same workspace / buffers (dpgp_elbo_grad_psi_step)."""
+    w, b = workspace, buffers
+    d, n, m, q = w.shape
+    _lib.check(_lib.lib().dpgp_elbo_grad_psi_step(
+        d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(),
+        g_psi2.data_ptr(), w_kuu.data_ptr(), g_v.data_ptr(), _lib.PREC[stage_b], w.ws.data_ptr(), w.nbytes, b.ws.data_ptr(), b.nbytes,
+        b.dmu.data_ptr(), b.ds.data_ptr(), b.dz.data_ptr(), b.dg.data_ptr(), _stream()), 'dpgp_elbo_grad_psi_step')
+    return b.dmu, b.ds, b.dz, b.dg
+
+
+def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None, psi2_slabs=None):
     """Backward pass, stage A: adjoints of the per-output dense algebra from the workspace of a finished ``elbo_fhat`` call
     (dp_gp_lvm.py:108-145 differentiated; prec mixed / f64).  M <= 128: one HIP kernel per output dim with B in LDS
     (dpgp_elbo_grad_chain).  M > 128 (needs z and gamma, mixed only downstream): composed here from the library's batched
     Cholesky / triangular solves and plain fp64 GEMMs (``_elbo_grad_chain_large``).
+    psi2_slabs: the number of Psi2 partial slabs the forward evaluation left (1 after ``elbo_fhat_step``; default: the layout's).
     Returns (g_psi2 [D,Mp,Mp], w_kuu [D,Mp,Mp], g_v [D,Mp], d_alpha_beta [D,2], info [D]); see include/dpgp.h."""
     f64 = torch.float64
     d, n, m, q = workspace.shape
@@ -433,7 +465,7 @@ def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None):
     assert alpha.numel() == d and beta.numel() == d
     mp = 16 * ((m + 15) // 16)
     if mp > 128 and z is not None and gamma is not None:
-        return _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma)
+        return _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma, psi2_slabs)
     dev = workspace.ws.device
     gp = torch.empty((d, mp, mp), dtype=f64, device=dev)
     wk = torch.empty((d, mp, mp), dtype=f64, device=dev)
@@ -447,7 +479,7 @@ def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None):
     return gp, wk, gv, dab, info
 
 
-def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma):
+def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma, psi2_slabs=None):
     """Stage A for M > 128 (first version): the same adjoints as chain_grad_kernel (grad.hip), with B^-1 and K^-1 formed
     explicitly from the library's Cholesky factors — L^-1 by dpgp_trsm_batched on the identity, the M x M products as plain
     fp64 GEMMs (the library's strided MFMA kernel, ``matmul`` above), element-wise work in torch.  Reads Psi2, Psi1^T y and y^T y from the
@@ -459,6 +491,7 @@ def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma):
     d, n, m, q = workspace.shape
     dev = workspace.ws.device
     off_p2, ns2, esz, mp, off_v, ns1, off_yy, nyy = workspace.layout[:8]
+    ns2 = ns2 if psi2_slabs is None else int(psi2_slabs)        # (after elbo_fhat_step: one slab)
     raw = workspace.ws
     pdt = torch.float32 if esz == 4 else f64
     p2 = raw[off_p2:off_p2 + esz * ns2 * d * mp * mp].view(pdt).view(ns2, d, mp, mp).sum(dim=0, dtype=f64)[:, :m, :m]

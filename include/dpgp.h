@@ -239,6 +239,18 @@ int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int ldy, const d
                    int *info_grad, void *gws, size_t gws_bytes, double *d_mu, double *d_s, double *d_z, double *d_gamma,
                    void *stream, const dpgp_exec_t *exec);
 
+/* The two halves of dpgp_elbo_step as calls of their own, for M > 128 (stage A is then composed by the caller from dpgp_potrf_batched /
+ * dpgp_trsm_batched / dpgp_gemm_strided_f64, as after dpgp_elbo_fhat_ex): dpgp_elbo_fhat_step = the forward evaluation with Psi2 out of
+ * the first pass of stage B (any M; afterwards the forward workspace holds ONE Psi2 slab: slab count 1 instead of
+ * dpgp_elbo_workspace_layout's), dpgp_elbo_grad_psi_step = the rest of stage B on the same two workspaces. */
+int dpgp_elbo_fhat_step(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
+                        const double *gamma, const double *alpha, const double *beta, double jitter, double *terms, double *sums,
+                        int *info, void *ws, size_t ws_bytes, void *gws, size_t gws_bytes, void *stream, const dpgp_exec_t *exec);
+int dpgp_elbo_grad_psi_step(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu, const double *s,
+                            const double *gamma, const double *alpha, const double *g_psi2, const double *w_kuu, const double *g_v,
+                            int prec, void *ws, size_t ws_bytes, void *gws, size_t gws_bytes, double *d_mu, double *d_s, double *d_z,
+                            double *d_gamma, void *stream);
+
 /* ---- f_hat of the over-T model dp_gp_lvm_t (reference: src/models/dp_gp_lvm.py:608-676; the [T,M,N] x [N,D] contraction at
  * :657-658): T atoms with their own kernel hyper-parameters, every atom coupled to all D columns of y through phit[T,D].
  *   inputs (fp64 device arrays): y[N,ldy], yy[D] = column sums of y^2, z[M,Q], mu[N,Q], s[N,Q], gamma[T,Q], alpha[T], beta[T],
