@@ -187,8 +187,9 @@ def manifold_relevance_determination(views_train, num_latent_dims=GP_LVM_DEFAULT
             for mv in inner:
                 bad = bad | (mv.cholesky_info != 0)
             if bool(bad):
-                raise FloatingPointError('iteration %d: failed Cholesky factorisation or non-finite gradient (precision=%r); '
-                                         'use precision="f64"' % (it, precision))
+                eff = precision or 'f64'                        # (None resolves to the reference's fp64 in the models it builds)
+                raise FloatingPointError('iteration %d: failed Cholesky factorisation or non-finite gradient (precision=%r)%s'
+                                         % (it, eff, '' if eff == 'f64' else '; use precision="f64"'))
             for k, p_ in raw.items():
                 p_.grad = g[k].reshape(p_.shape)
             opt.step()

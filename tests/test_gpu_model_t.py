@@ -159,3 +159,30 @@ def test_over_t_trains_faster_than_over_d_where_t_is_much_smaller_than_d(dev):
         torch.cuda.empty_cache()
     np.testing.assert_allclose(obj['over_t'], obj['over_d'], rtol=1e-6)
     assert ms['over_t'] < ms['over_d'], ms
+
+
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_masked_assignments_fused_composed_and_both_gradient_paths(dev, prec, monkeypatch):
+    """mask_size = 3 (one row of assignment logits per three output dims, reference dirichlet_process.py:39-51): the fused forward
+    (dpgp_model_prepare_t's row mapping (d_offset + d) / mask_size, phi read through strides) against the composed one, and the
+    gradients through the HIP model kernels (dpgp_model_prepare_t / dpgp_model_backward_t, which sums the members of a mask group
+    into its logits row) against torch autograd over the whole objective (DPGP_T_AUTOGRAD=1)."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm_t
+    from dp_gp_lvm_amd.utils.synthetic import make_problem
+    n, d, m, q, t, mask = 120, 12, 40, 3, 4, 3
+    p = make_problem(shape=(n, d, m, q), truncation_level=t, seed=5)
+    logits = np.log(p['phi'])[::mask]                            # [D / mask x T]
+    init = dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=logits, gamma_atoms=p['gamma_atoms'], alpha_atoms=p['alpha_atoms'],
+                beta_atoms=p['beta_atoms'], gamma_1=p['g1'], gamma_2=p['g2'], w_1=p['w1'], w_2=p['w2'])
+    kw = dict(num_latent_dims=q, num_inducing_points=m, truncation_level=t, alpha_prior_params=np.array([p['s1'], p['s2']]),
+              device=dev, initial_values=init, precision=prec, mask_size=mask)
+    mdl = dp_gp_lvm_t(p['y'], **kw)
+    fused = mdl.objective_terms.cpu().numpy()
+    g_hip = {k: v.cpu().numpy().copy() for k, v in mdl.gradients().items()}
+    monkeypatch.setenv('DPGP_FUSED_T', '0')
+    monkeypatch.setenv('DPGP_T_AUTOGRAD', '1')
+    ref = dp_gp_lvm_t(p['y'], **kw)
+    np.testing.assert_allclose(fused, ref.objective_terms.cpu().numpy(), rtol=1e-8 if prec == 'f64' else 2e-6)
+    for k, want in ref.gradients().items():
+        want = want.cpu().numpy()
+        np.testing.assert_allclose(g_hip[k], want, rtol=0, atol=(1e-8 if prec == "f64" else 1e-6) * max(np.abs(want).max(), 1e-12), err_msg=k)   # (the HIP trigamma / digamma series against torch.polygamma: 1e-9)
