@@ -571,13 +571,13 @@ __device__ __forceinline__ void pg_step(pg_f16v &c_nxt, const pg_f16v &c_cur, co
     wl1 = pg_quad(lw[4], lw[5], lw[6], lw[7]);
 }
 
-template <int KS, bool WLO>
+template <int KS, bool WLO, int G>
 __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_kernel(const _Float16 *__restrict__ rimg, int row_per_d,
                                                                    const _Float16 *__restrict__ ximg,
                                                                    const _Float16 *__restrict__ cimg, int col_per_d,
                                                                    float *__restrict__ out, int n_row_tiles, int n_col_tiles,
                                                                    int groups_per_d, int NTb, PgPsi2Out po) {
-    constexpr int NFB = PgCfg<KS>::NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW, NF = PG_FB * NFB;
+    constexpr int NFB = PgCfg<KS>::NFB, NW = PgCfg<KS>::NW, NF = PG_FB * NFB;
     constexpr int PIECES = KS + 4 * NFB, TILE_BYTES = 1024 * PIECES;   // LDS bytes of one row tile: K-steps of the exponent operand, then the features
     typedef PgSched<KS, NFB, WLO> S;
     constexpr int LA = G == 1 ? 2 : 1;                         // row tiles between an LDS read of the exponent operand and its row tile
@@ -1046,11 +1046,44 @@ static PgLayout pg_layout(int D, int N, int M, int Q) {
 }
 size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q) { return psi2_pgrad_supported(M, Q) ? pg_layout(D, N, M, Q).total : 0; }
 
+// One pass launch.  Resident column tiles per wave: PgCfg<KS>::G, or (KS <= 4, where the registers allow three) the one of {G, 3}
+// that leaves fewer surplus tile slots in the last group of a row — 258 pair tiles: 11 groups of 24 instead of 17 of 16 (fewer
+// steps and a third fewer LDS-DMA pieces per step); 63 observation tiles: 4 groups of 16 rather than 3 of 24.
+template <int KS, bool WLO, int G>
+static int pg_launch_pass_g(int D, const _Float16 *rimg, int row_per_d, const _Float16 *ximg, const _Float16 *cimg, int col_per_d,
+                            float *out, int n_row_tiles, int n_col_tiles, const PgPsi2Out &po, hipStream_t st) {
+    constexpr int NFB = PgCfg<KS>::NFB, NW = PgCfg<KS>::NW;
+    const int NTb = pg_ring_tiles<KS>();
+    const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
+    auto kern = pg_pass_kernel<KS, WLO, G>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DPGP_ERR_LAUNCH;
+    const int groups = dpgp_ceil_div(n_col_tiles, NW * G);
+    const long long nwg = (long long)D * groups;
+    if (nwg > 0x7fffffffLL) return -1;
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles,
+                       groups, NTb, po);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+template <int KS, bool WLO>
+static int pg_launch_pass(int D, const _Float16 *rimg, int row_per_d, const _Float16 *ximg, const _Float16 *cimg, int col_per_d, float *out,
+                          int n_row_tiles, int n_col_tiles, const PgPsi2Out &po, hipStream_t st) {
+    constexpr int G0 = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
+    if constexpr (KS <= 4 && G0 == 2) {
+        const int s2 = dpgp_ceil_div(n_col_tiles, NW * 2) * 2, s3 = dpgp_ceil_div(n_col_tiles, NW * 3) * 3;
+        if (s3 < s2 && !getenv("DPGP_PG_G2"))                      // (DPGP_PG_G2: experiments)
+            return pg_launch_pass_g<KS, WLO, 3>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
+    }
+    return pg_launch_pass_g<KS, WLO, G0>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
+}
+
 // part 1 (does not depend on the adjoints): observation images, pass 1 -> R2 [and Psi2: psi2_part != nullptr]
 template <int KS>
 static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
                               const double *gamma, unsigned char *ws, float *psi2_part, const float *scale, hipStream_t st, bool wlo) {
-    constexpr int NFB = PgCfg<KS>::NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
+    constexpr int NFB = PgCfg<KS>::NFB;
     const PgLayout L = pg_layout(D, N, M, Q);
     const Psi2Consts C = psi2_consts_layout(M, Q);
     int *flag = reinterpret_cast<int *>(ws + L.off_flag);
@@ -1067,22 +1100,11 @@ static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *c
                            flag, (const double *)nullptr, 0);
         DPGP_LAUNCH_CHECK();
     }
-    const int NTb = pg_ring_tiles<KS>();
-    const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
-    // (the pass that also yields Psi2 keeps the lo half of the exponentials whatever the mode: the objective is not a "fast" quantity)
-    auto kern = (wlo || psi2_part) ? pg_pass_kernel<KS, true> : pg_pass_kernel<KS, false>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DPGP_ERR_LAUNCH;
-    const int groups = dpgp_ceil_div(L.PT, NW * G);
-    const long long nwg = (long long)D * groups;
-    if (nwg > 0x7fffffffLL) return -1;
     PgPsi2Out po = {psi2_part, scale, reinterpret_cast<const unsigned *>(consts + C.off_pmap), flag, dpgp_round_up(M, 16), L.Ppad, 2 * Q};
     // rows: the observations of output dim d (cobs, xobs); columns: the pairs (the forward's pair image)
-    DPGP_PRELAUNCH();
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, (const _Float16 *)cobs, 1, (const _Float16 *)xobs, pimg, 0, r2, L.NT,
-                       L.PT, groups, NTb, po);
-    DPGP_LAUNCH_CHECK();
-    return DPGP_OK;
+    // (the pass that also yields Psi2 keeps the lo half of the exponentials whatever the mode: the objective is not a "fast" quantity)
+    if (wlo || psi2_part) return pg_launch_pass<KS, true>(D, cobs, 1, xobs, pimg, 0, r2, L.NT, L.PT, po, st);
+    return pg_launch_pass<KS, false>(D, cobs, 1, xobs, pimg, 0, r2, L.NT, L.PT, po, st);
 }
 
 // part 2: u_dp from the adjoint of Psi2, pair features, pass 2 -> R1, finishing kernels.  scale != nullptr: the forward's
@@ -1092,7 +1114,7 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
                               const double *s, const double *gamma, const double *alpha, const double *GP, const float *scale,
                               const float *psi2, unsigned char *ws, double *dmu, double *ds, double *dz, double *dgamma,
                               hipStream_t st, const double *y, int ldy, const double *Gv, bool wlo) {
-    constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB, G = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
+    constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
     const PgLayout L = pg_layout(D, N, M, Q);
     const Psi2Consts C = psi2_consts_layout(M, Q);
     const int Mp = dpgp_round_up(M, 16);
@@ -1114,21 +1136,13 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(L.Ppad, 256), D), dim3(256), 0, st, L.Ppad, Q, pimg,
                        (const float *)u, (const float *)kap, xpair);
     DPGP_LAUNCH_CHECK();
+    int rc;
     {
-        const int NTb = pg_ring_tiles<KS>();
-        const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
-        auto kern = wlo ? pg_pass_kernel<KS, true> : pg_pass_kernel<KS, false>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DPGP_ERR_LAUNCH;
-        const int groups = dpgp_ceil_div(L.NT, NW * G);
-        const long long nwg = (long long)D * groups;
-        if (nwg > 0x7fffffffLL) return -1;
         PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
         // rows: the pairs (pair image, xpair of output dim d); columns: the observations of output dim d
-        DPGP_PRELAUNCH();
-        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, st, pimg, 0, (const _Float16 *)xpair, (const _Float16 *)cobs, 1, r1, L.PT,
-                           L.NT, groups, NTb, po);
-        DPGP_LAUNCH_CHECK();
+        rc = wlo ? pg_launch_pass<KS, true>(D, pimg, 0, xpair, cobs, 1, r1, L.PT, L.NT, po, st)
+                 : pg_launch_pass<KS, false>(D, pimg, 0, xpair, cobs, 1, r1, L.PT, L.NT, po, st);
+        if (rc != DPGP_OK) return rc;
     }
     const int dcp = dpgp_ceil_div(D, PG_DC_PAIRS), ncp = dpgp_ceil_div(D, dcp);
     DPGP_PRELAUNCH();
@@ -1136,7 +1150,7 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
                                        gamma, (const float *)u, (const float *)r2, tp));
     DPGP_LAUNCH_CHECK();
     const size_t n3 = (size_t)3 * L.P * Q;
-    int rc = launch_reduce_rows<double>(n3, n3, ncp, tp, tt, 0, nullptr, st);
+    rc = launch_reduce_rows<double>(n3, n3, ncp, tp, tt, 0, nullptr, st);
     if (rc != DPGP_OK) return rc;
     DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_gather_dz_kernel, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, z, consts, (const double *)tt, dz);
     DPGP_LAUNCH_CHECK();
@@ -1169,24 +1183,15 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
         DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(Mpad, 256), D), dim3(256), 0, st, Mpad, Q,
                            (const _Float16 *)dimg, (const float *)u1, (const float *)kap1, xm1);
         DPGP_LAUNCH_CHECK();
-        const int NTb = pg_ring_tiles<KS>();
-        const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
-        auto kern = wlo ? pg_pass_kernel<KS, true> : pg_pass_kernel<KS, false>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DPGP_ERR_LAUNCH;
         PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
         // rows: the inducing points (dimg, features xm1 of output dim d); columns: the observations of output dim d -> R1' [d][n][.]
-        int groups = dpgp_ceil_div(L.NT, NW * G);
-        DPGP_PRELAUNCH();
-        hipLaunchKernelGGL(kern, dim3((unsigned)(D * groups)), dim3(64 * NW), lds, st, (const _Float16 *)dimg, 0, (const _Float16 *)xm1,
-                           (const _Float16 *)cobs1, 1, r1p, L.MT, L.NT, groups, NTb, po);
-        DPGP_LAUNCH_CHECK();
+        rc = wlo ? pg_launch_pass<KS, true>(D, dimg, 0, xm1, cobs1, 1, r1p, L.MT, L.NT, po, st)
+                 : pg_launch_pass<KS, false>(D, dimg, 0, xm1, cobs1, 1, r1p, L.MT, L.NT, po, st);
+        if (rc != DPGP_OK) return rc;
         // rows: the observations of output dim d (cobs1, y-weighted features xobs1); columns: the inducing points -> R2' [d][m][.]
-        groups = dpgp_ceil_div(L.MT, NW * G);
-        DPGP_PRELAUNCH();
-        hipLaunchKernelGGL(kern, dim3((unsigned)(D * groups)), dim3(64 * NW), lds, st, (const _Float16 *)cobs1, 1, (const _Float16 *)xobs1,
-                           (const _Float16 *)dimg, 0, r2p, L.NT, L.MT, groups, NTb, po);
-        DPGP_LAUNCH_CHECK();
+        rc = wlo ? pg_launch_pass<KS, true>(D, cobs1, 1, xobs1, dimg, 0, r2p, L.NT, L.MT, po, st)
+                 : pg_launch_pass<KS, false>(D, cobs1, 1, xobs1, dimg, 0, r2p, L.NT, L.MT, po, st);
+        if (rc != DPGP_OK) return rc;
         DPGP_PRELAUNCH();
         PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_m1_kernel<NF, QP_>), dim3(M), dim3(256), 0, st, M, Mpad, Q, D, z, consts, (const float *)u1,
                                            (const float *)r2p, dz));
@@ -1203,7 +1208,6 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
                                        (const float *)kap, (const float *)r1, (const float *)kap1, r1p_, y, ldy, dgamma));
     DPGP_LAUNCH_CHECK();
     const size_t nq = (size_t)N * Q;
-    rc = DPGP_OK;
     // (with the Psi1 term in the sweep nothing has written dmu, ds before: overwrite; otherwise launch_psi1_grad has: add)
     if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dmup, dmu, y ? 0 : 1, nullptr, st);
     if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dsp, ds, y ? 0 : 1, nullptr, st);
