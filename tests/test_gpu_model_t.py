@@ -89,7 +89,12 @@ def test_accessors_and_shapes(dev):
     # the same evaluation replayed from a HIP graph; it reads the variables in place
     g1 = model.objective_terms_graph()
     np.testing.assert_allclose(g1.cpu().numpy(), terms.cpu().numpy(), rtol=1e-12)
+    held = terms.cpu().numpy().copy()
     model.raw['x_mean'].add_(0.05)
+    # a terms tensor the caller holds is not a view of the model's persistent output buffer
+    terms_after = model.objective_terms
+    np.testing.assert_array_equal(terms.cpu().numpy(), held)
+    assert abs(float(terms_after[0]) - float(terms[0])) > 1e-6
     np.testing.assert_allclose(model.objective_terms_graph().cpu().numpy(), model.objective_terms.cpu().numpy(), rtol=1e-12)
     assert abs(float(model.objective_terms_graph()[0]) - float(g1[0])) > 1e-6
 
