@@ -50,6 +50,8 @@ template <int KS> struct PgCfg { static constexpr int NFB = 1, G = PG_G4, NW = P
 template <> struct PgCfg<6> { static constexpr int NFB = 1, G = 2, NW = 8, WPS = 2; };
 template <> struct PgCfg<8> { static constexpr int NFB = 2, G = 1, NW = 8, WPS = 2; };   // (G = 2 spills 130 registers)
 __host__ __device__ inline int pg_nfb(int KS) { return KS >= 8 ? 2 : 1; }
+// a pass result: [column tile][feature f < NF][32 columns]; col = (set * padded columns) + column, padded to tiles of 32
+template <int NF> __device__ __forceinline__ size_t pg_oix(size_t col, int f) { return ((col >> 5) * NF + f) * 32 + (col & 31); }
 
 // position of (feature f < 32 of a block, row rr of a 32-row tile) in the transposed feature image of one (row tile, block,
 // kind): the k-slot order of the second product's operands = the register order the exponent tile arrives in
@@ -68,32 +70,45 @@ __device__ __forceinline__ void pg_put(_Float16 *xt, int f, int rr, float v) {
 }
 
 // ---- the row of the exponent GEMM's A operand for observation n of output dim d (as phase A of psi2_pairs_kernel) --------
-// dst: 8 KS words (16 KS f16 slots); xt != nullptr: also the features a'_q, b_q (the values the slots were split from) of
-// this row (rr within its tile) into the transposed images of its row tile
+// dst: 8 KS words (16 KS f16 slots) in REGISTERS (the loop over the latent dims is unrolled to the most a K-step count holds, so every
+// index is a constant); the features a'_q, b_q (the values the slots were split from) of this row (rr within its tile) go into the
+// transposed images of its row tile.  mu and s of the row are fetched up front — inside the loop every latent dim waited for its own
+// two loads (config 5: 309 of the kernel's microseconds).
 template <int KS>
 __device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const double *__restrict__ mu, const double *__restrict__ s,
-                                           const float *gq, const float *zc, unsigned *dst, _Float16 *xt, int rr,
+                                           const float *gq, const float *zc, unsigned (&dst)[8 * KS], _Float16 *xt, int rr,
                                            float denfac = 2.0f, float half = 1.0f, float xw = 1.0f) {
-    constexpr int SLP = 16 * KS;
+    constexpr int SLP = 16 * KS, QM = (SLP - 2) / 6;              // 6 Q + 2 slots <= 16 KS (the third part of the row constant only where a slot is left)
     bool oor = false;
     float cc = -60000.0f;
+    float svv[QM], mcv[QM];
+#pragma unroll
+    for (int q = 0; q < QM; ++q) {
+        const bool lq = valid && q < Q;
+        svv[q] = lq ? (float)s[(size_t)n * Q + q] : 0.0f;
+        mcv[q] = lq ? (float)mu[(size_t)n * Q + q] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < SLP / 2; ++k) dst[k] = 0u;
     if (valid) {
         cc = 0.0f;
-        for (int q = 0; q < Q; ++q) {
-            const float g = gq[q], sv = (float)s[(size_t)n * Q + q], mc = (float)mu[(size_t)n * Q + q] - zc[q];
-            // Psi2: denfac = 2, half = 1.  Psi1 on the DIAGONAL pairs (s = 2 z', see launch_psi1_pgrad): den = g s + 1 and half the
-            // coefficients — log2 psi1 / alpha = c + sum_q (-8 log2e w1) (s^2 / 64) + (1/2 log2e w1 mu') s
-            const float den = denfac * g * sv + 1.0f, w = g / den;
-            const float a = dpgp_pin(half * (float)(-0.25 * DPGP_LOG2E / PSI2_PAIR_S2_SCALE) * w);
-            const float bb = dpgp_pin(half * (float)DPGP_LOG2E * w * mc);
-            cc -= bb * mc + 0.5f * __builtin_amdgcn_logf(den);
-            const _Float16 ah = (_Float16)a, alo = (_Float16)(a - (float)ah);
-            const _Float16 bh = (_Float16)bb, blo = (_Float16)(bb - (float)bh);
-            const pg_h2 w0 = {ah, ah}, w1 = {alo, bh}, w2 = {bh, blo};
-            dst[3 * q] = __builtin_bit_cast(unsigned, w0);
-            dst[3 * q + 1] = __builtin_bit_cast(unsigned, w1);
-            dst[3 * q + 2] = __builtin_bit_cast(unsigned, w2);
-            if (xt) {                                             // (xw: a per-row weight of the features — y_nd for the Psi1 term)
+#pragma unroll
+        for (int q = 0; q < QM; ++q) {
+            if (q < Q) {
+                const float g = gq[q], sv = svv[q], mc = mcv[q] - zc[q];
+                // Psi2: denfac = 2, half = 1.  Psi1 on the DIAGONAL pairs (s = 2 z', see launch_psi1_pgrad): den = g s + 1 and half the
+                // coefficients — log2 psi1 / alpha = c + sum_q (-8 log2e w1) (s^2 / 64) + (1/2 log2e w1 mu') s
+                const float den = denfac * g * sv + 1.0f, w = g / den;
+                const float a = dpgp_pin(half * (float)(-0.25 * DPGP_LOG2E / PSI2_PAIR_S2_SCALE) * w);
+                const float bb = dpgp_pin(half * (float)DPGP_LOG2E * w * mc);
+                cc -= bb * mc + 0.5f * __builtin_amdgcn_logf(den);
+                const _Float16 ah = (_Float16)a, alo = (_Float16)(a - (float)ah);
+                const _Float16 bh = (_Float16)bb, blo = (_Float16)(bb - (float)bh);
+                const pg_h2 w0 = {ah, ah}, w1 = {alo, bh}, w2 = {bh, blo};
+                dst[3 * q] = __builtin_bit_cast(unsigned, w0);
+                dst[3 * q + 1] = __builtin_bit_cast(unsigned, w1);
+                dst[3 * q + 2] = __builtin_bit_cast(unsigned, w2);
+                // (xw: a per-row weight of the features — y_nd for the Psi1 term)
                 pg_put(xt, 2 * q, rr, xw * ((float)ah + (float)alo));
                 pg_put(xt, 2 * q + 1, rr, xw * ((float)bh + (float)blo));
             }
@@ -101,18 +116,26 @@ __device__ __forceinline__ bool pg_obs_row(bool valid, int n, int Q, const doubl
         oor = !(cc >= -8192.0f);                                  // range guard of the f16-split exponent (psi2_pairs.hip)
         cc = fmaxf(cc, -60000.0f) + PG_WSHIFT;
     } else {
-        for (int q = 0; q < 3 * Q; ++q) dst[q] = 0u;
-        if (xt)
-            for (int f = 0; f < 2 * Q; ++f) pg_put(xt, f, rr, 0.0f);
+#pragma unroll
+        for (int q = 0; q < QM; ++q) {
+            if (q < Q) {
+                pg_put(xt, 2 * q, rr, 0.0f);
+                pg_put(xt, 2 * q + 1, rr, 0.0f);
+            }
+        }
     }
     cc = dpgp_pin(cc);
     const _Float16 ch = (_Float16)cc;
     const float r1 = dpgp_pin(cc - (float)ch);
     const _Float16 cm = (_Float16)r1;
     const pg_h2 cw = {ch, cm}, cw2 = {(_Float16)(r1 - (float)cm), (_Float16)0.0f};
-    dst[3 * Q] = __builtin_bit_cast(unsigned, cw);
-    for (int k = 3 * Q + 1; k < SLP / 2; ++k) dst[k] = 0u;
-    if (6 * Q + 2 < SLP) dst[3 * Q + 1] = __builtin_bit_cast(unsigned, cw2);
+    // (the row constant sits behind the last latent dim: a runtime position in the register array — selected, not indexed)
+#pragma unroll
+    for (int q = 0; q <= QM; ++q)
+        if (q == Q) {
+            dst[3 * q] = __builtin_bit_cast(unsigned, cw);
+            if (3 * q + 1 < SLP / 2 && 6 * q + 2 < SLP) dst[3 * q + 1] = __builtin_bit_cast(unsigned, cw2);
+        }
     return oor;
 }
 
@@ -162,24 +185,25 @@ __global__ __launch_bounds__(256) void pg_u_kernel(int M, int Q, int Mp, const d
 }
 
 // the same from the forward's per-pair factors scale[d][p] = alpha_d^2 exp2(beta_dp) (training step: the table exists)
-__global__ __launch_bounds__(256) void pg_u_scale_kernel(int Ppad, int Mp, int Q, const unsigned *__restrict__ pmap,
-                                                         const float *__restrict__ scale, const double *__restrict__ GP,
-                                                         float *__restrict__ u, float *__restrict__ kap,
-                                                         const float *__restrict__ psi2, const double *__restrict__ z,
-                                                         double *__restrict__ dgamma) {
+__global__ __launch_bounds__(1024) void pg_u_scale_kernel(int Ppad, int Mp, int Q, const unsigned *__restrict__ pmap,
+                                                          const float *__restrict__ scale, const double *__restrict__ GP,
+                                                          float *__restrict__ u, float *__restrict__ kap,
+                                                          const float *__restrict__ psi2, const double *__restrict__ z,
+                                                          double *__restrict__ dgamma) {
     // psi2 != nullptr ([D][Mp][Mp], slab 0 of the forward's partial slabs = the column sums of pass 1 with their per-pair factors):
     // the derivative through beta_dp = -1/4 log2e sum_q gamma_dq delta_pq^2 needs only g_dp psi2_dp per pair,
     //     dgamma[d][q] += sum_p -1/4 delta_pq^2 g_dp psi2_dp        (what pg_dgamma_pairs_kernel forms from u_dp and R2's constant feature)
-    __shared__ float red[256];
-    __shared__ double redd[256];
-    const int d = blockIdx.x, t = threadIdx.x;
+    // block = output dim, 1024 threads (a 256-thread block walked 33 dependent trips at M = 128), wave sums, one LDS hand-over
+    __shared__ float red[16];
+    __shared__ double redd[16][DPGP_MAX_Q];
+    const int d = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const double *Gd = GP + (size_t)d * Mp * Mp;
     const float *Pd = psi2 ? psi2 + (size_t)d * Mp * Mp : nullptr;
     float mx = 0.0f;
     double a[DPGP_MAX_Q];
 #pragma unroll
     for (int q = 0; q < DPGP_MAX_Q; ++q) a[q] = 0.0;
-    for (int p = t; p < Ppad; p += 256) {
+    for (int p = t; p < Ppad; p += 1024) {
         const unsigned pm = pmap[p];
         float val = 0.0f;
         if (pm != 0xffffffffu) {
@@ -199,15 +223,21 @@ __global__ __launch_bounds__(256) void pg_u_scale_kernel(int Ppad, int Mp, int Q
         u[(size_t)d * Ppad + p] = val;
         mx = fmaxf(mx, fabsf(val));
     }
-    red[t] = mx;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) red[t] = fmaxf(red[t], red[t + o]);
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wv] = mx;
+    if (Pd) {
+#pragma unroll
+        for (int q = 0; q < DPGP_MAX_Q; ++q)
+            if (q < Q) {
+                const double v = wave_sum(a[q]);
+                if (lane == 0) redd[wv][q] = v;
+            }
     }
+    __syncthreads();
     if (t == 0) {
-        float k = 1.0f;
-        const float m0 = red[0];
+        float k = 1.0f, m0 = 0.0f;
+        for (int w = 0; w < 16; ++w) m0 = fmaxf(m0, red[w]);
         if (m0 > 0.0f && m0 < 3.0e38f) {
             int ex;
             (void)frexpf(m0, &ex);
@@ -216,19 +246,10 @@ __global__ __launch_bounds__(256) void pg_u_scale_kernel(int Ppad, int Mp, int Q
         }
         kap[d] = k;
     }
-    if (Pd) {
-#pragma unroll
-        for (int q = 0; q < DPGP_MAX_Q; ++q) {
-            if (q >= Q) break;
-            __syncthreads();
-            redd[t] = a[q];
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (t < o) redd[t] += redd[t + o];
-                __syncthreads();
-            }
-            if (t == 0) dgamma[(size_t)d * Q + q] += redd[0];
-        }
+    if (Pd && t >= 64 && t - 64 < Q) {
+        double v = 0.0;
+        for (int w = 0; w < 16; ++w) v += redd[w][t - 64];
+        dgamma[(size_t)d * Q + t - 64] += v;
     }
 }
 
@@ -247,34 +268,38 @@ __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const 
                                                             _Float16 *__restrict__ ximg, int NT, int *__restrict__ flag,
                                                             const double *__restrict__ y, int ldy) {
     // y != nullptr: the images of the Psi1 term (den = g s + 1, half coefficients, features weighted by y_nd)
-    constexpr int SLP = 16 * KS, RW = SLP / 2 + 4, NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
+    constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *gq = reinterpret_cast<float *>(smem_raw), *zc = gq + 32;
-    unsigned *rows = reinterpret_cast<unsigned *>(smem_raw + 256);                 // [256][RW]
-    _Float16 *xt = reinterpret_cast<_Float16 *>(rows + 256 * RW);                  // [8 tiles][NFB][2][2][64][8]
+    _Float16 *xt = reinterpret_cast<_Float16 *>(smem_raw + 256);                   // [8 tiles][NFB][2][2][64][8]
     const int d = blockIdx.y, t = threadIdx.x, n0 = 256 * blockIdx.x;
     if (t < 32) {
         gq[t] = (t < Q) ? (float)gamma[(size_t)d * Q + t] : 0.0f;
         zc[t] = reinterpret_cast<const float *>(consts)[t];
     }
     __syncthreads();
+    const int tile0 = n0 / 32, ntl = min(8, NT - tile0);
     {
         _Float16 *xr = xt + (size_t)(t >> 5) * 2048 * NFB;
         const bool valid = n0 + t < N;
         const float xw = (y && valid) ? (float)y[(size_t)(n0 + t) * ldy + d] : 1.0f;
-        const bool oor = pg_obs_row<KS>(valid, n0 + t, Q, mu, s, gq, zc, rows + t * RW, xr, t & 31, y ? 1.0f : 2.0f, y ? 0.5f : 1.0f, xw);
+        unsigned row[8 * KS];
+        const bool oor = pg_obs_row<KS>(valid, n0 + t, Q, mu, s, gq, zc, row, xr, t & 31, y ? 1.0f : 2.0f, y ? 0.5f : 1.0f, xw);
         pg_put(xr, 2 * Q, t & 31, valid ? xw : 0.0f);
         for (int f = 2 * Q + 1; f < NF; ++f) pg_put(xr, f, t & 31, 0.0f);
         if (oor) atomicOr(flag, 1);
+        // the row's 2 KS sixteen-byte pieces straight into the operand-order image: piece (ks, half) of the 32 rows of a tile is a
+        // 512-byte run
+        if ((t >> 5) < ntl) {
+            pg_u4 *cd = reinterpret_cast<pg_u4 *>(cimg) + ((size_t)d * NT + tile0 + (t >> 5)) * KS * 64 + (t & 31);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    cd[ks * 64 + 32 * hf] = (pg_u4){row[8 * ks + 4 * hf], row[8 * ks + 4 * hf + 1], row[8 * ks + 4 * hf + 2], row[8 * ks + 4 * hf + 3]};
+        }
     }
     __syncthreads();
-    const int tile0 = n0 / 32, ntl = min(8, NT - tile0);
-    pg_u4 *cd = reinterpret_cast<pg_u4 *>(cimg) + ((size_t)d * NT + tile0) * KS * 64;
-    for (int e = t; e < ntl * KS * 64; e += 256) {
-        const int lane = e & 63, ks = (e >> 6) % KS, tl = e / (64 * KS);
-        const unsigned *r = rows + (32 * tl + (lane & 31)) * RW + 8 * ks + 4 * (lane >> 5);
-        cd[e] = (pg_u4){r[0], r[1], r[2], r[3]};
-    }
     pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * NT + tile0) * 256 * NFB;
     for (int e = t; e < ntl * 256 * NFB; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
 }
@@ -376,22 +401,17 @@ __global__ __launch_bounds__(256) void pg_finish_m1_kernel(int M, int Mpad, int 
     for (int q = 0; q < QP; ++q) { ta[q] = 0.0; tb[q] = 0.0; }
     for (int d = t; d < D; d += 256) {
         const double ud = (double)u1[(size_t)d * Mpad + m];
-        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r + ((size_t)d * Mpad + m) * NF);
-        float rv[NF];
-#pragma unroll
-        for (int k = 0; k < NF / 4; ++k) {
-            const pg_f4 v = row[k];
-            rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
-        }
+        const float *row = r + pg_oix<NF>((size_t)d * Mpad + m, 0);
 #pragma unroll
         for (int q = 0; q < QP; ++q)
-            if (q < Q && 2 * q + 1 < NF) { ta[q] += ud * (double)rv[2 * q]; tb[q] += ud * (double)rv[2 * q + 1]; }
+            if (q < Q && 2 * q + 1 < NF) { ta[q] += ud * (double)row[64 * q]; tb[q] += ud * (double)row[64 * q + 32]; }
     }
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
-        if (q >= Q) break;
-        const double va = wave_sum(ta[q]), vb = wave_sum(tb[q]);
-        if (lane == 0) { red[wv][2 * q] = va; red[wv][2 * q + 1] = vb; }
+        if (q < Q) {
+            const double va = wave_sum(ta[q]), vb = wave_sum(tb[q]);
+            if (lane == 0) { red[wv][2 * q] = va; red[wv][2 * q + 1] = vb; }
+        }
     }
     __syncthreads();
     if (t < Q) {
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(256) void pg_finish_m1_kernel(int M, int Mpad, int 
 }
 
 // ---- one pass: rows (LDS ring, LDS-DMA copies of an operand-order image and of ximg) x resident column tiles (cimg) --------
-// out[set][column][32 NFB] = sum_rows exp2(E[row, column]) X[row, :].  Pass 1: rows = observations of output dim d, columns =
+// out[set][column tile][32 NFB features][32 columns] (pg_oix) = sum_rows exp2(E[row, column]) X[row, :].  Pass 1: rows = observations of output dim d, columns =
 // pairs; pass 2: rows = pairs, columns = observations of output dim d.  row_per_d / col_per_d: 1 = that operand image is per
 // output dim, 0 = shared (the pair image).
 //
@@ -741,82 +761,113 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
                 po.part[(size_t)d * po.Mp * po.Mp + (size_t)(pm >> 16) * po.Mp + (pm & 0xffffu)] =
                     po.scale[(size_t)d * po.Ppad + p] * (cs * (1.0f / 4096.0f)) + poison;      // (x 2^-PG_WSHIFT)
         }
-        float *o = out + (((size_t)d * n_col_tiles + tile) * 32 + l5) * NF + 4 * half;
+        // feature-major inside a column tile (pg_oix): one store instruction = two 128-byte runs, and the finishing kernels (thread =
+        // column) read every feature as a coalesced run
+        float *o = out + (((size_t)d * n_col_tiles + tile) * NF + 4 * half) * 32 + l5;
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-            for (int vq = 0; vq < 4; ++vq)
-                *reinterpret_cast<pg_f4 *>(o + 32 * fb + 8 * vq) =
-                    (pg_f4){acc[g][fb][4 * vq], acc[g][fb][4 * vq + 1], acc[g][fb][4 * vq + 2], acc[g][fb][4 * vq + 3]};
+            for (int v = 0; v < 16; ++v) o[(32 * fb + 8 * (v >> 2) + (v & 3)) * 32] = acc[g][fb][v];
     }
 }
 
 // ---- finishing, pair side -----------------------------------------------------------------------------------------------
-// thread = pair p, block row = chunk of output dims: partial sums over the chunk's d of
-//   tp[c][0][p][q] = sum_d u_dp R2[2q],  tp[c][1][p][q] = sum_d u_dp R2[2q+1],  tp[c][2][p][q] = sum_d u_dp C_dp gamma_dq  (C = R2[2Q])
-template <int NF, int QP>
+// thread = pair p, blockIdx.y = chunk of output dims, blockIdx.z = block of four latent dims: partial sums over the chunk's d of
+//   tp[c][0][q][p] = sum_d u_dp R2[2q],  tp[c][1][q][p] = sum_d u_dp R2[2q+1],  tp[c][2][q][p] = sum_d u_dp C_dp gamma_dq  (C = R2[2Q])
+// (tp: [chunk][3][Q][P]).  Every load is a coalesced run (pg_oix); two output dims per trip so that their loads are in flight
+// together; four latent dims per thread keep it at a few dozen registers (a thread with all Q of them needed 200).
+template <int NF>
 __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int D, int Ppad, int dchunk,
                                                               const double *__restrict__ gamma, const float *__restrict__ u,
                                                               const float *__restrict__ r2, double *__restrict__ tp) {
-    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    constexpr int QB = 4;
+    __shared__ double gsh[32][QB];
+    const int t = threadIdx.x, p = blockIdx.x * 256 + t, c = blockIdx.y, q0 = QB * blockIdx.z;
     const int P = (int)((long long)M * (M + 1) / 2);
-    if (p >= P) return;
-    double a1[QP], a2[QP], a3[QP];
+    const bool ok = p < P;
+    const int pp = ok ? p : P - 1;
+    double a1[QB], a2[QB], a3[QB];
 #pragma unroll
-    for (int q = 0; q < QP; ++q) { a1[q] = 0.0; a2[q] = 0.0; a3[q] = 0.0; }
+    for (int q = 0; q < QB; ++q) { a1[q] = 0.0; a2[q] = 0.0; a3[q] = 0.0; }
     const int d1 = min(D, (c + 1) * dchunk);
-    for (int d = c * dchunk; d < d1; ++d) {
-        const float ud = u[(size_t)d * Ppad + p] * (1.0f / 4096.0f);          // (x 2^-PG_WSHIFT)
-        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r2 + ((size_t)d * Ppad + p) * NF);
-        float rv[NF];
-#pragma unroll
-        for (int k = 0; k < NF / 4; ++k) {
-            const pg_f4 v = row[k];
-            rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
+    for (int d0 = c * dchunk; d0 < d1; d0 += 32) {
+        const int nd = min(32, d1 - d0);
+        __syncthreads();
+        if (t < nd * QB) {
+            const int dd = t / QB, q = t - dd * QB;
+            gsh[dd][q] = q0 + q < Q ? gamma[(size_t)(d0 + dd) * Q + q0 + q] : 0.0;
         }
-        float cc = 0.0f;
+        __syncthreads();
+        for (int dd = 0; dd < nd; dd += 2) {
+            float ud[2], cc[2], ra[2][QB], rb[2][QB];
 #pragma unroll
-        for (int k = 0; k < NF; ++k) cc = (k == 2 * Q) ? rv[k] : cc;
-        const double uc = (double)ud * (double)cc;
+            for (int k = 0; k < 2; ++k) {
+                const bool on = dd + k < nd;
+                const int d = d0 + (on ? dd + k : dd);
+                ud[k] = on ? u[(size_t)d * Ppad + pp] * (1.0f / 4096.0f) : 0.0f;          // (x 2^-PG_WSHIFT)
+                const float *row = r2 + pg_oix<NF>((size_t)d * Ppad + pp, 0);
+                cc[k] = row[64 * Q];
 #pragma unroll
-        for (int q = 0; q < QP; ++q)
-            if (q < Q && 2 * q + 1 < NF) {
-                a1[q] += (double)ud * (double)rv[2 * q];
-                a2[q] += (double)ud * (double)rv[2 * q + 1];
-                a3[q] += uc * gamma[(size_t)d * Q + q];
+                for (int q = 0; q < QB; ++q) {
+                    const bool lq = q0 + q < Q;
+                    ra[k][q] = lq ? row[64 * (q0 + q)] : 0.0f;
+                    rb[k][q] = lq ? row[64 * (q0 + q) + 32] : 0.0f;
+                }
             }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double udd = (double)ud[k], uc = udd * (double)cc[k];
+                const int dl = dd + k < nd ? dd + k : dd;
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    a1[q] += udd * (double)ra[k][q];
+                    a2[q] += udd * (double)rb[k][q];
+                    a3[q] += uc * gsh[dl][q];
+                }
+            }
+        }
     }
+    if (!ok) return;
     double *o = tp + (size_t)c * 3 * P * Q;
 #pragma unroll
-    for (int q = 0; q < QP; ++q)
-        if (q < Q) {
-            o[(size_t)p * Q + q] = a1[q];
-            o[((size_t)P + p) * Q + q] = a2[q];
-            o[((size_t)2 * P + p) * Q + q] = a3[q];
+    for (int q = 0; q < QB; ++q)
+        if (q0 + q < Q) {
+            o[(size_t)(q0 + q) * P + p] = a1[q];
+            o[((size_t)Q + q0 + q) * P + p] = a2[q];
+            o[((size_t)2 * Q + q0 + q) * P + p] = a3[q];
         }
 }
-// thread = (m, q): dz[m][q] += sum over the pairs that hold m of  ln2 (2 S2 s_pq t[0] + t[1]) -+ 1/2 delta_pq t[2]
+// block = inducing point m, thread = (latent dim q = t % 32, group of the other ends o = t / 32 + 8 i):
+//   dz[m][q] += sum over the pairs that hold m of  ln2 (2 S2 s_pq t[0] + t[1]) -+ 1/2 delta_pq t[2]          (tt: [3][Q][P])
 __global__ __launch_bounds__(256) void pg_gather_dz_kernel(int M, int Q, const double *__restrict__ z,
                                                            const unsigned char *__restrict__ consts,
                                                            const double *__restrict__ tt, double *__restrict__ dz) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= M * Q) return;
-    const int m = e / Q, q = e - m * Q;
+    __shared__ double red[8][32];
+    const int m = blockIdx.x, t = threadIdx.x, q = t & 31, og = t >> 5;
     const size_t P = (size_t)M * (M + 1) / 2;
-    const double c = (double)reinterpret_cast<const float *>(consts)[q];     // (the centring constant the images were built with)
-    const double zm = z[(size_t)m * Q + q];
     double acc = 0.0;
-    for (int o = 0; o < M; ++o) {
-        const int hi = o > m ? o : m, lo = o > m ? m : o;
-        const size_t p = (size_t)hi * (hi + 1) / 2 + lo;
-        const double zo = z[(size_t)o * Q + q];
-        const double sp = (zm - c) + (zo - c);
-        const double d1 = 0.6931471805599453 * (2.0 * (double)PSI2_PAIR_S2_SCALE * sp * tt[p * Q + q] + tt[(P + p) * Q + q]);
-        const double d2 = -0.5 * (zm - zo) * tt[(2 * P + p) * Q + q];      // (delta is antisymmetric in (m, o): one formula for both ends)
-        acc += d1 + d2;
-        if (o == m) acc += d1;
+    if (q < Q) {
+        const double c = (double)reinterpret_cast<const float *>(consts)[q];     // (the centring constant the images were built with)
+        const double zm = z[(size_t)m * Q + q];
+        for (int o = og; o < M; o += 8) {
+            const int hi = o > m ? o : m, lo = o > m ? m : o;
+            const size_t p = (size_t)hi * (hi + 1) / 2 + lo;
+            const double zo = z[(size_t)o * Q + q];
+            const double sp = (zm - c) + (zo - c);
+            const double d1 = 0.6931471805599453 * (2.0 * (double)PSI2_PAIR_S2_SCALE * sp * tt[(size_t)q * P + p] + tt[((size_t)Q + q) * P + p]);
+            const double d2 = -0.5 * (zm - zo) * tt[((size_t)2 * Q + q) * P + p];   // (delta is antisymmetric in (m, o): one formula for both ends)
+            acc += d1 + d2;
+            if (o == m) acc += d1;
+        }
     }
-    dz[e] += acc;
+    red[og][q] = acc;
+    __syncthreads();
+    if (t < Q) {
+        double a = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) a += red[g][t];
+        dz[(size_t)m * Q + t] += a;
+    }
 }
 // block = output dim d: dgamma[d][q] += sum_p -1/4 delta_pq^2 u_dp C_dp
 template <int NF>
@@ -832,7 +883,7 @@ __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int 
     for (int p = t; p < P; p += 256) {
         int m, mp;
         psi2_pair_of(p, m, mp);
-        const double uc = (double)u[(size_t)d * Ppad + p] * (double)r2[((size_t)d * Ppad + p) * NF + 2 * Q] * (1.0 / 4096.0);
+        const double uc = (double)u[(size_t)d * Ppad + p] * (double)r2[pg_oix<NF>((size_t)d * Ppad + p, 2 * Q)] * (1.0 / 4096.0);
 #pragma unroll
         for (int q = 0; q < DPGP_MAX_Q; ++q)
             if (q < Q) {
@@ -842,15 +893,16 @@ __global__ __launch_bounds__(256) void pg_dgamma_pairs_kernel(int M, int Q, int 
     }
 #pragma unroll
     for (int q = 0; q < DPGP_MAX_Q; ++q) {
-        if (q >= Q) break;
-        red[t] = a[q];
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (t < o) red[t] += red[t + o];
+        if (q < Q) {
+            red[t] = a[q];
             __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (t < o) red[t] += red[t + o];
+                __syncthreads();
         }
         if (t == 0) dgamma[(size_t)d * Q + q] += red[0];
         __syncthreads();
+        }
     }
 }
 
@@ -872,103 +924,107 @@ __device__ __forceinline__ void pg_obs_chain_q(double ra, double rb, double rc, 
     as_ += df * g * dden;
     dg += dw * id + df * sv * dden;
 }
-// thread = observation n, block row = chunk of output dims: dmu_part / ds_part [chunk][N][Q] = partial sums over the chunk's d
-// (no cross-thread reduction).  r1p / kap1 / y (optional): the Psi1 term's rows in the same sweep.
-template <int NF, int QP>
-__global__ __launch_bounds__(256) void pg_finish_obs_n_kernel(int N, int Q, int D, int NT, int dchunk,
-                                                              const unsigned char *__restrict__ consts,
-                                                              const double *__restrict__ mu, const double *__restrict__ s,
-                                                              const double *__restrict__ gamma, const float *__restrict__ kap,
-                                                              const float *__restrict__ r1, const float *__restrict__ kap1,
-                                                              const float *__restrict__ r1p, const double *__restrict__ y, int ldy,
-                                                              double *__restrict__ dmu_part, double *__restrict__ ds_part) {
-    __shared__ double gsh[QP];
-    const int t = threadIdx.x, n = blockIdx.x * 256 + t, c = blockIdx.y;
+// four values per lane summed over the 64 lanes of a wave, the value set halved in the first two butterfly steps (7 shuffles instead
+// of 24): lane L returns the total of value L / 16 (the 16 lanes of one value hold copies)
+__device__ __forceinline__ double pg_wave_reduce4(const double (&v)[4], int lane) {
+    const bool u5 = (lane & 32) != 0, u4 = (lane & 16) != 0;
+    const double w0 = (u5 ? v[2] : v[0]) + __shfl_xor(u5 ? v[0] : v[2], 32, 64);
+    const double w1 = (u5 ? v[3] : v[1]) + __shfl_xor(u5 ? v[1] : v[3], 32, 64);
+    double w = (u4 ? w1 : w0) + __shfl_xor(u4 ? w0 : w1, 16, 64);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+    return w;
+}
+// thread = observation n, blockIdx.y = chunk of output dims, blockIdx.z = block of four latent dims.  dmu_part / ds_part
+// [chunk][N][Q] = partial sums over the chunk's d (registers, no cross-thread reduction); dg_part [4 blockIdx.x + wave][D][Q] = the
+// wave's sum over its 64 observations of the d/dgamma_dq terms.  r1p / kap1 / y (optional): the Psi1 term's rows in the same sweep.
+// Every feature of a row is a coalesced run (pg_oix); gamma and the scales of eight output dims at a time through LDS; four latent
+// dims per thread: ~60 registers and five times the workgroups of a thread that carries all Q (246 registers, one wave per SIMD).
+template <int NF>
+__global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D, int NT, int dchunk,
+                                                            const unsigned char *__restrict__ consts,
+                                                            const double *__restrict__ mu, const double *__restrict__ s,
+                                                            const double *__restrict__ gamma, const float *__restrict__ kap,
+                                                            const float *__restrict__ r1, const float *__restrict__ kap1,
+                                                            const float *__restrict__ r1p, const double *__restrict__ y, int ldy,
+                                                            double *__restrict__ dmu_part, double *__restrict__ ds_part,
+                                                            double *__restrict__ dg_part) {
+    constexpr int QB = 4;
+    __shared__ double gsh[8][QB];
+    __shared__ double iksh[8][2];
+    const int t = threadIdx.x, n = blockIdx.x * 256 + t, c = blockIdx.y, q0 = QB * blockIdx.z, lane = t & 63, wv = t >> 6;
     const bool ok = n < N;
     const int nn = ok ? n : N - 1;
-    float mc[QP], sv[QP];
-    double am[QP], as_[QP];
+    double mc[QB], sv[QB], am[QB], as_[QB];
 #pragma unroll
-    for (int q = 0; q < QP; ++q) {
-        mc[q] = q < Q ? (float)(mu[(size_t)nn * Q + q] - (double)reinterpret_cast<const float *>(consts)[q]) : 0.0f;
-        sv[q] = q < Q ? (float)s[(size_t)nn * Q + q] : 1.0f;
+    for (int q = 0; q < QB; ++q) {
+        const bool lq = q0 + q < Q;
+        mc[q] = lq ? mu[(size_t)nn * Q + q0 + q] - (double)reinterpret_cast<const float *>(consts)[q0 + q] : 0.0;
+        sv[q] = lq ? s[(size_t)nn * Q + q0 + q] : 1.0;
         am[q] = 0.0; as_[q] = 0.0;
     }
+    double *dgw = dg_part + ((size_t)(4 * blockIdx.x + wv) * D) * Q;
     const int d1 = min(D, (c + 1) * dchunk);
-    for (int d = c * dchunk; d < d1; ++d) {
+    for (int d0 = c * dchunk; d0 < d1; d0 += 8) {
+        const int nd = min(8, d1 - d0);
         __syncthreads();
-        if (t < QP) gsh[t] = t < Q ? gamma[(size_t)d * Q + t] : 0.0;
+        if (t < nd * QB) {
+            const int dd = t / QB, q = t - dd * QB;
+            gsh[dd][q] = q0 + q < Q ? gamma[(size_t)(d0 + dd) * Q + q0 + q] : 0.0;
+        }
+        if (t >= 64 && t - 64 < nd) {
+            iksh[t - 64][0] = 1.0 / ((double)kap[d0 + t - 64] * 4096.0);
+            iksh[t - 64][1] = r1p ? 0.5 / ((double)kap1[d0 + t - 64] * 4096.0) : 0.0;
+        }
         __syncthreads();
+        for (int dd = 0; dd < nd; ++dd) {
+            const int d = d0 + dd;
+            double dg[QB];
 #pragma unroll
-        for (int src = 0; src < 2; ++src) {
-            if (src && !r1p) break;
-            const float *row = (src ? r1p : r1) + ((size_t)d * NT * 32 + nn) * NF;
-            const double ik = (src ? 0.5 * y[(size_t)nn * ldy + d] : 1.0) / ((double)(src ? kap1 : kap)[d] * 4096.0);
-            const double rc = (double)row[2 * Q] * ik;
-            double dg = 0.0;
+            for (int q = 0; q < QB; ++q) dg[q] = 0.0;
+            // (both sources' loads first)
+            float ra[2][QB], rb[2][QB], rcf[2] = {0.0f, 0.0f};
+            double yv = 0.0;
 #pragma unroll
-            for (int q = 0; q < QP; ++q) {
-                if (q >= Q) break;
-                const float2 ab = *reinterpret_cast<const float2 *>(row + 2 * q);
-                pg_obs_chain_q((double)ab.x * ik, (double)ab.y * ik, rc, gsh[q], (double)mc[q], (double)sv[q], src, am[q], as_[q], dg);
+            for (int src = 0; src < 2; ++src) {
+                if (src && !r1p) break;
+                const float *row = (src ? r1p : r1) + pg_oix<NF>((size_t)d * NT * 32 + nn, 0);
+                rcf[src] = row[64 * Q];
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    const bool lq = q0 + q < Q;
+                    ra[src][q] = lq ? row[64 * (q0 + q)] : 0.0f;
+                    rb[src][q] = lq ? row[64 * (q0 + q) + 32] : 0.0f;
+                }
+                if (src) yv = y[(size_t)nn * ldy + d];
             }
+#pragma unroll
+            for (int src = 0; src < 2; ++src) {
+                if (src && !r1p) break;
+                const double ik = src ? iksh[dd][1] * yv : iksh[dd][0];
+                const double rc = (double)rcf[src] * ik;
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+                    if (q0 + q < Q)
+                        pg_obs_chain_q((double)ra[src][q] * ik, (double)rb[src][q] * ik, rc, gsh[dd][q], mc[q], sv[q], src, am[q], as_[q], dg[q]);
+            }
+            if (!ok) {
+#pragma unroll
+                for (int q = 0; q < QB; ++q) dg[q] = 0.0;
+            }
+            const double tot = pg_wave_reduce4(dg, lane);
+            const int qi = q0 + (lane >> 4);
+            if ((lane & 15) == 0 && qi < Q) dgw[(size_t)d * Q + qi] = tot;
         }
     }
     if (ok) {
 #pragma unroll
-        for (int q = 0; q < QP; ++q)
-            if (q < Q) {
-                dmu_part[((size_t)c * N + n) * Q + q] = am[q];
-                ds_part[((size_t)c * N + n) * Q + q] = as_[q];
+        for (int q = 0; q < QB; ++q)
+            if (q0 + q < Q) {
+                dmu_part[((size_t)c * N + n) * Q + q0 + q] = am[q];
+                ds_part[((size_t)c * N + n) * Q + q0 + q] = as_[q];
             }
     }
-}
-// block = output dim d, threads over the observations: dgamma[d][q] += sum_n (...), ONE block reduction per output dim
-template <int NF, int QP>
-__global__ __launch_bounds__(256) void pg_finish_obs_d_kernel(int N, int Q, int NT, const unsigned char *__restrict__ consts,
-                                                              const double *__restrict__ mu, const double *__restrict__ s,
-                                                              const double *__restrict__ gamma, const float *__restrict__ kap,
-                                                              const float *__restrict__ r1, const float *__restrict__ kap1,
-                                                              const float *__restrict__ r1p, const double *__restrict__ y, int ldy,
-                                                              double *__restrict__ dgamma) {
-    __shared__ double gsh[QP];
-    __shared__ float zc[QP];
-    __shared__ double red[4][QP];
-    const int t = threadIdx.x, d = blockIdx.x, lane = t & 63, wv = t >> 6;
-    if (t < QP) {
-        gsh[t] = t < Q ? gamma[(size_t)d * Q + t] : 0.0;
-        zc[t] = t < Q ? reinterpret_cast<const float *>(consts)[t] : 0.0f;
-    }
-    __syncthreads();
-    double dgq[QP];
-#pragma unroll
-    for (int q = 0; q < QP; ++q) dgq[q] = 0.0;
-    const double ik0 = 1.0 / ((double)kap[d] * 4096.0), ik1 = r1p ? 0.5 / ((double)kap1[d] * 4096.0) : 0.0;
-    for (int n = t; n < N; n += 256) {
-#pragma unroll
-        for (int src = 0; src < 2; ++src) {
-            if (src && !r1p) break;
-            const float *row = (src ? r1p : r1) + ((size_t)d * NT * 32 + n) * NF;
-            const double ik = src ? ik1 * y[(size_t)n * ldy + d] : ik0;
-            const double rc = (double)row[2 * Q] * ik;
-#pragma unroll
-            for (int q = 0; q < QP; ++q) {
-                if (q >= Q) break;
-                const float2 ab = *reinterpret_cast<const float2 *>(row + 2 * q);
-                double am = 0.0, as_ = 0.0;
-                pg_obs_chain_q((double)ab.x * ik, (double)ab.y * ik, rc, gsh[q], mu[(size_t)n * Q + q] - (double)zc[q], s[(size_t)n * Q + q],
-                               src, am, as_, dgq[q]);
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < QP; ++q) {
-        if (q >= Q) break;
-        const double v = wave_sum(dgq[q]);
-        if (lane == 0) red[wv][q] = v;
-    }
-    __syncthreads();
-    if (t < Q) dgamma[(size_t)d * Q + t] += red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
 // a range-guard hit anywhere: the outputs become NaN (never a silently wrong gradient)
@@ -1009,7 +1065,7 @@ template <int KS> static int pg_ring_tiles() {                   // row tiles pe
 #define PG_DC_OBS 64
 struct PgLayout {
     int KS, NF, P, Ppad, NT, PT, nblk_obs, MT;
-    size_t off_u, off_kap, off_flag, off_cobs, off_xobs, off_xpair, off_r2, off_r1, off_tp, off_tt, off_dmup, off_dsp,
+    size_t off_u, off_kap, off_flag, off_cobs, off_xobs, off_xpair, off_r2, off_r1, off_tp, off_tt, off_dmup, off_dsp, off_dgp,
         off_cobs1, off_xobs1, off_dimg, off_xm1, off_r1p, off_r2p, off_u1, off_kap1, total;   // (..1 / ..p: the Psi1 term)
 };
 static PgLayout pg_layout(int D, int N, int M, int Q) {
@@ -1032,6 +1088,7 @@ static PgLayout pg_layout(int D, int N, int M, int Q) {
     L.off_tt = o;    o += dpgp_align256(sizeof(double) * (size_t)3 * L.P * Q);
     L.off_dmup = o;  o += dpgp_align256(sizeof(double) * (size_t)PG_DC_OBS * N * Q);
     L.off_dsp = o;   o += dpgp_align256(sizeof(double) * (size_t)PG_DC_OBS * N * Q);
+    L.off_dgp = o;   o += dpgp_align256(sizeof(double) * (size_t)4 * L.nblk_obs * D * Q);
     L.MT = dpgp_ceil_div(M, 32);
     L.off_cobs1 = o; o += dpgp_align256(h * (size_t)D * L.NT * L.KS * 64 * 8);
     L.off_xobs1 = o; o += dpgp_align256(h * (size_t)D * L.NT * 2048 * nfb);
@@ -1092,7 +1149,7 @@ static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *c
     const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
     if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return DPGP_ERR_LAUNCH;
     {
-        const size_t lds = 256 + sizeof(unsigned) * 256 * (8 * KS + 4) + sizeof(_Float16) * 8 * 2048 * NFB;
+        const size_t lds = 256 + sizeof(_Float16) * 8 * 2048 * NFB;
         auto kern = pg_obs_images_kernel<KS>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
@@ -1128,7 +1185,7 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
     DPGP_PRELAUNCH();
     if (scale)
-        hipLaunchKernelGGL(pg_u_scale_kernel, dim3(D), dim3(256), 0, st, L.Ppad, Mp, Q, reinterpret_cast<const unsigned *>(consts + C.off_pmap),
+        hipLaunchKernelGGL(pg_u_scale_kernel, dim3(D), dim3(1024), 0, st, L.Ppad, Mp, Q, reinterpret_cast<const unsigned *>(consts + C.off_pmap),
                            scale, GP, u, kap, psi2, z, dgamma);
     else
         hipLaunchKernelGGL(pg_u_kernel, dim3(D), dim3(256), 0, st, M, Q, Mp, z, gamma, alpha, GP, u, kap);
@@ -1146,13 +1203,13 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     }
     const int dcp = dpgp_ceil_div(D, PG_DC_PAIRS), ncp = dpgp_ceil_div(D, dcp);
     DPGP_PRELAUNCH();
-    PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_pairs_kernel<NF, QP_>), dim3(dpgp_ceil_div(L.P, 256), ncp), dim3(256), 0, st, M, Q, D, L.Ppad, dcp,
-                                       gamma, (const float *)u, (const float *)r2, tp));
+    hipLaunchKernelGGL((pg_finish_pairs_kernel<NF>), dim3(dpgp_ceil_div(L.P, 256), ncp, dpgp_ceil_div(Q, 4)), dim3(256), 0, st, M, Q, D, L.Ppad, dcp,
+                       gamma, (const float *)u, (const float *)r2, tp);
     DPGP_LAUNCH_CHECK();
     const size_t n3 = (size_t)3 * L.P * Q;
     rc = launch_reduce_rows<double>(n3, n3, ncp, tp, tt, 0, nullptr, st);
     if (rc != DPGP_OK) return rc;
-    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_gather_dz_kernel, dim3(dpgp_ceil_div(M * Q, 256)), dim3(256), 0, st, M, Q, z, consts, (const double *)tt, dz);
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_gather_dz_kernel, dim3(M), dim3(256), 0, st, M, Q, z, consts, (const double *)tt, dz);
     DPGP_LAUNCH_CHECK();
     if (!(scale && psi2)) {          // (training step: formed by pg_u_scale_kernel from Psi2 itself)
         DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_dgamma_pairs_kernel<NF>), dim3(D), dim3(256), 0, st, M, Q, L.Ppad, z, (const float *)u,
@@ -1168,7 +1225,7 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
         float *r2p = reinterpret_cast<float *>(ws + L.off_r2p), *u1 = reinterpret_cast<float *>(ws + L.off_u1);
         const int Mpad = 32 * L.MT;
         {
-            const size_t lds = 256 + sizeof(unsigned) * 256 * (8 * KS + 4) + sizeof(_Float16) * 8 * 2048 * NFB;
+            const size_t lds = 256 + sizeof(_Float16) * 8 * 2048 * NFB;
             auto kern = pg_obs_images_kernel<KS>;
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return DPGP_ERR_LAUNCH;
@@ -1199,14 +1256,13 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     }
     const int dco = dpgp_ceil_div(D, PG_DC_OBS), nco = dpgp_ceil_div(D, dco);
     const float *r1p_ = y ? (const float *)r1p : (const float *)nullptr;
+    double *dgp = reinterpret_cast<double *>(ws + L.off_dgp);
     DPGP_PRELAUNCH();
-    PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_obs_n_kernel<NF, QP_>), dim3(L.nblk_obs, nco), dim3(256), 0, st, N, Q, D, L.NT, dco, consts, mu, s,
-                                       gamma, (const float *)kap, (const float *)r1, (const float *)kap1, r1p_, y, ldy, dmup, dsp));
+    hipLaunchKernelGGL((pg_finish_obs_kernel<NF>), dim3(L.nblk_obs, nco, dpgp_ceil_div(Q, 4)), dim3(256), 0, st, N, Q, D, L.NT, dco, consts, mu, s,
+                       gamma, (const float *)kap, (const float *)r1, (const float *)kap1, r1p_, y, ldy, dmup, dsp, dgp);
     DPGP_LAUNCH_CHECK();
-    DPGP_PRELAUNCH();
-    PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_obs_d_kernel<NF, QP_>), dim3(D), dim3(256), 0, st, N, Q, L.NT, consts, mu, s, gamma,
-                                       (const float *)kap, (const float *)r1, (const float *)kap1, r1p_, y, ldy, dgamma));
-    DPGP_LAUNCH_CHECK();
+    const size_t dq = (size_t)D * Q;
+    rc = launch_reduce_rows<double>(dq, dq, 4 * L.nblk_obs, dgp, dgamma, 1, nullptr, st);
     const size_t nq = (size_t)N * Q;
     // (with the Psi1 term in the sweep nothing has written dmu, ds before: overwrite; otherwise launch_psi1_grad has: add)
     if (rc == DPGP_OK) rc = launch_reduce_rows<double>(nq, nq, nco, dmup, dmu, y ? 0 : 1, nullptr, st);
