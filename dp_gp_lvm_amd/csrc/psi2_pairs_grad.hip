@@ -48,7 +48,12 @@ typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
 #endif
 template <int KS> struct PgCfg { static constexpr int NFB = 1, G = PG_G4, NW = PG_NW4, WPS = PG_WPS4; };
 template <> struct PgCfg<6> { static constexpr int NFB = 1, G = 2, NW = 8, WPS = 2; };
-template <> struct PgCfg<8> { static constexpr int NFB = 2, G = 1, NW = 8, WPS = 2; };   // (G = 2 spills 130 registers)
+#ifndef PG_G8
+#define PG_G8 1
+#define PG_NW8 8
+#define PG_WPS8 2
+#endif
+template <> struct PgCfg<8> { static constexpr int NFB = 2, G = PG_G8, NW = PG_NW8, WPS = PG_WPS8; };   // (G = 2 at two waves per SIMD spills 130 registers)
 __host__ __device__ inline int pg_nfb(int KS) { return KS >= 8 ? 2 : 1; }
 // a pass result: [column tile][feature f < NF][32 columns]; col = (set * padded columns) + column, padded to tiles of 32
 template <int NF> __device__ __forceinline__ size_t pg_oix(size_t col, int f) { return ((col >> 5) * NF + f) * 32 + (col & 31); }
@@ -625,6 +630,41 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const pg_u4 *>(src) + lane, (lds_void *)(base + (size_t)1024 * i), 16, 0, 0);
         }
     };
+    // KS = 8, chunks >= 2 (inside the loop): the same pieces through registers (global_load_dwordx4 at the chunk barrier, ds_write_b128
+    // one row tile later) — an LDS-DMA piece among the loop's matrix instructions costs the issuing wave ~100 cycles, and with G = 1 there
+    // are 16 pieces per row tile and ONE step per row tile to carry them: config 5 4.74 -> 4.58 ms per training step.  KS = 4 (8 pieces
+    // per 2-3 steps): 1.3 % SLOWER through registers (24 more of them), so the DMA stays there.
+    constexpr bool STAGED = KS >= 8 && G == 1;
+    // KS = 8 with G >= 2: ONE register set for the exponent operand — K-step ks of the next row tile is read into the register of K-step
+    // ks right behind the last matrix instruction that reads it (the chain of step G - 2), a whole step ahead of its first use
+    constexpr bool SINGLE_A = KS >= 8 && G >= 2;
+    constexpr int NTB_MAX = (160 * 1024 * NW / (4 * PgCfg<KS>::WPS)) / (3 * 1024 * PIECES), MAXP = STAGED ? (NTB_MAX * PIECES + NW - 1) / NW : 1;
+    pg_u4 stage[MAXP];
+    int st_chunk = -1;
+    auto fill_load = [&](int c) __attribute__((always_inline)) {
+        const int rt0 = c * NTb, npc = min(NTb, n_row_tiles - rt0) * PIECES;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int i = wv + k * NW;
+            if (i < npc) {
+                const int tl = i / PIECES, pc = i - tl * PIECES;
+                const unsigned char *src = pc < KS ? rsrc + ((size_t)(rt0 + tl) * KS + pc) * 1024
+                                                   : xsrc + ((size_t)(rt0 + tl) * NFB * 4 + (pc - KS)) * 1024;
+                stage[k] = reinterpret_cast<const pg_u4 *>(src)[lane];
+            }
+        }
+        st_chunk = c;
+    };
+    auto fill_store = [&]() __attribute__((always_inline)) {
+        const int c = st_chunk, rt0 = c * NTb, npc = min(NTb, n_row_tiles - rt0) * PIECES;
+        unsigned char *base = smem_raw + (size_t)(c % 3) * NTb * TILE_BYTES;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int i = wv + k * NW;
+            if (i < npc) reinterpret_cast<pg_u4 *>(base + (size_t)1024 * i)[lane] = stage[k];
+        }
+        st_chunk = -1;
+    };
     const int n_chunks = (n_row_tiles + NTb - 1) / NTb;
     fill(0);
     if (n_chunks > 1) fill(1);
@@ -679,6 +719,8 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
     // steps in front of this row tile (the two exponent tiles alternate from step to step).
     auto row_tile = [&](auto par, pg_h8 (&a_cur)[KS], pg_h8 (&a_nxt)[KS], int rt) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
+        if constexpr (STAGED)
+            if (st_chunk >= 0) fill_store();                      // (the row tile behind the one that issued the loads)
         if (in_chunk == NTb - LA && chunk + 1 < n_chunks) {
             // LA row tiles in front of the chunk's end: the next chunk is complete in LDS (own pieces: vmcnt, everybody's: barrier),
             // and everybody has left the previous chunk, whose ring slots take the chunk after the next
@@ -687,7 +729,10 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
             __syncthreads();
 #endif
 #ifndef PG_DIAG_NOFILL                                             // (timing experiments only: wrong results)
-            if (chunk + 2 < n_chunks) fill(chunk + 2);
+            if (chunk + 2 < n_chunks) {
+                if constexpr (STAGED) fill_load(chunk + 2);
+                else fill(chunk + 2);
+            }
 #endif
         }
         // ring slot of the row tile LA ahead (behind the last row tile: surplus chains on the last one)
@@ -710,6 +755,9 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
                 if constexpr (g == 0 && j == S::first_of(1)) load_x(x0h, x0l, pos, 0);
                 if constexpr (G == 1) {
                     if constexpr (j == S::first_of(1)) load_a(a_cur, pos_n);
+                } else if constexpr (SINGLE_A) {
+                    if constexpr (g == G - 2 && S::slot(j).kind == 0)
+                        a_cur[S::slot(j).i] = (reinterpret_cast<const pg_h8 *>(smem_raw + (size_t)pos_n * TILE_BYTES) + lane)[S::slot(j).i * 64];
                 } else {
                     if constexpr (g == G - 2 && j == S::first_of(1)) load_a(a_nxt, pos_n);
                 }
@@ -727,10 +775,18 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
     typedef std::integral_constant<int, G & 1> P1;
 #pragma unroll 1
     for (int rt = 0; rt + 1 < n_row_tiles; rt += 2) {          // (pairs: the two operand buffers swap roles without register moves;
-        row_tile(P0{}, a_0, a_1, rt);                             //  a break between the two made the compiler copy the accumulators)
-        row_tile(P1{}, a_1, a_0, rt + 1);
+        if constexpr (SINGLE_A) {                                 //  a break between the two made the compiler copy the accumulators)
+            row_tile(P0{}, a_0, a_0, rt);
+            row_tile(P1{}, a_0, a_0, rt + 1);
+        } else {
+            row_tile(P0{}, a_0, a_1, rt);
+            row_tile(P1{}, a_1, a_0, rt + 1);
+        }
     }
-    if (n_row_tiles & 1) row_tile(P0{}, a_0, a_1, n_row_tiles - 1);
+    if (n_row_tiles & 1) {
+        if constexpr (SINGLE_A) row_tile(P0{}, a_0, a_0, n_row_tiles - 1);
+        else row_tile(P0{}, a_0, a_1, n_row_tiles - 1);
+    }
     // the last step's K-step-1 half
 #pragma unroll
     for (int i = 0; i < 3 * NFB; ++i) {
@@ -1132,6 +1188,14 @@ static int pg_launch_pass(int D, const _Float16 *rimg, int row_per_d, const _Flo
         const int s2 = dpgp_ceil_div(n_col_tiles, NW * 2) * 2, s3 = dpgp_ceil_div(n_col_tiles, NW * 3) * 3;
         if (s3 < s2 && !getenv("DPGP_PG_G2"))                      // (DPGP_PG_G2: experiments)
             return pg_launch_pass_g<KS, WLO, 3>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
+    }
+    if constexpr (KS >= 8 && G0 == 1) {
+        // two resident column tiles per wave (one register set for the exponent operand: 248 registers) halve the ring fills and the LDS
+        // reads per step — about 8 % per step — unless the coarser groups leave that many more surplus tile slots (config 5's 65 pair tiles:
+        // 80 slots instead of 72)
+        const int s1 = dpgp_ceil_div(n_col_tiles, NW), s2 = dpgp_ceil_div(n_col_tiles, NW * 2) * 2;
+        if (s2 * 92 <= s1 * 100 && !getenv("DPGP_PG_G1"))          // (DPGP_PG_G1: experiments)
+            return pg_launch_pass_g<KS, WLO, 2>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
     }
     return pg_launch_pass_g<KS, WLO, G0>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
 }

@@ -25,9 +25,10 @@ cat $O/trace_stats.txt
 mkdir -p $O/keep; cp $O/t/*/*kernel_stats.csv $O/keep/ 2>/dev/null
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/p1 -- python3 $O/run.py $C 2 >> $O/log.txt 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -- python3 $O/run.py $C 2 >> $O/log.txt 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_INSTS_LDS --output-format csv -d $O/p3 -- python3 $O/run.py $C 2 >> $O/log.txt 2>&1
 python3 - > $O/pmc.txt <<PY
 import csv, glob, collections
-for pas in ("p1", "p2"):
+for pas in ("p1", "p2", "p3"):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for f in glob.glob("$O/%s/*/*counter_collection.csv" % pas):
         for r in csv.DictReader(open(f)):
