@@ -105,59 +105,104 @@ __global__ __launch_bounds__(256, 2) void chain_grad_kernel(int D, int N, int M,
     __syncthreads();
     const double vw = block_sum((t < M) ? vv[t] * ww[t] : 0.0, scratch);
     // ---- T1 = K^-1 P (full), 16x16 tile products C += X Y^T on the symmetric operands ----
+    // Register-blocked: a wave owns two tile rows and all their column tiles, so one K-step of the operands is 2 + nb loads for
+    // 2 nb matrix instructions (one tile per wave and trip: 2 loads per instruction, all of them 16 x 32-byte gathers from L2 — they
+    // set the kernel's pace).  nb <= 8 (Mp <= 128): at most one pair of rows per wave.
+    constexpr int NBX = 8;
     {
-        int cnt = 0;
-        for (int I = 0; I < nb; ++I)
-            for (int J = 0; J < nb; ++J, ++cnt) {
-                if ((cnt & 3) != wv) continue;
-                acc_t c = {0, 0, 0, 0};
-                for (int k = 0; k < nb; ++k) {
+        const int I0 = 2 * wv, I1 = I0 + 1;
+        if (I0 < nb) {
+            acc_t c[2][NBX];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        c = Mfma<double>::mma(sym_at(KI, Mp, 16 * I + li, 16 * k + 4 * ks + kk),
-                                              sym_at(Pd, Mp, 16 * J + li, 16 * k + 4 * ks + kk), c);
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int J = 0; J < NBX; ++J) c[r][J] = (acc_t){0, 0, 0, 0};
+            const bool two = I1 < nb;
+            for (int k = 0; k < nb; ++k) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int col = 16 * k + 4 * ks + kk;
+                    const double a0 = sym_at(KI, Mp, 16 * I0 + li, col), a1 = two ? sym_at(KI, Mp, 16 * I1 + li, col) : 0.0;
+                    double bj[NBX];
+#pragma unroll
+                    for (int J = 0; J < NBX; ++J) bj[J] = J < nb ? sym_at(Pd, Mp, 16 * J + li, col) : 0.0;
+#pragma unroll
+                    for (int J = 0; J < NBX; ++J)
+                        if (J < nb) {
+                            c[0][J] = Mfma<double>::mma(a0, bj[J], c[0][J]);
+                            c[1][J] = Mfma<double>::mma(a1, bj[J], c[1][J]);
+                        }
                 }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) T1[(size_t)(16 * I + Mfma<double>::row(lane, v)) * Mp + 16 * J + li] = c[v];
             }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int J = 0; J < NBX; ++J)
+                    if (J < nb && (r == 0 || two)) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            T1[(size_t)(16 * (I0 + r) + Mfma<double>::row(lane, v)) * Mp + 16 * J + li] = c[r][J][v];
+                    }
+        }
     }
     __threadfence_block();
     __syncthreads();
     // ---- X = T1 K^-1 (lower tiles) and the outputs, element by element in the MFMA result layout ----
+    // wave p owns the tile rows p and nb - 1 - p (p + 1 and nb - p lower tiles: nb + 1 per wave)
     double sK = 0.0, sP = 0.0, sGBP = 0.0, tr = 0.0;
     {
-        int cnt = 0;
-        for (int I = 0; I < nb; ++I)
-            for (int J = 0; J <= I; ++J, ++cnt) {
-                if ((cnt & 3) != wv) continue;
-                acc_t c = {0, 0, 0, 0};
-                for (int k = 0; k < nb; ++k) {
+        const int Ia = wv, Ib = nb - 1 - wv;
+        if (Ia <= Ib) {
+            acc_t c[2][NBX];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        c = Mfma<double>::mma(T1[(size_t)(16 * I + li) * Mp + 16 * k + 4 * ks + kk],
-                                              sym_at(KI, Mp, 16 * J + li, 16 * k + 4 * ks + kk), c);
-                }
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int i = 16 * I + Mfma<double>::row(lane, v), j = 16 * J + li;
-                    double gp = 0.0, wk = 0.0;
-                    if (j <= i && i < M) {
-                        const double ki = KI[(size_t)i * Mp + j], bi = binv_at(tiles, nb, i, j), p = Pd[(size_t)i * Mp + j];
-                        const double k0 = K0[(size_t)i * Mp + j] - (i == j ? jitter : 0.0);
-                        const double gb = -0.5 * bi - 0.5 * be * be * ww[i] * ww[j];
-                        const double gk = 0.5 * ki - 0.5 * be * c[v] + gb;
-                        gp = 0.5 * be * ki + be * gb;
-                        wk = gk * k0;
-                        const double mult = (i == j) ? 1.0 : 2.0;
-                        sK += mult * wk;
-                        sP += mult * gp * p;
-                        sGBP += mult * gb * p;
-                        tr += mult * ki * p;
-                    }
-                    GP[(size_t)d * Mp * Mp + (size_t)i * Mp + j] = gp;
-                    WK[(size_t)d * Mp * Mp + (size_t)i * Mp + j] = wk;
+                for (int J = 0; J < NBX; ++J) c[r][J] = (acc_t){0, 0, 0, 0};
+            const bool two = Ia < Ib;
+            for (int k = 0; k < nb; ++k) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int col = 16 * k + 4 * ks + kk;
+                    const double aa = two ? T1[(size_t)(16 * Ia + li) * Mp + col] : 0.0, ab = T1[(size_t)(16 * Ib + li) * Mp + col];
+                    double bj[NBX];
+#pragma unroll
+                    for (int J = 0; J < NBX; ++J) bj[J] = J <= Ib ? sym_at(KI, Mp, 16 * J + li, col) : 0.0;
+#pragma unroll
+                    for (int J = 0; J < NBX; ++J)
+                        if (J <= Ib) {
+                            if (J <= Ia) c[0][J] = Mfma<double>::mma(aa, bj[J], c[0][J]);
+                            c[1][J] = Mfma<double>::mma(ab, bj[J], c[1][J]);
+                        }
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int J = 0; J < NBX; ++J) {
+                    const int I = r ? Ib : Ia;
+                    if (J > I || (r == 0 && !two)) continue;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = 16 * I + Mfma<double>::row(lane, v), j = 16 * J + li;
+                        double gp = 0.0, wk = 0.0;
+                        if (j <= i && i < M) {
+                            const double ki = KI[(size_t)i * Mp + j], bi = binv_at(tiles, nb, i, j), p = Pd[(size_t)i * Mp + j];
+                            const double k0 = K0[(size_t)i * Mp + j] - (i == j ? jitter : 0.0);
+                            const double gb = -0.5 * bi - 0.5 * be * be * ww[i] * ww[j];
+                            const double gk = 0.5 * ki - 0.5 * be * c[r][J][v] + gb;
+                            gp = 0.5 * be * ki + be * gb;
+                            wk = gk * k0;
+                            const double mult = (i == j) ? 1.0 : 2.0;
+                            sK += mult * wk;
+                            sP += mult * gp * p;
+                            sGBP += mult * gb * p;
+                            tr += mult * ki * p;
+                        }
+                        GP[(size_t)d * Mp * Mp + (size_t)i * Mp + j] = gp;
+                        WK[(size_t)d * Mp * Mp + (size_t)i * Mp + j] = wk;
+                    }
+                }
+        }
     }
     sK = block_sum(sK, scratch);
     sP = block_sum(sP, scratch);

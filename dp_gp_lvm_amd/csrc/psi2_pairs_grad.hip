@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
     constexpr bool STAGED = KS >= 8 && G == 1;
     // KS = 8 with G >= 2: ONE register set for the exponent operand — K-step ks of the next row tile is read into the register of K-step
     // ks right behind the last matrix instruction that reads it (the chain of step G - 2), a whole step ahead of its first use
-    constexpr bool SINGLE_A = KS >= 8 && G >= 2;
+    constexpr bool SINGLE_A = (KS >= 8 && G >= 2) || G >= 4;
     constexpr int NTB_MAX = (160 * 1024 * NW / (4 * PgCfg<KS>::WPS)) / (3 * 1024 * PIECES), MAXP = STAGED ? (NTB_MAX * PIECES + NW - 1) / NW : 1;
     pg_u4 stage[MAXP];
     int st_chunk = -1;
@@ -1159,9 +1159,9 @@ static PgLayout pg_layout(int D, int N, int M, int Q) {
 }
 size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q) { return psi2_pgrad_supported(M, Q) ? pg_layout(D, N, M, Q).total : 0; }
 
-// One pass launch.  Resident column tiles per wave: PgCfg<KS>::G, or (KS <= 4, where the registers allow three) the one of {G, 3}
-// that leaves fewer surplus tile slots in the last group of a row — 258 pair tiles: 11 groups of 24 instead of 17 of 16 (fewer
-// steps and a third fewer LDS-DMA pieces per step); 63 observation tiles: 4 groups of 16 rather than 3 of 24.
+// One pass launch.  Resident column tiles per wave: PgCfg<KS>::G, or (KS <= 4, where the registers allow up to four) the one of
+// {2, 3, 4} with the least (tile slots x cost per step) — 258 pair tiles: 11 groups of 24 instead of 17 of 16; 63 observation tiles: 2
+// groups of 32 rather than 4 of 16 (half the LDS-DMA pieces per step and half the re-reads of the pair image).
 template <int KS, bool WLO, int G>
 static int pg_launch_pass_g(int D, const _Float16 *rimg, int row_per_d, const _Float16 *ximg, const _Float16 *cimg, int col_per_d,
                             float *out, int n_row_tiles, int n_col_tiles, const PgPsi2Out &po, hipStream_t st) {
@@ -1185,9 +1185,14 @@ static int pg_launch_pass(int D, const _Float16 *rimg, int row_per_d, const _Flo
                           int n_row_tiles, int n_col_tiles, const PgPsi2Out &po, hipStream_t st) {
     constexpr int G0 = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
     if constexpr (KS <= 4 && G0 == 2) {
-        const int s2 = dpgp_ceil_div(n_col_tiles, NW * 2) * 2, s3 = dpgp_ceil_div(n_col_tiles, NW * 3) * 3;
-        if (s3 < s2 && !getenv("DPGP_PG_G2"))                      // (DPGP_PG_G2: experiments)
-            return pg_launch_pass_g<KS, WLO, 3>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
+        // tile slots of the last group included, times the measured cost of a step (config 3: G = 3 and 4 — the latter with one register
+        // set for the exponent operand — take 0.945 / 0.94 of a G = 2 step: a third / half the LDS-DMA pieces per step)
+        const int s2 = dpgp_ceil_div(n_col_tiles, NW * 2) * 2 * 1000, s3 = dpgp_ceil_div(n_col_tiles, NW * 3) * 3 * 945,
+                  s4 = dpgp_ceil_div(n_col_tiles, NW * 4) * 4 * 940;
+        const char *e = getenv("DPGP_PG_G");                       // (experiments: 2, 3 or 4)
+        const int pick = e ? atoi(e) : (s4 < s3 && s4 < s2 ? 4 : (s3 < s2 ? 3 : 2));
+        if (pick == 4) return pg_launch_pass_g<KS, WLO, 4>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
+        if (pick == 3) return pg_launch_pass_g<KS, WLO, 3>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
     }
     if constexpr (KS >= 8 && G0 == 1) {
         // two resident column tiles per wave (one register set for the exponent operand: 248 registers) halve the ring fills and the LDS
