@@ -86,6 +86,10 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     }
     if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1, aux ? aux : st)))
         return rc;
+    // training step with a second stream: the K_uu branch (a launch of its own there, 0.12 ms of latency-bound Cholesky work at config
+    // 3) follows Psi1^T y on it, beside the image build and the head of pass 1
+    const bool k_on_aux = aux && pgws != nullptr && la_chain_k_resident(M, (int)sizeof(TL)) && algo != DPGP_ALGO_PLAIN;
+    if (k_on_aux && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, aux))) return rc;
     if (aux && hipEventRecord((hipEvent_t)ex->ev_join, aux) != hipSuccess) return DPGP_ERR_LAUNCH;
     // the K_uu branch rides in the psi2 dispatch when it is LDS-resident (or the exact-MFMA psi2 kernel runs, which carries
     // both forms); otherwise it is a launch of its own ahead of psi2
@@ -103,7 +107,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
         big = (algo != DPGP_ALGO_PLAIN) && chain_big_applicable(D, M, 8);
         if (big && (rc = launch_chain_big_k(D, M, reinterpret_cast<double *>(la), ik, st))) return rc;
     }
-    if (!big && !fused_k && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, st))) return rc;
+    if (!big && !fused_k && !k_on_aux && (rc = launch_chain_k<TL>(D, M, la, ldk, ik, algo, st))) return rc;
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return DPGP_ERR_LAUNCH;
     // psi2 on the matrix cores; the same dispatch carries, ahead of the psi2 workgroups, the D workgroups of the K_uu
     // branch (Cholesky, log-det, inverse of K_uu), which are latency-bound and overlap the psi2 work completely

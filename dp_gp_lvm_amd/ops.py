@@ -395,6 +395,24 @@ class ElboStepBuffers:
         self.ws = _ws(self.nbytes, device)
         self.dmu, self.ds = torch.empty((n, q), dtype=f64, device=device), torch.empty((n, q), dtype=f64, device=device)
         self.dz, self.dg = torch.empty((m, q), dtype=f64, device=device), torch.empty((d, q), dtype=f64, device=device)
+        # second stream + fork / join events of the one-call step: Psi1^T y and the K_uu branch (in a step the latter is a launch of its
+        # own) run beside the image build and the head of pass 1.  DPGP_STEP_AUX=0 keeps one stream.
+        import os
+        self.aux = None
+        if mp <= 128 and os.environ.get('DPGP_STEP_AUX', '1') != '0':
+            l = _lib.lib()
+            self.aux = (l.dpgp_stream_create(), l.dpgp_event_create(), l.dpgp_event_create())
+
+    def __del__(self):
+        try:
+            if self.aux:
+                l = _lib.lib()
+                l.dpgp_stream_destroy(self.aux[0])
+                l.dpgp_event_destroy(self.aux[1])
+                l.dpgp_event_destroy(self.aux[2])
+                self.aux = None
+        except Exception:                                        # (interpreter shutdown)
+            pass
 
 
 def elbo_step(y, z, mu, s, gamma, alpha, beta, workspace, buffers, jitter=1e-8, model_tail=None, stage_b='mixed'):
@@ -412,12 +430,18 @@ def elbo_step(y, z, mu, s, gamma, alpha, beta, workspace, buffers, jitter=1e-8, 
     w.exec.ev_psi2_begin, w.exec.ev_psi2_end = None, None
     w.exec.model_scal, w.exec.model_pack, w.exec.model_out = (
         (None, None, None) if model_tail is None else tuple(None if t_ is None else t_.data_ptr() for t_ in model_tail))
-    _lib.check(_lib.lib().dpgp_elbo_step(
-        d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(),
-        beta.data_ptr(), float(jitter), _lib.PREC[stage_b], w.terms.data_ptr(), w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(),
-        w.nbytes, b.gp.data_ptr(), b.wk.data_ptr(), b.gv.data_ptr(), b.dab.data_ptr(), b.info.data_ptr(), b.ws.data_ptr(), b.nbytes,
-        b.dmu.data_ptr(), b.ds.data_ptr(), b.dz.data_ptr(), b.dg.data_ptr(), _stream(),
-        ctypes.cast(ctypes.pointer(w.exec), ctypes.c_void_p)), 'dpgp_elbo_step')
+    own = (w.exec.stream_aux, w.exec.ev_fork, w.exec.ev_join)
+    if b.aux and not own[0]:
+        w.exec.stream_aux, w.exec.ev_fork, w.exec.ev_join = b.aux
+    try:
+        _lib.check(_lib.lib().dpgp_elbo_step(
+            d, n, m, q, y.data_ptr(), y.stride(0), z.data_ptr(), mu.data_ptr(), s.data_ptr(), gamma.data_ptr(), alpha.data_ptr(),
+            beta.data_ptr(), float(jitter), _lib.PREC[stage_b], w.terms.data_ptr(), w.sums.data_ptr(), w.info.data_ptr(), w.ws.data_ptr(),
+            w.nbytes, b.gp.data_ptr(), b.wk.data_ptr(), b.gv.data_ptr(), b.dab.data_ptr(), b.info.data_ptr(), b.ws.data_ptr(), b.nbytes,
+            b.dmu.data_ptr(), b.ds.data_ptr(), b.dz.data_ptr(), b.dg.data_ptr(), _stream(),
+            ctypes.cast(ctypes.pointer(w.exec), ctypes.c_void_p)), 'dpgp_elbo_step')
+    finally:
+        w.exec.stream_aux, w.exec.ev_fork, w.exec.ev_join = own
     return (w.terms, w.sums, w.info), (b.dmu, b.ds, b.dz, b.dg, b.dab, b.info)
 
 
