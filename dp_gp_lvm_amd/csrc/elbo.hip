@@ -55,6 +55,22 @@ extern "C" int dpgp_elbo_workspace_layout(int D, int N, int M, int Q, int prec, 
     return DPGP_OK;
 }
 
+// A forked second stream is joined on EVERY way out: an error return between fork and join would otherwise leave work in flight on
+// it that still writes the caller's workspace (and, inside a stream capture, an unjoined stream invalidates the capture).
+struct AuxJoin {
+    hipStream_t st = nullptr, aux = nullptr;
+    hipEvent_t ev = nullptr;
+    bool armed = false;
+    void arm(hipStream_t st_, hipStream_t aux_, hipEvent_t ev_) { st = st_; aux = aux_; ev = ev_; armed = true; }
+    int join() {                                               // the regular join (the event has been recorded on aux)
+        armed = false;
+        return hipStreamWaitEvent(st, ev, 0) == hipSuccess ? DPGP_OK : DPGP_ERR_LAUNCH;
+    }
+    ~AuxJoin() {
+        if (armed && hipEventRecord(ev, aux) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+    }
+};
+
 template <typename TP, typename TL>
 static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                     const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
@@ -80,9 +96,11 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     // Psi1^T y needs only the front launch and feeds only the chain: with a second stream in `exec` it runs beside the psi2
     // launch instead of in front of it (12 us of the per-GPU share at D = 64)
     hipStream_t aux = (ex && ex->stream_aux && ex->ev_fork && ex->ev_join) ? (hipStream_t)ex->stream_aux : nullptr;
+    AuxJoin aj;
     if (aux) {
         if (hipEventRecord((hipEvent_t)ex->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)ex->ev_fork, 0) != hipSuccess)
             return DPGP_ERR_LAUNCH;
+        aj.arm(st, aux, (hipEvent_t)ex->ev_join);
     }
     if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1, aux ? aux : st)))
         return rc;
@@ -122,7 +140,7 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
                                                      pairs_psi2 ? 2 : 1, pscale)))
         return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return DPGP_ERR_LAUNCH;
-    if (aux && hipStreamWaitEvent(st, (hipEvent_t)ex->ev_join, 0) != hipSuccess) return DPGP_ERR_LAUNCH;
+    if (aux && aj.join() != DPGP_OK) return DPGP_ERR_LAUNCH;
     // ... and, in the workgroup that finishes last, f_hat and KL; with the model-level pointers of exec also the packed pair /
     // the finished objective (round 2: a launch of its own, sum_terms_kernel)
     if (big && lb_out) return -30;
@@ -588,6 +606,8 @@ extern "C" int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double 
     }
     if (aux && (hipEventRecord((hipEvent_t)ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)ev_fork, 0) != hipSuccess))
         return DPGP_ERR_LAUNCH;
+    AuxJoin aj;
+    if (aux) aj.arm(st, aux, (hipEvent_t)ev_join);
     hipStream_t sb = aux ? aux : st;
     if (aux) {                                                 // the branch first, so that both start at once
         if ((rc = dpgp_psi1_f64(T, N, M, Q, z, mu, s, gamma, alpha, p1, (void *)sb))) return rc - 100;
@@ -610,7 +630,7 @@ extern "C" int dpgp_elbo_fhat_t(int T, int D, int N, int M, int Q, const double 
         if ((rc = launch_gemm_splitk_f64(T, M, D, N, p1, (long long)N * M, 1, M, y, 0, ldy, 1, vp, (long long)M * D, D, 1, E.ksplit,
                                          (long long)T * M * D, st)))
             return rc - 200;
-    } else if (hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0) != hipSuccess) {
+    } else if (aj.join() != DPGP_OK) {
         return DPGP_ERR_LAUNCH;
     }
     if ((rc = launch_tcols_quad(T, M, D, lb, vp, E.ksplit, (long long)T * M * D, beta, quad, st))) return rc;

@@ -319,8 +319,16 @@ __global__ __launch_bounds__(256, OCC) void chain_b_kernel(int D, int N, int M, 
         int *counter = reinterpret_cast<int *>(const_cast<double *>(kl_part) + DPGP_KL_NBLK);
         int &last = *reinterpret_cast<int *>(smem_raw + 68);
         if (t == 0) {
-            __builtin_amdgcn_s_waitcnt(0);                     // the sc1 stores of the terms above have been acknowledged
+            // Order: terms (relaxed agent-scope stores, written through to memory: sc1) -> all of them acknowledged (s_waitcnt) ->
+            // arrival counter.  The language's memory model has no edge between relaxed operations on different addresses, and the
+            // waitcnt builtin is not a compiler barrier: the two signal fences pin the order for the COMPILER (no instruction), the
+            // waitcnt for the hardware.  (A release fetch_add would do both but writes back the whole L2: 4-11 us per workgroup.)  The
+            // last workgroup reads the terms with agent-scope loads (sum_terms_body<true>): they do not hit in its XCD's L2.
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __builtin_amdgcn_s_waitcnt(0);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             last = (__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == D - 1) ? 1 : 0;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
         }
         __syncthreads();
         if (last) sum_terms_body<true>(D, terms, kl_part, sums, model_scal, model_pack, model_out, scratch);

@@ -78,7 +78,10 @@ def dp_gp_lvm(y_train,
     assert backward_precision in (None, 'mixed', 'f64', 'mixed_fast'), "backward_precision must be None, 'mixed', 'mixed_fast' or 'f64'"
     # stage B behind an fp64 forward pass (the training configuration): the patch form of the Psi2 term, which keeps its accuracy
     # where the adjoints cancel (include/dpgp.h, DPGP_PREC_MIXED_PATCH); behind a mixed forward pass the faster pair-tile form
-    stage_b_precision = backward_precision or precision
+    # precision='f32' (the psi-statistics as exact fp32 products, fp32 chain) is a scoring precision: its gradients are those of the
+    # mixed evaluation — the same function to the mixed tolerance, fp64 dense adjoints — on a second, lazily built workspace
+    grad_precision = 'mixed' if precision == 'f32' else precision
+    stage_b_precision = backward_precision or grad_precision
     if precision == 'f64' and backward_precision == 'mixed':
         stage_b_precision = 'mixed_patch'
     assert psi_algo in _lib.ALGO, 'psi_algo must be one of %s' % sorted(_lib.ALGO)
@@ -155,13 +158,20 @@ def dp_gp_lvm(y_train,
 
     # one training step through dpgp_elbo_step (mixed precision, M <= 128, Q <= 20: DESIGN.md section 7.1): the forward's psi2 dispatch is
     # replaced by the first pass of stage B (DPGP_FUSED_STEP=0: the three separate calls, e.g. for bench.py's per-stage breakdown)
-    step_ok = (precision == 'mixed' and stage_b_precision in ('mixed', 'mixed_fast') and psi_algo == 'auto' and
+    step_ok = (grad_precision == 'mixed' and stage_b_precision in ('mixed', 'mixed_fast') and psi_algo == 'auto' and
                num_latent_dims <= 20 and os.environ.get('DPGP_FUSED_STEP', '1') != '0')
     fused_step = step_ok and ops.elbo_step_supported(num_inducing_points, num_latent_dims)
     split_step = step_ok and not fused_step            # (M > 128: the two halves of the step around the host-composed stage A)
     step_state = {}
 
-    def evaluate(events=None, out=None, _local_part_only=False, _step=False, _half_step=False):
+    def grad_workspace():
+        if precision != 'f32':
+            return workspace
+        if 'ws_mixed' not in step_state:
+            step_state['ws_mixed'] = ops.ElboWorkspace(d_local, num_samples, num_inducing_points, num_latent_dims, 'mixed', device)
+        return step_state['ws_mixed']
+
+    def evaluate(events=None, out=None, _local_part_only=False, _step=False, _half_step=False, _grad=False):
         """One objective evaluation; returns the device tensor out[5] = (objective, f_hat, KL, DP objective, hyper-prior).
         Five launches: prepare, front (KL, y'y, K_uu tiles, operand constants, pair factors), psi1T_y,
         psi2 (+ the K_uu tasks), chain_b (+ the final reduction: sum, pack, finalize); D sharded: the all-reduce and the
@@ -179,26 +189,27 @@ def dp_gp_lvm(y_train,
         # single GPU: the last kernel of the fused ELBO also packs and finalises; sharded: it packs, then one all-reduce
         if (_step or _half_step) and 'buf' not in step_state:
             step_state['buf'] = ops.ElboStepBuffers(d_local, num_samples, num_inducing_points, num_latent_dims, device)
+        ws_ = grad_workspace() if (_step or _half_step or _grad) else workspace
         if _half_step:
-            ops.elbo_fhat_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'], workspace, step_state['buf'],
+            ops.elbo_fhat_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'], ws_, step_state['buf'],
                                jitter=GP_DEFAULT_JITTER, model_tail=(buf['scal'], red, None if sharded else out))
         elif _step:
-            step_state['grads'] = ops.elbo_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'], workspace,
+            step_state['grads'] = ops.elbo_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'], ws_,
                                                 step_state['buf'], jitter=GP_DEFAULT_JITTER,
                                                 model_tail=(buf['scal'], red, None if sharded else out),
                                                 stage_b=stage_b_precision)[1]
         else:
             ops.elbo_fhat(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], buf['beta'],
-                          jitter=GP_DEFAULT_JITTER, prec=precision, algo=psi_algo, workspace=workspace, events=events,
+                          jitter=GP_DEFAULT_JITTER, prec=grad_precision if _grad else precision, algo=psi_algo, workspace=ws_, events=events,
                           model_tail=(buf['scal'], red, None if sharded else out))
         if sharded and not _local_part_only:
-            _exchange_and_finalise(out)
+            _exchange_and_finalise(out, ws_)
         return out
 
-    def _exchange_and_finalise(out):
+    def _exchange_and_finalise(out, ws_=None):
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
         dist.all_reduce(buf['red'], op=dist.ReduceOp.SUM, group=process_group)    # the only exchange: 2 fp64 scalars
-        _lib.check(lib.dpgp_model_finalize(buf['red'].data_ptr(), workspace.sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
+        _lib.check(lib.dpgp_model_finalize(buf['red'].data_ptr(), (ws_ or workspace).sums[1:2].data_ptr(), buf['scal'][1:2].data_ptr(),
                                            out.data_ptr(), st), 'dpgp_model_finalize')
 
     graph_state = {}
@@ -237,8 +248,8 @@ def dp_gp_lvm(y_train,
         partial gradients are packed into one buffer and sum-all-reduced.  Returns {name: tensor} keyed like ``raw``.
         events: optional list of 4 torch.cuda.Event(enable_timing=True), recorded after the forward evaluation, stage A,
         stage B and the chain rule to the raw variables (bench.py's breakdown)."""
-        assert precision in ('mixed', 'f64'), 'the backward pass exists for precision mixed and f64'
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+        gws = grad_workspace()
         mark = (lambda i: events[i].record()) if events is not None else (lambda i: None)
         r = dp_model.raw
         if fused_step and events is None:
@@ -246,14 +257,14 @@ def dp_gp_lvm(y_train,
             dmu, ds, dz, dg, dab, _ = step_state['grads']
         elif split_step and events is None:
             evaluate(_half_step=True)
-            gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER, z=x_u,
+            gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], gws, jitter=GP_DEFAULT_JITTER, z=x_u,
                                                      gamma=buf['gamma'], psi2_slabs=1)
-            dmu, ds, dz, dg = ops.elbo_grad_psi_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv, workspace,
+            dmu, ds, dz, dg = ops.elbo_grad_psi_step(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv, gws,
                                                      step_state['buf'], stage_b=stage_b_precision)
         else:
-            evaluate()
+            evaluate(_grad=True)
             mark(0)
-            gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], workspace, jitter=GP_DEFAULT_JITTER, z=x_u,
+            gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], gws, jitter=GP_DEFAULT_JITTER, z=x_u,
                                                      gamma=buf['gamma'])
             mark(1)
             dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
@@ -275,7 +286,7 @@ def dp_gp_lvm(y_train,
         mark(3)
         # trouble flag of the LOCAL output dims (a Cholesky / conditioning flag of the forward evaluation or a non-finite
         # partial gradient), reduced with the gradients: every rank sees the same decision (optimise() branches on it)
-        flat[-1] = ((workspace.info != 0).any() | ~torch.isfinite(flat[:-1]).all()).to(TORCH_DTYPE)
+        flat[-1] = ((gws.info != 0).any() | ~torch.isfinite(flat[:-1]).all()).to(TORCH_DTYPE)
         if sharded:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)      # one packed exchange (N Q x 2 + M Q + ...)
         grad_state['flag'] = flat[-1]

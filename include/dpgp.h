@@ -63,6 +63,10 @@ extern "C" {
  *   K_uu^-1, may move this output dim's terms by more than DPGP_GUARD_REL * N (bound written to the workspace's guard[d],
  *   see dpgp_elbo_workspace_layout): the terms are written but are not covered by the mixed-precision tolerance any more.
  *   Evaluate with DPGP_PREC_F64 (the reference's arithmetic, src/utils/types.py:13-14).
+ *   Two paths use a LOOSER form of the bound (they flag earlier, never later): M > 128 with D >= 128 (chain_big.hip) takes
+ *   tr K_uu^-1 for |K_uu^-1|_F (at most sqrt(M) larger); the over-T evaluation (dpgp_elbo_fhat_t) evaluates the guard of atom t with
+ *   the data-fit factor of a stand-in column (column t of y) instead of the D columns the atom is solved against — there the flag
+ *   says "this atom's K_uu / B is ill-conditioned for an fp32 Psi2", not a bound on a particular output dim's terms.
  * Operands outside the f16 range of the default fp32 psi kernels (|z - mean z| or |mu - mean z| beyond ~90 length scales)
  * are detected in the kernels: the affected Psi2 patch / Psi1^T y slab comes out as NaN, which the fused ELBO reports as a
  * failed factorisation (info > 0, NaN terms).  DPGP_ALGO_MFMA_F32 and fp64 have no such limit.                              */
