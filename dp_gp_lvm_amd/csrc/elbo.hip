@@ -1034,6 +1034,37 @@ static int model_backward_run(int D, int T, int Q, int N, int M, int d_offset, i
     return DPGP_OK;
 }
 
+// ---- the trouble flag of a gradient evaluation: out[0] = 1 if any info[0..d) != 0 or any of flat[0..n) is not finite, else 0 (what
+// optimise() branches on, summed over the ranks with the packed gradients; eight small torch kernels before) ----
+__global__ __launch_bounds__(1024) void trouble_flag_kernel(size_t n, const double *__restrict__ flat, int d, const int *__restrict__ info,
+                                                            double *__restrict__ out) {
+    __shared__ int bad_w[16];
+    const int t = threadIdx.x;
+    int bad = 0;
+    for (size_t i = t; i < n; i += 1024) {
+        const double v = flat[i];
+        bad |= !(fabs(v) <= 1.7976931348623157e308);            // (NaN compares false)
+    }
+    for (int i = t; i < d; i += 1024) bad |= info[i] != 0;
+    bad = __any(bad);
+    if ((t & 63) == 0) bad_w[t >> 6] = bad;
+    __syncthreads();
+    if (t == 0) {
+        int b = 0;
+        for (int w = 0; w < 16; ++w) b |= bad_w[w];
+        out[0] = b ? 1.0 : 0.0;
+    }
+}
+extern "C" int dpgp_trouble_flag(size_t n, const double *flat, int d, const int *info, double *out, void *stream) {
+    if (n > 0 && !flat) return -2;
+    if (d < 0 || (d > 0 && !info)) return -4;
+    if (!out) return -5;
+    DPGP_PRELAUNCH();
+    hipLaunchKernelGGL(trouble_flag_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, flat, d, info, out);
+    DPGP_LAUNCH_CHECK();
+    return DPGP_OK;
+}
+
 extern "C" int dpgp_model_backward(int D, int T, int Q, int N, int M, int d_offset, int mask_size, int logits_rows,
                                    const double *logits, const double *gamma_atoms_raw, const double *alpha_atoms_raw,
                                    const double *beta_atoms_raw, const double *s_raw, const double *g1_raw,

@@ -517,6 +517,9 @@ static size_t pt_lds_bytes() {
 __global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const double *__restrict__ Lall, size_t lstride,
                                                                double *__restrict__ Xall, size_t xstride,
                                                                double *__restrict__ nrm2, size_t nstride, int identity) {
+    // identity bit 1 (dpgp_trtri_lower_batched_f64): X itself is the result — the last block row is stored as well
+    const bool keep_all = (identity & 2) != 0;
+    identity &= 1;
     // identity != 0: R = I — X need not be initialised (its diagonal blocks are taken as I, the blocks below as 0 where they
     // are first touched): the caller saves writing Mw^2 / 2 doubles per matrix and this kernel reading them
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const dou
             const int nct = PP_NT * (k + 1), r0 = lane >> 3, c2 = (lane & 7) * 2;
             double *S = stage + (size_t)wv * 16 * PP_SLD;
             double *Xk = X + (size_t)(PP_PW * k) * Mw;
-            const bool keep = (k + 1 < nblk);                  // the last block row is only summed
+            const bool keep = (k + 1 < nblk) || keep_all;      // the last block row is only summed (fused ELBO)
             pp_f2 pre[16];
             if (wv < nct) {
 #pragma unroll
@@ -691,6 +694,22 @@ __global__ __launch_bounds__(256) void ptrsm_persistent_kernel(int Mw, const dou
     __syncthreads();
     fro = block_sum(fro, scratch);
     if (t == 0) nrm2[(size_t)b * nstride] = fro;
+}
+
+// L^-1 of B lower-triangular factors [M][M], M a multiple of 128 (the block width of the persistent kernels): out = L^-1, lower, zeros
+// above the diagonal.  The solve X = L^-1 I of the persistent kernel above with every block row stored; the blocks above the diagonal
+// are zeroed here (the kernel never touches them).  ws: B doubles (the squared norms the kernel also forms).   (stage A of the backward
+// pass for M > 128, ops._elbo_grad_chain_large: K^-1 = W^T W, B^-1 likewise; tf.matrix_triangular_solve on the identity)
+extern "C" int dpgp_trtri_lower_batched_f64(int B, int M, const double *l, double *out, void *ws, size_t ws_bytes, void *stream) {
+    if (B <= 0) return -1;
+    if (M <= 0 || M % PP_PW != 0) return -2;
+    if (!l) return -3;
+    if (!out) return -4;
+    if (!ws) return -5;
+    if (ws_bytes < sizeof(double) * (size_t)B) return -6;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(double) * (size_t)B * M * M, st) != hipSuccess) return DPGP_ERR_LAUNCH;
+    return launch_ptrsm_persist(B, M, l, (size_t)M * M, out, (size_t)M * M, (double *)ws, 1, st, 3);
 }
 
 int launch_ptrsm_persist(int B, int Mw, const double *l, size_t lstride, double *x, size_t xstride, double *nrm2,

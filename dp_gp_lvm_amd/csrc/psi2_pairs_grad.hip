@@ -406,10 +406,16 @@ __global__ __launch_bounds__(256) void pg_finish_m1_kernel(int M, int Mpad, int 
     for (int q = 0; q < QP; ++q) { ta[q] = 0.0; tb[q] = 0.0; }
     for (int d = t; d < D; d += 256) {
         const double ud = (double)u1[(size_t)d * Mpad + m];
-        const float *row = r + pg_oix<NF>((size_t)d * Mpad + m, 0);
+        const pg_f4 *row = reinterpret_cast<const pg_f4 *>(r + ((size_t)d * Mpad + m) * NF);   // (this pass writes [column][feature])
+        float rv[NF];
+#pragma unroll
+        for (int k = 0; k < NF / 4; ++k) {
+            const pg_f4 v = row[k];
+            rv[4 * k] = v[0]; rv[4 * k + 1] = v[1]; rv[4 * k + 2] = v[2]; rv[4 * k + 3] = v[3];
+        }
 #pragma unroll
         for (int q = 0; q < QP; ++q)
-            if (q < Q && 2 * q + 1 < NF) { ta[q] += ud * (double)row[64 * q]; tb[q] += ud * (double)row[64 * q + 32]; }
+            if (q < Q && 2 * q + 1 < NF) { ta[q] += ud * (double)rv[2 * q]; tb[q] += ud * (double)rv[2 * q + 1]; }
     }
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
@@ -447,6 +453,7 @@ struct PgPsi2Out {                    // Psi2 as a by-product of pass 1 (see the
     const unsigned *pmap;             // [Ppad] m << 16 | m'
     const int *flag;                  // range-guard flag of the image build
     int Mp, Ppad, fsel;
+    int col_major;                    // != 0: out[set][column][32 NFB features] (the reader is a thread per (output dim, column): pg_finish_m1_kernel)
 };
 struct PgSlot { int kind, i; };      // kind 0: exponent chain K-step i; 1: product i of the previous step's K-step-1 half; 2: of this step's K-step-0 half
 struct PgUnit { int kind, i; };      // kind 0: v_exp_f32 of element i; 1: v_cvt_pk_f16_f32 (hi) of element pair i; 2: the two v_fma_mix_f32 (e - hi) of pair i; 3: v_cvt_pk_f16_f32 (lo)
@@ -819,6 +826,16 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
         }
         // feature-major inside a column tile (pg_oix): one store instruction = two 128-byte runs, and the finishing kernels (thread =
         // column) read every feature as a coalesced run
+        if (po.col_major) {
+            float *oc = out + (((size_t)d * n_col_tiles + tile) * 32 + l5) * NF + 4 * half;
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                for (int vq = 0; vq < 4; ++vq)
+                    *reinterpret_cast<pg_f4 *>(oc + 32 * fb + 8 * vq) =
+                        (pg_f4){acc[g][fb][4 * vq], acc[g][fb][4 * vq + 1], acc[g][fb][4 * vq + 2], acc[g][fb][4 * vq + 3]};
+            continue;
+        }
         float *o = out + (((size_t)d * n_col_tiles + tile) * NF + 4 * half) * 32 + l5;
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb)
@@ -1226,7 +1243,7 @@ static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *c
                            flag, (const double *)nullptr, 0);
         DPGP_LAUNCH_CHECK();
     }
-    PgPsi2Out po = {psi2_part, scale, reinterpret_cast<const unsigned *>(consts + C.off_pmap), flag, dpgp_round_up(M, 16), L.Ppad, 2 * Q};
+    PgPsi2Out po = {psi2_part, scale, reinterpret_cast<const unsigned *>(consts + C.off_pmap), flag, dpgp_round_up(M, 16), L.Ppad, 2 * Q, 0};
     // rows: the observations of output dim d (cobs, xobs); columns: the pairs (the forward's pair image)
     // (the pass that also yields Psi2 keeps the lo half of the exponentials whatever the mode: the objective is not a "fast" quantity)
     if (wlo || psi2_part) return pg_launch_pass<KS, true>(D, cobs, 1, xobs, pimg, 0, r2, L.NT, L.PT, po, st);
@@ -1264,7 +1281,7 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     DPGP_LAUNCH_CHECK();
     int rc;
     {
-        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
         // rows: the pairs (pair image, xpair of output dim d); columns: the observations of output dim d
         rc = wlo ? pg_launch_pass<KS, true>(D, pimg, 0, xpair, cobs, 1, r1, L.PT, L.NT, po, st)
                  : pg_launch_pass<KS, false>(D, pimg, 0, xpair, cobs, 1, r1, L.PT, L.NT, po, st);
@@ -1309,12 +1326,13 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
         DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(Mpad, 256), D), dim3(256), 0, st, Mpad, Q,
                            (const _Float16 *)dimg, (const float *)u1, (const float *)kap1, xm1);
         DPGP_LAUNCH_CHECK();
-        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
         // rows: the inducing points (dimg, features xm1 of output dim d); columns: the observations of output dim d -> R1' [d][n][.]
         rc = wlo ? pg_launch_pass<KS, true>(D, dimg, 0, xm1, cobs1, 1, r1p, L.MT, L.NT, po, st)
                  : pg_launch_pass<KS, false>(D, dimg, 0, xm1, cobs1, 1, r1p, L.MT, L.NT, po, st);
         if (rc != DPGP_OK) return rc;
         // rows: the observations of output dim d (cobs1, y-weighted features xobs1); columns: the inducing points -> R2' [d][m][.]
+        po.col_major = 1;
         rc = wlo ? pg_launch_pass<KS, true>(D, cobs1, 1, xobs1, dimg, 0, r2p, L.NT, L.MT, po, st)
                  : pg_launch_pass<KS, false>(D, cobs1, 1, xobs1, dimg, 0, r2p, L.NT, L.MT, po, st);
         if (rc != DPGP_OK) return rc;

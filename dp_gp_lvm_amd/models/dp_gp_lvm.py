@@ -286,7 +286,8 @@ def dp_gp_lvm(y_train,
         mark(3)
         # trouble flag of the LOCAL output dims (a Cholesky / conditioning flag of the forward evaluation or a non-finite
         # partial gradient), reduced with the gradients: every rank sees the same decision (optimise() branches on it)
-        flat[-1] = ((gws.info != 0).any() | ~torch.isfinite(flat[:-1]).all()).to(TORCH_DTYPE)
+        _lib.check(lib.dpgp_trouble_flag(flat.numel() - 1, flat.data_ptr(), d_local, gws.info.data_ptr(),
+                                         flat[-1:].data_ptr(), st), 'dpgp_trouble_flag')
         if sharded:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)      # one packed exchange (N Q x 2 + M Q + ...)
         grad_state['flag'] = flat[-1]

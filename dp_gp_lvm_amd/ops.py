@@ -175,6 +175,22 @@ def trsm_batched(l_, rhs, algo='auto'):
     return x
 
 
+def tril_inverse_batched(l_):
+    """tf.matrix_triangular_solve(l, eye, lower=True) on [B,M,M] fp64 -> L^-1 [B,M,M] (lower, zeros above the diagonal).  M a multiple
+    of 128: one persistent-workgroup launch (dpgp_trtri_lower_batched_f64); otherwise dpgp_trsm_batched on the identity."""
+    f64 = torch.float64
+    l_ = _prep(l_, f64, 'l')
+    b, m = l_.shape[0], l_.shape[1]
+    assert l_.dim() == 3 and l_.shape[2] == m
+    if m % 128 != 0:
+        return trsm_batched(l_, torch.eye(m, dtype=f64, device=l_.device).expand(b, m, m).contiguous())
+    out = torch.empty_like(l_)
+    ws = _ws(8 * b, l_.device)
+    _lib.check(_lib.lib().dpgp_trtri_lower_batched_f64(b, m, l_.data_ptr(), out.data_ptr(), ws.data_ptr(), 8 * b, _stream()),
+               'dpgp_trtri_lower_batched_f64')
+    return out
+
+
 def matmul(a, b, out=None, alpha=1.0, beta=0.0):
     """tf.matmul on fp64 device tensors of 2 or 3 dimensions (batch broadcast as in TensorFlow / torch.matmul), through the
     library's strided batched MFMA kernel (dpgp_gemm_strided_f64): transposed or sliced VIEWS are passed by their strides, no
@@ -523,12 +539,11 @@ def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma, psi2_slabs=
     v = raw[off_v:off_v + 8 * ns1 * d * m].view(f64).view(ns1, d, m).sum(dim=0)
     yy = raw[off_yy:off_yy + 8 * nyy * d].view(f64).view(nyy, d).sum(dim=0)
     k_uu = ard_rbf_gram(_prep(z, f64, 'z'), None, gamma, alpha, beta, include_noise=False, include_jitter=True, jitter=jitter)
-    eye = torch.eye(m, dtype=f64, device=dev).expand(d, m, m).contiguous()
     l_k, info_k = potrf_batched(k_uu)
     l_b, info_b = potrf_batched(k_uu + beta[:, None, None] * p2)
-    li = trsm_batched(l_k, eye)
+    li = tril_inverse_batched(l_k)
     k_inv = matmul(li.transpose(1, 2), li)
-    li = trsm_batched(l_b, eye)
+    li = tril_inverse_batched(l_b)
     b_inv = matmul(li.transpose(1, 2), li)
     del li
     w = matmul(b_inv, v[:, :, None])[:, :, 0]

@@ -131,6 +131,10 @@ int dpgp_trsm_batched_f32(int B, int M, int K, const float *l, float *rhs, void 
                           void *stream);
 int dpgp_trsm_batched_f64(int B, int M, int K, const double *l, double *rhs, void *ws, size_t ws_bytes, int algo,
                           void *stream);
+/* L^-1 of B lower-triangular factors l[B][M][M] (M a multiple of 128; -2 otherwise): out[B][M][M] = L^-1, lower, zeros above the
+ * diagonal — tf.matrix_triangular_solve(l, eye) (the composed stage A of the backward pass for M > 128 forms K_uu^-1 = W^T W and
+ * B^-1 from it) as one persistent-workgroup launch per batch (potrf_persist.hip).  ws: B doubles. */
+int dpgp_trtri_lower_batched_f64(int B, int M, const double *l, double *out, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- strided batched matrix product, fp64, on the matrix cores:  C[b] = alpha A[b] B[b] + beta C[b],
  *      A[b][i][k] = a[b a_sb + i a_si + k a_sk],  B[b][k][j] = b[b b_sb + k b_sk + j b_sj],  C likewise (element strides:
@@ -310,6 +314,10 @@ int dpgp_model_prepare_t(int D, int T, int Q, int N, int d_offset, int mask_size
                          const double *gamma_atoms_raw, const double *alpha_atoms_raw, const double *beta_atoms_raw,
                          const double *s_raw, const double *g1_raw, const double *g2_raw, const double *w_raw, double s1,
                          double s2, int add_constants, double *s, double *phi, double *atoms, double *scal, void *stream);
+/* The trouble flag of a gradient evaluation: out[0] = 1.0 if any info[0..d) != 0 (failed factorisation / conditioning guard of the
+ * forward evaluation) or any of flat[0..n) is not finite, else 0.0 — the value the host-side optimiser loop branches on where the
+ * reference's tf.cholesky raises (dp_gp_lvm.py:116,127), reduced over the ranks with the packed gradients.  One launch. */
+int dpgp_trouble_flag(size_t n, const double *flat, int d, const int *info, double *out, void *stream);
 /* Model-level backward pass (first version): d objective / d (the reference's eleven raw trainable variables,
  * dp_gp_lvm.py:63-94, dirichlet_process.py:40-59) from d f_hat / d (mu, S, z, gamma, alpha, beta) of dpgp_elbo_grad_chain +
  * dpgp_elbo_grad_psi, for the D output dims resident on this GPU.  phi[D,T]: as written by dpgp_model_prepare.  Outputs are

@@ -212,6 +212,21 @@ def test_trsm_many_right_hand_sides(dev, shape):
     close(x, x_ref, dict(rtol=1e-10, atol_rel=1e-12), 'trsm')
 
 
+@pytest.mark.parametrize('m', [128, 256, 512, 200])
+def test_inverse_of_a_lower_triangular_factor(dev, m):
+    """tf.matrix_triangular_solve(l, eye): the persistent-workgroup solve with every block row stored (M a multiple of 128), the
+    column-chunk kernel otherwise; lower, exact zeros above the diagonal."""
+    rng = np.random.default_rng(m + 1)
+    b = 3
+    a = rng.standard_normal((b, m, m + 3))
+    a = a @ a.transpose(0, 2, 1) + 0.5 * m * np.eye(m)
+    l_ref = np.linalg.cholesky(a)
+    w = ops.tril_inverse_batched(T(l_ref, torch.float64, dev))
+    w_ref = np.stack([np.linalg.inv(l_ref[i]) for i in range(b)])
+    close(w, w_ref, dict(rtol=1e-10, atol_rel=1e-12), 'L^-1')
+    assert float(torch.triu(w, 1).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('m', [200, 256, 300, 512])
 @pytest.mark.parametrize('dt', [torch.float64, torch.float32])
 def test_potrf_large_multi_workgroup(dev, m, dt):
