@@ -1038,29 +1038,29 @@ static int model_backward_run(int D, int T, int Q, int N, int M, int d_offset, i
 // optimise() branches on, summed over the ranks with the packed gradients; eight small torch kernels before) ----
 __global__ __launch_bounds__(1024) void trouble_flag_kernel(size_t n, const double *__restrict__ flat, int d, const int *__restrict__ info,
                                                             double *__restrict__ out) {
-    __shared__ int bad_w[16];
+    // out[0] is zero on entry (dpgp_trouble_flag clears it on the stream); a workgroup that sees trouble stores 1 (every writer the same value)
     const int t = threadIdx.x;
+    const size_t i0 = (size_t)blockIdx.x * 1024 + t, stride = (size_t)gridDim.x * 1024;
     int bad = 0;
-    for (size_t i = t; i < n; i += 1024) {
+    for (size_t i = i0; i < n; i += stride) {
         const double v = flat[i];
         bad |= !(fabs(v) <= 1.7976931348623157e308);            // (NaN compares false)
     }
-    for (int i = t; i < d; i += 1024) bad |= info[i] != 0;
-    bad = __any(bad);
-    if ((t & 63) == 0) bad_w[t >> 6] = bad;
-    __syncthreads();
-    if (t == 0) {
-        int b = 0;
-        for (int w = 0; w < 16; ++w) b |= bad_w[w];
-        out[0] = b ? 1.0 : 0.0;
-    }
+    for (size_t i = i0; i < (size_t)d; i += stride) bad |= info[i] != 0;
+    if (__any(bad) && (t & 63) == 0) out[0] = 1.0;
 }
 extern "C" int dpgp_trouble_flag(size_t n, const double *flat, int d, const int *info, double *out, void *stream) {
     if (n > 0 && !flat) return -2;
     if (d < 0 || (d > 0 && !info)) return -4;
     if (!out) return -5;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return DPGP_ERR_LAUNCH;
+    const size_t work = n > (size_t)d ? n : (size_t)d;
+    unsigned grid = (unsigned)((work + 8191) / 8192);
+    if (grid < 1) grid = 1;
+    if (grid > 256) grid = 256;
     DPGP_PRELAUNCH();
-    hipLaunchKernelGGL(trouble_flag_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, flat, d, info, out);
+    hipLaunchKernelGGL(trouble_flag_kernel, dim3(grid), dim3(1024), 0, st, n, flat, d, info, out);
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
