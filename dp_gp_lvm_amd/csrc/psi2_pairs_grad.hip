@@ -55,6 +55,11 @@ template <> struct PgCfg<6> { static constexpr int NFB = 1, G = 2, NW = 8, WPS =
 #endif
 template <> struct PgCfg<8> { static constexpr int NFB = 2, G = PG_G8, NW = PG_NW8, WPS = PG_WPS8; };   // (G = 2 at two waves per SIMD spills 130 registers)
 __host__ __device__ inline int pg_nfb(int KS) { return KS >= 8 ? 2 : 1; }
+// 1 KB pieces of the feature image of one row tile.  One block: [hi | lo] x [K-step 0 | 1].  Two blocks (33 .. 41 features, Q = 16 .. 20):
+// the second block holds at most 9 features — its hi words sit in rows 0-15 and its lo words in rows 16-31 of ONE operand, so that
+// (X_hi, W_hi) and (X_lo, W_hi) are one matrix instruction and the block needs no lo plane: 6 pieces, 5 products per K-step half instead
+// of 8 and 6 (the rows r and r + 16 of its result are added in the pass kernel's epilogue)
+__host__ __device__ constexpr int pg_xp(int NFB) { return NFB == 2 ? 6 : 4; }
 // a pass result: [column tile][feature f < NF][32 columns]; col = (set * padded columns) + column, padded to tiles of 32
 template <int NF> __device__ __forceinline__ size_t pg_oix(size_t col, int f) { return ((col >> 5) * NF + f) * 32 + (col & 31); }
 
@@ -64,14 +69,18 @@ __device__ __forceinline__ int pg_xt_index(int f, int rr) {
     const int c = rr >> 3, h = (rr >> 2) & 1, j = rr & 3, s_ = c >> 1, t_ = 4 * (c & 1) + j;
     return (((s_ * 2 + h) * 32) + f) * 8 + t_;
 }
-// feature f (< 32 NFB) of row rr as an f16 (hi, lo) pair into the transposed images of this row tile: xt = [block][hi | lo][1024]
+// feature f of row rr as an f16 (hi, lo) pair into the transposed images of this row tile: xt = [hi | lo][1024] of block 0, then the one plane of block 1 (pg_xp)
 __device__ __forceinline__ void pg_put(_Float16 *xt, int f, int rr, float v) {
     v = dpgp_pin(v);
-    const _Float16 vh = (_Float16)v;
-    _Float16 *xh = xt + (size_t)(f >> 5) * 2048;
-    const int ix = pg_xt_index(f & 31, rr);
-    xh[ix] = vh;
-    xh[1024 + ix] = (_Float16)(v - (float)vh);
+    const _Float16 vh = (_Float16)v, vl = (_Float16)(v - (float)vh);
+    if (f < 32) {
+        const int ix = pg_xt_index(f, rr);
+        xt[ix] = vh;
+        xt[1024 + ix] = vl;
+    } else {                                                  // second block (f < 48): hi in row f - 32, lo in row f - 16 of its one plane
+        xt[2048 + pg_xt_index(f - 32, rr)] = vh;
+        xt[2048 + pg_xt_index(f - 16, rr)] = vl;
+    }
 }
 
 // ---- the row of the exponent GEMM's A operand for observation n of output dim d (as phase A of psi2_pairs_kernel) --------
@@ -273,10 +282,10 @@ __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const 
                                                             _Float16 *__restrict__ ximg, int NT, int *__restrict__ flag,
                                                             const double *__restrict__ y, int ldy) {
     // y != nullptr: the images of the Psi1 term (den = g s + 1, half coefficients, features weighted by y_nd)
-    constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
+    constexpr int NFB = PgCfg<KS>::NFB, XP = pg_xp(NFB), NFZ = NFB == 2 ? 48 : 32;   // (NFZ: feature slots that exist in the image)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *gq = reinterpret_cast<float *>(smem_raw), *zc = gq + 32;
-    _Float16 *xt = reinterpret_cast<_Float16 *>(smem_raw + 256);                   // [8 tiles][NFB][2][2][64][8]
+    _Float16 *xt = reinterpret_cast<_Float16 *>(smem_raw + 256);                   // [8 tiles][XP pieces][64][8]
     const int d = blockIdx.y, t = threadIdx.x, n0 = 256 * blockIdx.x;
     if (t < 32) {
         gq[t] = (t < Q) ? (float)gamma[(size_t)d * Q + t] : 0.0f;
@@ -285,13 +294,13 @@ __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const 
     __syncthreads();
     const int tile0 = n0 / 32, ntl = min(8, NT - tile0);
     {
-        _Float16 *xr = xt + (size_t)(t >> 5) * 2048 * NFB;
+        _Float16 *xr = xt + (size_t)(t >> 5) * 512 * XP;
         const bool valid = n0 + t < N;
         const float xw = (y && valid) ? (float)y[(size_t)(n0 + t) * ldy + d] : 1.0f;
         unsigned row[8 * KS];
         const bool oor = pg_obs_row<KS>(valid, n0 + t, Q, mu, s, gq, zc, row, xr, t & 31, y ? 1.0f : 2.0f, y ? 0.5f : 1.0f, xw);
         pg_put(xr, 2 * Q, t & 31, valid ? xw : 0.0f);
-        for (int f = 2 * Q + 1; f < NF; ++f) pg_put(xr, f, t & 31, 0.0f);
+        for (int f = 2 * Q + 1; f < NFZ; ++f) pg_put(xr, f, t & 31, 0.0f);
         if (oor) atomicOr(flag, 1);
         // the row's 2 KS sixteen-byte pieces straight into the operand-order image: piece (ks, half) of the 32 rows of a tile is a
         // 512-byte run
@@ -305,8 +314,8 @@ __global__ __launch_bounds__(256) void pg_obs_images_kernel(int N, int Q, const 
         }
     }
     __syncthreads();
-    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * NT + tile0) * 256 * NFB;
-    for (int e = t; e < ntl * 256 * NFB; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
+    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * NT + tile0) * 64 * XP;
+    for (int e = t; e < ntl * 64 * XP; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
 }
 
 // pair side: thread = pair; ximg per output dim (features x kap_d u_dp).  pimg: an operand-order image of Ppad rows (the pair image
@@ -315,8 +324,8 @@ template <int KS>
 __global__ __launch_bounds__(256) void pg_pair_images_kernel(int Ppad, int Q, const _Float16 *__restrict__ pimg,
                                                              const float *__restrict__ u, const float *__restrict__ kap,
                                                              _Float16 *__restrict__ ximg) {
-    constexpr int SLP = 16 * KS, NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
-    __shared__ __align__(16) _Float16 xt[8 * 2048 * NFB];
+    constexpr int SLP = 16 * KS, NFB = PgCfg<KS>::NFB, XP = pg_xp(NFB), NFZ = NFB == 2 ? 48 : 32;
+    __shared__ __align__(16) _Float16 xt[8 * 512 * XP];
     struct { int Ppad; } C = {Ppad};
     const int d = blockIdx.y, t = threadIdx.x, p0 = 256 * blockIdx.x, p = p0 + t, PT = C.Ppad / 32;
     const int tile0 = p0 / 32, ntl = min(8, PT - tile0);
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(256) void pg_pair_images_kernel(int Ppad, int Q, co
                 row[8 * ks + 4 * hf + 2] = w[2]; row[8 * ks + 4 * hf + 3] = w[3];
             }
         const float up = kap[d] * u[(size_t)d * C.Ppad + p];
-        _Float16 *xr = xt + (size_t)(t >> 5) * 2048 * NFB;
+        _Float16 *xr = xt + (size_t)(t >> 5) * 512 * XP;
         const int rr = t & 31;
 #pragma unroll
         for (int q = 0; q < DPGP_MAX_Q; ++q) {                    // slots {h, l, h | h, l, h} of (s^2 / 64, s): words 3q .. 3q + 2
@@ -344,11 +353,11 @@ __global__ __launch_bounds__(256) void pg_pair_images_kernel(int Ppad, int Q, co
             }
         }
         pg_put(xr, 2 * Q, rr, up);
-        for (int f = 2 * Q + 1; f < NF; ++f) pg_put(xr, f, rr, 0.0f);
+        for (int f = 2 * Q + 1; f < NFZ; ++f) pg_put(xr, f, rr, 0.0f);
     }
     __syncthreads();
-    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * PT + tile0) * 256 * NFB;
-    for (int e = t; e < ntl * 256 * NFB; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
+    pg_u4 *xd = reinterpret_cast<pg_u4 *>(ximg) + ((size_t)d * PT + tile0) * 64 * XP;
+    for (int e = t; e < ntl * 64 * XP; e += 256) xd[e] = reinterpret_cast<const pg_u4 *>(xt)[e];
 }
 
 // ---- Psi1 term through the same passes --------------------------------------------------------------------------------------
@@ -490,7 +499,11 @@ template <int KS, int NFB> struct PgSchedUnits2 {
 template <int KS, int NFB, bool WLO> struct PgSched : std::conditional<WLO, PgSchedUnits2<KS, NFB>, PgSchedUnits1<KS, NFB>>::type {
     typedef typename std::conditional<WLO, PgSchedUnits2<KS, NFB>, PgSchedUnits1<KS, NFB>>::type U;
     using U::NU; using U::CYC; using U::U_D3; using U::NPR; using U::unit;
-    static constexpr int NM = KS + 2 * NPR * NFB, NK = NPR * NFB;
+    // products per K-step half: (X_hi, W_hi), (X_hi, W_lo), (X_lo, W_hi) [WLO] or (X_hi, W_hi), (X_lo, W_hi) of block 0; of the stacked second
+    // block (pg_xp) its one operand against W_hi [and W_lo].  Blocks interleaved.
+    static constexpr int NK = NPR * NFB - (NFB == 2 ? 1 : 0), NM = KS + 2 * NK;
+    static constexpr int prod_fb(int i) { return NFB == 1 ? 0 : (WLO ? (i < 4 ? (i & 1) : 0) : (i == 1 ? 1 : 0)); }
+    static constexpr int prod_pr(int i) { return NFB == 1 ? (WLO ? i : 2 * i) : (WLO ? (i < 4 ? (i >> 1) : 2) : (i == 2 ? 2 : 0)); }
     // issue cycles (MI355X guide).  (v_fma_mixlo_f16 + v_fma_mixhi_f16 into one register would save the second conversion: measured
     // slower, adjacent (the second waits for the first) as well as spaced apart (the compiler pads each asm statement))
     static constexpr int cost(int u) { return (unit(u).kind & 1) ? 4 : 8; }
@@ -560,8 +573,7 @@ __device__ __forceinline__ void pg_step(pg_f16v &c_nxt, const pg_f16v &c_cur, co
                 c_nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_n[sl.i], b_n[sl.i], c_nxt, 0, 0, 0);
             }
         } else {
-            // products (X_hi, W_hi), (X_hi, W_lo), (X_lo, W_hi) [WLO] or (X_hi, W_hi), (X_lo, W_hi), blocks interleaved
-            constexpr int fb = sl.i % NFB, pr = WLO ? sl.i / NFB : 2 * (sl.i / NFB);
+            constexpr int fb = S::prod_fb(sl.i), pr = S::prod_pr(sl.i);
             if constexpr (sl.kind == 1)
                 acc_p[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? x1l[fb] : x1h[fb], pr == 1 ? wl1p : wh1p, acc_p[fb], 0, 0, 0);
             else
@@ -610,7 +622,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
                                                                    float *__restrict__ out, int n_row_tiles, int n_col_tiles,
                                                                    int groups_per_d, int NTb, PgPsi2Out po) {
     constexpr int NFB = PgCfg<KS>::NFB, NW = PgCfg<KS>::NW, NF = PG_FB * NFB;
-    constexpr int PIECES = KS + 4 * NFB, TILE_BYTES = 1024 * PIECES;   // LDS bytes of one row tile: K-steps of the exponent operand, then the features
+    constexpr int XP = pg_xp(NFB), PIECES = KS + XP, TILE_BYTES = 1024 * PIECES;   // LDS bytes of one row tile: K-steps of the exponent operand, then the features
     typedef PgSched<KS, NFB, WLO> S;
     constexpr int LA = G == 1 ? 2 : 1;                         // row tiles between an LDS read of the exponent operand and its row tile
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int RING = 3 * NTb;                                    // row-tile slots of the LDS ring: three chunks of NTb
     const unsigned char *rsrc = reinterpret_cast<const unsigned char *>(rimg) + (row_per_d ? (size_t)d * n_row_tiles * KS * 1024 : 0);
-    const unsigned char *xsrc = reinterpret_cast<const unsigned char *>(ximg) + (size_t)d * n_row_tiles * NFB * 4096;
+    const unsigned char *xsrc = reinterpret_cast<const unsigned char *>(ximg) + (size_t)d * n_row_tiles * XP * 1024;
     const _Float16 *csrc = cimg + (col_per_d ? (size_t)d * n_col_tiles * KS * 64 * 8 : 0);
     // chunk c = row tiles [c NTb, (c + 1) NTb) -> ring slots (c % 3) NTb ...: 1 KB pieces by LDS-DMA (global_load_lds_dwordx4: lane-linear
     // destination, no staging registers), piece i of the chunk by wave i % NW
@@ -633,7 +645,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
         for (int i = wv; i < ntile * PIECES; i += NW) {           // (wave-uniform)
             const int tl = i / PIECES, pc = i - tl * PIECES;
             const unsigned char *src = pc < KS ? rsrc + ((size_t)(rt0 + tl) * KS + pc) * 1024
-                                               : xsrc + ((size_t)(rt0 + tl) * NFB * 4 + (pc - KS)) * 1024;
+                                               : xsrc + ((size_t)(rt0 + tl) * XP + (pc - KS)) * 1024;
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const pg_u4 *>(src) + lane, (lds_void *)(base + (size_t)1024 * i), 16, 0, 0);
         }
     };
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
             if (i < npc) {
                 const int tl = i / PIECES, pc = i - tl * PIECES;
                 const unsigned char *src = pc < KS ? rsrc + ((size_t)(rt0 + tl) * KS + pc) * 1024
-                                                   : xsrc + ((size_t)(rt0 + tl) * NFB * 4 + (pc - KS)) * 1024;
+                                                   : xsrc + ((size_t)(rt0 + tl) * XP + (pc - KS)) * 1024;
                 stage[k] = reinterpret_cast<const pg_u4 *>(src)[lane];
             }
         }
@@ -701,11 +713,9 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
     };
     auto load_x = [&](pg_h8 (&xh)[NFB], pg_h8 (&xl)[NFB], int pos, int kstep) __attribute__((always_inline)) {
         const pg_h8 *p = reinterpret_cast<const pg_h8 *>(smem_raw + (size_t)pos * TILE_BYTES + 1024 * KS) + lane;
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {                        // [block][kind][K-step][64 lanes]
-            xh[fb] = p[((fb * 2 + 0) * 2 + kstep) * 64];
-            xl[fb] = p[((fb * 2 + 1) * 2 + kstep) * 64];
-        }
+        xh[0] = p[kstep * 64];                                    // block 0: [hi | lo][K-step][64 lanes]
+        xl[0] = p[(2 + kstep) * 64];
+        if constexpr (NFB == 2) xh[1] = p[(4 + kstep) * 64];      // block 1: its one plane (hi rows 0-15, lo rows 16-31)
     };
     pg_h8 a_0[KS], a_1[KS], x0h[NFB], x0l[NFB], x1h[NFB], x1l[NFB];
     pg_h8 wh1 = pg_quad(0u, 0u, 0u, 0u), wl1 = wh1;             // (the first step's "previous" products add zero)
@@ -796,10 +806,16 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
     }
     // the last step's K-step-1 half
 #pragma unroll
-    for (int i = 0; i < 3 * NFB; ++i) {
-        const int fb = i % NFB, pr = i / NFB;
-        if (!WLO && pr == 1) continue;
+    for (int i = 0; i < S::NK; ++i) {
+        const int fb = S::prod_fb(i), pr = S::prod_pr(i);
         acc[G - 1][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? x1l[fb] : x1h[fb], pr == 1 ? wl1 : wh1, acc[G - 1][fb], 0, 0, 0);
+    }
+    // the stacked second block: feature 32 + r = rows r and r + 16 of its result (registers v and v + 8)
+    if constexpr (NFB == 2) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc[g][1][v] += acc[g][1][v + 8];
     }
     // ---- out[d][column][f]: register v of lane (column l5, half) of block fb is feature 32 fb + 8 (v / 4) + 4 half + v % 4 ----
     // po.part != nullptr (pass 1 of a training step): feature po.fsel (the constant 1) is the column sum of the exponentials, i.e.
@@ -831,7 +847,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-                for (int vq = 0; vq < 4; ++vq)
+                for (int vq = 0; vq < (fb ? 2 : 4); ++vq)
                     *reinterpret_cast<pg_f4 *>(oc + 32 * fb + 8 * vq) =
                         (pg_f4){acc[g][fb][4 * vq], acc[g][fb][4 * vq + 1], acc[g][fb][4 * vq + 2], acc[g][fb][4 * vq + 3]};
             continue;
@@ -840,7 +856,7 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) o[(32 * fb + 8 * (v >> 2) + (v & 3)) * 32] = acc[g][fb][v];
+            for (int v = 0; v < (fb ? 8 : 16); ++v) o[(32 * fb + 8 * (v >> 2) + (v & 3)) * 32] = acc[g][fb][v];   // (block 1: features 32 .. 47)
     }
 }
 
@@ -1113,12 +1129,12 @@ __global__ void pg_poison_kernel(const int *__restrict__ flag, double *dmu, doub
 // ---------------------------------------------------------------------------------------------------------------
 bool psi2_pgrad_supported(int M, int Q) {
     const int ks = psi2_pairs_ksteps(Q);
-    return ks <= 8 && 2 * Q + 1 <= PG_FB * pg_nfb(ks) && M >= 1 && M <= 4096;
+    return ks <= 8 && 2 * Q + 1 <= (pg_nfb(ks) == 2 ? 48 : PG_FB) && M >= 1 && M <= 4096;   // (a second block holds 16 features: pg_xp)
 }
 
 template <int KS> static int pg_ring_tiles() {                   // row tiles per chunk of the pass kernel's LDS ring
-    // three chunks of NTb row tiles (KS + 4 NFB KB each) in the workgroup's share of the 160 KB
-    int NTb = (int)((size_t)(160 * 1024 * PgCfg<KS>::NW / (4 * PgCfg<KS>::WPS)) / ((size_t)3 * 1024 * (KS + 4 * PgCfg<KS>::NFB)));
+    // three chunks of NTb row tiles (KS + pg_xp KB each) in the workgroup's share of the 160 KB
+    int NTb = (int)((size_t)(160 * 1024 * PgCfg<KS>::NW / (4 * PgCfg<KS>::WPS)) / ((size_t)3 * 1024 * (KS + pg_xp(PgCfg<KS>::NFB))));
     if (const char *e = getenv("DPGP_PG_NTB")) {                 // (experiments only)
         const int v = atoi(e);
         if (v >= (PgCfg<KS>::G == 1 ? 2 : 1) && v <= NTb) NTb = v;
@@ -1147,14 +1163,14 @@ static PgLayout pg_layout(int D, int N, int M, int Q) {
     L.KS = C.KS; L.P = C.P; L.Ppad = C.Ppad; L.NT = dpgp_ceil_div(N, 32); L.PT = C.Ppad / 32;
     L.NF = PG_FB * pg_nfb(C.KS);
     L.nblk_obs = dpgp_ceil_div(N, 256);
-    const size_t h = sizeof(_Float16), nfb = (size_t)pg_nfb(C.KS);
+    const size_t h = sizeof(_Float16), xp = (size_t)pg_xp(pg_nfb(C.KS));
     size_t o = 0;
     L.off_u = o;     o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad);
     L.off_kap = o;   o += dpgp_align256(sizeof(float) * (size_t)D);
     L.off_flag = o;  o += 256;
     L.off_cobs = o;  o += dpgp_align256(h * (size_t)D * L.NT * L.KS * 64 * 8);
-    L.off_xobs = o;  o += dpgp_align256(h * (size_t)D * L.NT * 2048 * nfb);
-    L.off_xpair = o; o += dpgp_align256(h * (size_t)D * L.PT * 2048 * nfb);
+    L.off_xobs = o;  o += dpgp_align256(h * (size_t)D * L.NT * 512 * xp);
+    L.off_xpair = o; o += dpgp_align256(h * (size_t)D * L.PT * 512 * xp);
     L.off_r2 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.Ppad * L.NF);
     L.off_r1 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * L.NF);
     L.off_tp = o;    o += dpgp_align256(sizeof(double) * (size_t)PG_DC_PAIRS * 3 * L.P * Q);
@@ -1164,9 +1180,9 @@ static PgLayout pg_layout(int D, int N, int M, int Q) {
     L.off_dgp = o;   o += dpgp_align256(sizeof(double) * (size_t)4 * L.nblk_obs * D * Q);
     L.MT = dpgp_ceil_div(M, 32);
     L.off_cobs1 = o; o += dpgp_align256(h * (size_t)D * L.NT * L.KS * 64 * 8);
-    L.off_xobs1 = o; o += dpgp_align256(h * (size_t)D * L.NT * 2048 * nfb);
+    L.off_xobs1 = o; o += dpgp_align256(h * (size_t)D * L.NT * 512 * xp);
     L.off_dimg = o;  o += dpgp_align256(h * (size_t)L.MT * L.KS * 64 * 8);
-    L.off_xm1 = o;   o += dpgp_align256(h * (size_t)D * L.MT * 2048 * nfb);
+    L.off_xm1 = o;   o += dpgp_align256(h * (size_t)D * L.MT * 512 * xp);
     L.off_r1p = o;   o += dpgp_align256(sizeof(float) * (size_t)D * L.NT * 32 * L.NF);
     L.off_r2p = o;   o += dpgp_align256(sizeof(float) * (size_t)D * L.MT * 32 * L.NF);
     L.off_u1 = o;    o += dpgp_align256(sizeof(float) * (size_t)D * L.MT * 32);
@@ -1184,7 +1200,7 @@ static int pg_launch_pass_g(int D, const _Float16 *rimg, int row_per_d, const _F
                             float *out, int n_row_tiles, int n_col_tiles, const PgPsi2Out &po, hipStream_t st) {
     constexpr int NFB = PgCfg<KS>::NFB, NW = PgCfg<KS>::NW;
     const int NTb = pg_ring_tiles<KS>();
-    const size_t lds = (size_t)3 * NTb * 1024 * (KS + 4 * NFB);
+    const size_t lds = (size_t)3 * NTb * 1024 * (KS + pg_xp(NFB));
     auto kern = pg_pass_kernel<KS, WLO, G>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DPGP_ERR_LAUNCH;
@@ -1235,7 +1251,7 @@ static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *c
     const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
     if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return DPGP_ERR_LAUNCH;
     {
-        const size_t lds = 256 + sizeof(_Float16) * 8 * 2048 * NFB;
+        const size_t lds = 256 + sizeof(_Float16) * 8 * 512 * pg_xp(NFB);
         auto kern = pg_obs_images_kernel<KS>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return DPGP_ERR_LAUNCH;
@@ -1311,7 +1327,7 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
         float *r2p = reinterpret_cast<float *>(ws + L.off_r2p), *u1 = reinterpret_cast<float *>(ws + L.off_u1);
         const int Mpad = 32 * L.MT;
         {
-            const size_t lds = 256 + sizeof(_Float16) * 8 * 2048 * NFB;
+            const size_t lds = 256 + sizeof(_Float16) * 8 * 512 * pg_xp(NFB);
             auto kern = pg_obs_images_kernel<KS>;
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return DPGP_ERR_LAUNCH;
