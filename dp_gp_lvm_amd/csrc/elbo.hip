@@ -903,25 +903,28 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
     // df_dgamma [T][Q] and df_dab [T][2] are d f_hat / d (softplus'd atoms) themselves, and phi enters f_hat directly: df_dphi [D][T]
     if (blockIdx.x == 0) {
         // A[k][j] = sum_d phi[d,k] X[d,j], X = [df/dgamma (Q) | df/dalpha | df/dbeta | 1]: output dims staged through LDS in
-        // chunks of 32 (coalesced loads, fixed summation order) instead of one serial pass over D per thread
+        // chunks (coalesced loads, fixed summation order) instead of one serial pass over D per thread; as many output dims per chunk as
+        // 2048 doubles hold (128 at T = 8, Q = 10: four barriers pairs at D = 512 where chunks of 32 took sixteen: 69 -> ~30 us)
         const int cols = Q + 3;                          // j < Q: gamma atoms; Q: alpha atoms; Q+1: beta atoms; Q+2: sum_d phi
-        __shared__ double ph_s[32][PREP_MAX_T], x_s[32][DPGP_MAX_Q + 3], sphi_s[PREP_MAX_T];
+        __shared__ double ph_s[2048], x_s[2048], sphi_s[PREP_MAX_T];
+        int DC = 2048 / (T > cols ? T : cols);
+        DC = DC > 128 ? 128 : DC;
         for (int e0 = 0; e0 < T * cols; e0 += 256) {
             const int e = e0 + t, k = e / cols, j = e - k * cols;
             double acc = 0.0;
-            for (int dc = 0; dc < D; dc += 32) {
+            for (int dc = 0; dc < D; dc += DC) {
                 __syncthreads();
-                for (int i = t; i < 32 * T; i += 256) {
-                    const int dd = i / T, kk = i - dd * T;
-                    ph_s[dd][kk] = (dc + dd < D) ? phi[(size_t)(dc + dd) * T + kk] : 0.0;
+                for (int i = t; i < DC * T; i += 256) {
+                    const int dd = i / T;
+                    ph_s[i] = (dc + dd < D) ? phi[(size_t)dc * T + i] : 0.0;
                 }
-                for (int i = t; i < 32 * cols; i += 256) {
+                for (int i = t; i < DC * cols; i += 256) {
                     const int dd = i / cols, jj = i - dd * cols, d = dc + dd;
-                    x_s[dd][jj] = (d < D) ? (jj > Q + 1 ? 1.0 : (df_dphi ? 0.0 : (jj < Q ? df_dgamma[(size_t)d * Q + jj] : (jj == Q ? df_dab[2 * d] : df_dab[2 * d + 1])))) : 0.0;
+                    x_s[i] = (d < D) ? (jj > Q + 1 ? 1.0 : (df_dphi ? 0.0 : (jj < Q ? df_dgamma[(size_t)d * Q + jj] : (jj == Q ? df_dab[2 * d] : df_dab[2 * d + 1])))) : 0.0;
                 }
                 __syncthreads();
                 if (e < T * cols)
-                    for (int dd = 0; dd < 32; ++dd) acc += ph_s[dd][k] * x_s[dd][j];
+                    for (int dd = 0; dd < DC; ++dd) acc += ph_s[dd * T + k] * x_s[dd * cols + j];
             }
             if (e < T * cols) {
                 if (j <= Q + 1) {
