@@ -45,6 +45,8 @@ if [ "$part" = pmc ] || [ "$part" = all ]; then
   # the pass kernel of stage B (config 3 training step): the counters the round-3 verdict asked for, two SQ passes + GRBM
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_grad1 -- python3 $O/grad_run.py 3 2 > $O/pmc_grad1.log 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grad2 -- python3 $O/grad_run.py 3 2 > $O/pmc_grad2.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_grad5_1 -- python3 $O/grad_run.py 5 2 > $O/pmc_grad5_1.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grad5_2 -- python3 $O/grad_run.py 5 2 > $O/pmc_grad5_2.log 2>&1
   echo "bench pmc done" >> $O/progress.txt
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_la_fetch -- python3 scratch/prof_linalg.py 3 > $O/pmc_la_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_la_write -- python3 scratch/prof_linalg.py 3 > $O/pmc_la_write.log 2>&1

@@ -53,10 +53,11 @@ for k, v in vals.items():
 if rec:
     json.dump(rec, open(os.path.join(O, 'traffic.json'), 'w'), indent=1)
     P('traffic.json:', json.dumps(rec))
-P('== PMC of the training step at config 3 (model.gradients() x 2), averages per dispatch: the pass kernel of stage B')
+P('== PMC of the training step at configs 3 and 5 (model.gradients() x 2), averages per dispatch: the pass kernel of stage B')
 gp = collections.defaultdict(dict)
-for tag in ('pmc_grad1', 'pmc_grad2'):
+for tag in ('pmc_grad1', 'pmc_grad2', 'pmc_grad5_1', 'pmc_grad5_2'):          # (..5_: the same at config 5, the Q = 20 form of the kernel)
     for k, d in agg_pmc(tag, ('pg_pass_kernel',)).items():
+        k = k + (' [config 5]' if '5_' in tag else '')
         for c, v in d.items():
             P('  %-50s %-30s %.6g' % (k, c, v)); gp[k][c] = v
 for k, v in gp.items():
