@@ -75,7 +75,8 @@ template <typename TP, typename TL>
 static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                     const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                     int algo, double *terms, double *sums, int *info, unsigned char *ws, const ElboLayout &L,
-                    hipStream_t st, const dpgp_exec_t *ex, TL *lb_out = nullptr, unsigned char *pgws = nullptr) {
+                    hipStream_t st, const dpgp_exec_t *ex, TL *lb_out = nullptr, unsigned char *pgws = nullptr,
+                    bool psi1_from_pass = false) {
     double *yy = reinterpret_cast<double *>(ws + L.off_yy);
     double *ldk = reinterpret_cast<double *>(ws + L.off_ld);
     int *ik = reinterpret_cast<int *>(ws + L.off_ik);
@@ -102,7 +103,11 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
             return DPGP_ERR_LAUNCH;
         aj.arm(st, aux, (hipEvent_t)ex->ev_join);
     }
-    if ((rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1, aux ? aux : st)))
+    // psi1_from_pass (dpgp_elbo_step): Psi1^T y comes out of the Psi1 term's adjoint-free pass of stage B (rows = observations, columns
+    // = inducing points, y-weighted features: psi2_pairs_grad.hip, launch_psi1_front) as ONE slab — no Psi1^T y launch here
+    const int ns1 = psi1_from_pass ? 1 : L.ns1;
+    if (!psi1_from_pass &&
+        (rc = launch_psi1T_y_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, y, ldy, vpart, L.ns1, pconst, 1, aux ? aux : st)))
         return rc;
     // training step with a second stream: the K_uu branch (a launch of its own there, 0.12 ms of latency-bound Cholesky work at config
     // 3) follows Psi1^T y on it, beside the image build and the head of pass 1
@@ -132,7 +137,8 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     if (step) {
         if constexpr (sizeof(TP) == 4) {
             if ((rc = launch_psi2_pgrad(D, N, M, Q, pconst, z, mu, s, gamma, alpha, nullptr, pgws, nullptr, nullptr, nullptr, nullptr,
-                                        nullptr, st, 1, reinterpret_cast<float *>(p2), pscale)))
+                                        nullptr, st, 1, reinterpret_cast<float *>(p2), pscale, psi1_from_pass ? y : nullptr, ldy, nullptr, 0,
+                                        psi1_from_pass ? vpart : nullptr)))
                 return rc;
         }
     } else if ((rc = launch_psi2_partial<double, TP>(D, N, M, Q, z, mu, s, gamma, alpha, p2, L.ns2, algo, st,
@@ -146,12 +152,12 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     if (big && lb_out) return -30;
     if constexpr (sizeof(TL) == 8) {
         if (big)
-            return launch_chain_big_b<TP>(D, N, M, p2, step ? 1 : L.ns2, vpart, L.ns1, alpha, beta, yy, ik, terms, info,
+            return launch_chain_big_b<TP>(D, N, M, p2, step ? 1 : L.ns2, vpart, ns1, alpha, beta, yy, ik, terms, info,
                                           reinterpret_cast<double *>(ws + L.off_guard), reinterpret_cast<double *>(la), st, klp,
                                           sums, ex ? (const double *)ex->model_scal : nullptr,
                                           ex ? (double *)ex->model_pack : nullptr, ex ? (double *)ex->model_out : nullptr);
     }
-    return launch_chain_b<TP, TL>(D, N, M, p2, step ? 1 : L.ns2, vpart, L.ns1, alpha, beta, yy, ldk, ik, terms, info,
+    return launch_chain_b<TP, TL>(D, N, M, p2, step ? 1 : L.ns2, vpart, ns1, alpha, beta, yy, ldk, ik, terms, info,
                                   reinterpret_cast<double *>(ws + L.off_guard), la, algo, st, klp, sums,
                                   ex ? (const double *)ex->model_scal : nullptr, ex ? (double *)ex->model_pack : nullptr,
                                   ex ? (double *)ex->model_out : nullptr, lb_out);
@@ -213,7 +219,7 @@ static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, 
                           const double *gamma, const double *alpha, const double *g_psi2, const double *w_kuu, const double *g_v,
                           const double *g_psi1, bool patch_form, unsigned char *ws, double *d_mu, double *d_s, double *d_z,
                           double *d_gamma, hipStream_t st, const unsigned char *fwd_consts, const float *fwd_scale,
-                          const float *fwd_psi2 = nullptr, int w11 = 0) {
+                          const float *fwd_psi2 = nullptr, int w11 = 0, double *psi1_front_done = nullptr) {
     // K_uu term by the plain kernel (no pass over the observations), Psi1 by the reduction-free kernels, Psi2 (nearly all
     // of the work) on the matrix pipe -- where those apply; otherwise everything by the plain kernel
     const bool fast = psi2_grad_supported(M, Q) && !getenv("DPGP_GRAD_PLAIN");
@@ -244,7 +250,7 @@ static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, 
     if (pair_form)
         return launch_psi2_pgrad(D, N, M, Q, consts, z, mu, s, gamma, alpha, g_psi2, W.pgws, W.stage, d_mu, d_s, d_z, d_gamma, st,
                                  fwd_consts ? 2 : 3, const_cast<float *>(fwd_psi2), fwd_scale, psi1_pairs ? y : nullptr, ldy,
-                                 psi1_pairs ? g_v : nullptr, w11);
+                                 psi1_pairs ? g_v : nullptr, w11, (fwd_consts && psi1_pairs) ? psi1_front_done : nullptr);
     if (fwd_consts) return -30;
     return launch_psi2_grad(D, N, M, Q, consts, mu, s, gamma, alpha, g_psi2, W.part, W.stage, d_mu, d_s, d_z, d_gamma, st);
 }
@@ -409,18 +415,21 @@ extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int l
     hipStream_t st = (hipStream_t)stream;
     unsigned char *w = (unsigned char *)ws;
     const GradPsiWs W = grad_psi_ws(D, N, M, Q, (unsigned char *)gws, false);
+    // (DPGP_PSI1_PLAIN, an experiment switch of grad_psi_mixed, keeps the Psi1 term off the passes: then the forward's own Psi1^T y launch)
+    const bool v_from_pass = !getenv("DPGP_PSI1_PLAIN") && !getenv("DPGP_GRAD_PATCH") && !getenv("DPGP_GRAD_PLAIN");
     int rc = elbo_run<float, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums, info, w,
-                                     L, st, exec, nullptr, W.pgws);
+                                     L, st, exec, nullptr, W.pgws, v_from_pass);
     if (rc != DPGP_OK) return rc;
-    // stage A on the ONE slab pass 1 left
+    // stage A on the ONE slab pass 1 left (and the one slab of Psi1^T y)
     rc = launch_chain_grad<float>(D, N, M, reinterpret_cast<const float *>(w + L.off_p2), 1,
-                                  reinterpret_cast<const double *>(w + L.off_v), L.ns1, alpha, beta,
+                                  reinterpret_cast<const double *>(w + L.off_v), v_from_pass ? 1 : L.ns1, alpha, beta,
                                   reinterpret_cast<const double *>(w + L.off_yy), jitter, reinterpret_cast<double *>(w + L.off_la),
                                   g_psi2, w_kuu, g_v, d_alpha_beta, info_grad, st);
     if (rc != DPGP_OK) return rc;
     return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, nullptr, false, (unsigned char *)gws, d_mu,
                           d_s, d_z, d_gamma, st, w + L.off_pc, reinterpret_cast<const float *>(w + L.off_sc),
-                          reinterpret_cast<const float *>(w + L.off_p2), prec == DPGP_PREC_MIXED_FAST ? 1 : 0);
+                          reinterpret_cast<const float *>(w + L.off_p2), prec == DPGP_PREC_MIXED_FAST ? 1 : 0,
+                          v_from_pass ? reinterpret_cast<double *>(w + L.off_v) : nullptr);
 }
 
 // The two halves of the step as entry points of their own (M > 128: stage A between them is composed on the host side):

@@ -150,5 +150,5 @@ int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, c
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
                       double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st, int which = 3,
                       float *psi2_part = nullptr, const float *scale = nullptr, const double *y = nullptr, int ldy = 0,
-                      const double *Gv = nullptr, int fast = 0);
+                      const double *Gv = nullptr, int fast = 0, double *psi1v = nullptr);
 // (y, Gv != nullptr: the Psi1 term with the rank-1 adjoint g_v[d][a] y[n][d] through the same passes: dmu, ds overwritten)

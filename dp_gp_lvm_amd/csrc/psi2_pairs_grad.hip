@@ -463,6 +463,9 @@ struct PgPsi2Out {                    // Psi2 as a by-product of pass 1 (see the
     const int *flag;                  // range-guard flag of the image build
     int Mp, Ppad, fsel;
     int col_major;                    // != 0: out[set][column][32 NFB features] (the reader is a thread per (output dim, column): pg_finish_m1_kernel)
+    double *vout;                     // [D][vM] or nullptr: alpha_d 2^-12 x the column sums of feature fsel (the Psi1 pass with rows =
+    const double *valpha;             //   observations, y-weighted features: Psi1^T y of the forward pass, elbo_run's v)
+    int vM;
 };
 struct PgSlot { int kind, i; };      // kind 0: exponent chain K-step i; 1: product i of the previous step's K-step-1 half; 2: of this step's K-step-0 half
 struct PgUnit { int kind, i; };      // kind 0: v_exp_f32 of element i; 1: v_cvt_pk_f16_f32 (hi) of element pair i; 2: the two v_fma_mix_f32 (e - hi) of pair i; 3: v_cvt_pk_f16_f32 (lo)
@@ -822,12 +825,12 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
     // Psi2 of output dim d up to its per-pair factor — written where the forward's psi2 kernel writes it (slab 0 of the partial
     // slabs, entries m' <= m), so the forward needs no psi2 dispatch of its own
     float poison = 0.0f;
-    if (po.part && *po.flag) poison = __builtin_nanf("");
+    if ((po.part || po.vout) && *po.flag) poison = __builtin_nanf("");
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int tile = cg * NW * G + wv + NW * g;
         if (tile >= n_col_tiles) continue;
-        if (po.part) {
+        if (po.part || po.vout) {
             const int fi = po.fsel & 31, vs = (fi >> 3) * 4 + (fi & 3), hs = (fi >> 2) & 1;
             float cs = 0.0f;
 #pragma unroll
@@ -835,10 +838,14 @@ __global__ __launch_bounds__(64 * PgCfg<KS>::NW, PgCfg<KS>::WPS) void pg_pass_ke
 #pragma unroll
                 for (int v = 0; v < 16; ++v) cs = (fb == (po.fsel >> 5) && v == vs) ? acc[g][fb][v] : cs;
             const int p = 32 * tile + l5;
-            const unsigned pm = po.pmap[p];
-            if (half == hs && pm != 0xffffffffu)
-                po.part[(size_t)d * po.Mp * po.Mp + (size_t)(pm >> 16) * po.Mp + (pm & 0xffffu)] =
-                    po.scale[(size_t)d * po.Ppad + p] * (cs * (1.0f / 4096.0f)) + poison;      // (x 2^-PG_WSHIFT)
+            if (po.part) {
+                const unsigned pm = po.pmap[p];
+                if (half == hs && pm != 0xffffffffu)
+                    po.part[(size_t)d * po.Mp * po.Mp + (size_t)(pm >> 16) * po.Mp + (pm & 0xffffu)] =
+                        po.scale[(size_t)d * po.Ppad + p] * (cs * (1.0f / 4096.0f)) + poison;      // (x 2^-PG_WSHIFT)
+            } else if (half == hs && p < po.vM) {
+                po.vout[(size_t)d * po.vM + p] = po.valpha[d] * (double)(cs * (1.0f / 4096.0f) + poison);
+            }
         }
         // feature-major inside a column tile (pg_oix): one store instruction = two 128-byte runs, and the finishing kernels (thread =
         // column) read every feature as a coalesced run
@@ -1238,6 +1245,41 @@ static int pg_launch_pass(int D, const _Float16 *rimg, int row_per_d, const _Flo
     return pg_launch_pass_g<KS, WLO, G0>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
 }
 
+// The half of the Psi1 term that does not depend on the adjoints: its observation images (den = g s + 1, half coefficients, features
+// weighted by y_nd), the diagonal rows of the pair image, and the pass with rows = observations, columns = inducing points -> R2'.
+// psi1v != nullptr (training step): the same pass's y-weighted constant feature gives Psi1^T y of the forward pass, [D][M] — the
+// forward's Psi1^T y launch is not needed (as Psi2 out of pass 1).
+template <int KS>
+static int launch_psi1_front(int D, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
+                             const double *gamma, const double *alpha, unsigned char *ws, const double *y, int ldy, double *psi1v,
+                             hipStream_t st, bool wlo) {
+    constexpr int NFB = PgCfg<KS>::NFB;
+    const PgLayout L = pg_layout(D, N, M, Q);
+    const Psi2Consts C = psi2_consts_layout(M, Q);
+    int *flag = reinterpret_cast<int *>(ws + L.off_flag);
+    const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
+    _Float16 *cobs1 = reinterpret_cast<_Float16 *>(ws + L.off_cobs1), *xobs1 = reinterpret_cast<_Float16 *>(ws + L.off_xobs1),
+             *dimg = reinterpret_cast<_Float16 *>(ws + L.off_dimg);
+    float *r2p = reinterpret_cast<float *>(ws + L.off_r2p);
+    const int Mpad = 32 * L.MT;
+    {
+        const size_t lds = 256 + sizeof(_Float16) * 8 * 512 * pg_xp(NFB);
+        auto kern = pg_obs_images_kernel<KS>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
+        DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(dpgp_ceil_div(N, 256), D), dim3(256), lds, st, N, Q, consts, mu, s, gamma, cobs1, xobs1,
+                           L.NT, flag, y, ldy);
+        DPGP_LAUNCH_CHECK();
+    }
+    DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_diag_image_kernel<KS>), dim3(dpgp_ceil_div(Mpad * KS * 2, 256)), dim3(256), 0, st, M, Mpad, pimg, dimg);
+    DPGP_LAUNCH_CHECK();
+    // rows: the observations of output dim d (cobs1, y-weighted features xobs1); columns: the inducing points -> R2' [d][m][.]
+    // (the pass that also yields Psi1^T y keeps the lo half of the exponentials whatever the mode, as the one that yields Psi2)
+    PgPsi2Out po = {nullptr, nullptr, nullptr, flag, 0, 0, 2 * Q, 1, psi1v, alpha, M};
+    if (wlo || psi1v) return pg_launch_pass<KS, true>(D, cobs1, 1, xobs1, dimg, 0, r2p, L.NT, L.MT, po, st);
+    return pg_launch_pass<KS, false>(D, cobs1, 1, xobs1, dimg, 0, r2p, L.NT, L.MT, po, st);
+}
+
 // part 1 (does not depend on the adjoints): observation images, pass 1 -> R2 [and Psi2: psi2_part != nullptr]
 template <int KS>
 static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *consts, const double *mu, const double *s,
@@ -1259,7 +1301,7 @@ static int launch_pgrad_part1(int D, int N, int M, int Q, const unsigned char *c
                            flag, (const double *)nullptr, 0);
         DPGP_LAUNCH_CHECK();
     }
-    PgPsi2Out po = {psi2_part, scale, reinterpret_cast<const unsigned *>(consts + C.off_pmap), flag, dpgp_round_up(M, 16), L.Ppad, 2 * Q, 0};
+    PgPsi2Out po = {psi2_part, scale, reinterpret_cast<const unsigned *>(consts + C.off_pmap), flag, dpgp_round_up(M, 16), L.Ppad, 2 * Q, 0, nullptr, nullptr, 0};
     // rows: the observations of output dim d (cobs, xobs); columns: the pairs (the forward's pair image)
     // (the pass that also yields Psi2 keeps the lo half of the exponentials whatever the mode: the objective is not a "fast" quantity)
     if (wlo || psi2_part) return pg_launch_pass<KS, true>(D, cobs, 1, xobs, pimg, 0, r2, L.NT, L.PT, po, st);
@@ -1272,7 +1314,7 @@ template <int KS>
 static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                               const double *s, const double *gamma, const double *alpha, const double *GP, const float *scale,
                               const float *psi2, unsigned char *ws, double *dmu, double *ds, double *dz, double *dgamma,
-                              hipStream_t st, const double *y, int ldy, const double *Gv, bool wlo) {
+                              hipStream_t st, const double *y, int ldy, const double *Gv, bool wlo, bool psi1_front_done) {
     constexpr int NFB = PgCfg<KS>::NFB, NF = PG_FB * NFB;
     const PgLayout L = pg_layout(D, N, M, Q);
     const Psi2Consts C = psi2_consts_layout(M, Q);
@@ -1297,7 +1339,7 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     DPGP_LAUNCH_CHECK();
     int rc;
     {
-        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, 0};
         // rows: the pairs (pair image, xpair of output dim d); columns: the observations of output dim d
         rc = wlo ? pg_launch_pass<KS, true>(D, pimg, 0, xpair, cobs, 1, r1, L.PT, L.NT, po, st)
                  : pg_launch_pass<KS, false>(D, pimg, 0, xpair, cobs, 1, r1, L.PT, L.NT, po, st);
@@ -1322,35 +1364,24 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     // half coefficients, features weighted by y_nd), the pair image's diagonal rows, features alpha_d g_v[d][m] (s^2 / 64, s, 1)
     float *r1p = reinterpret_cast<float *>(ws + L.off_r1p), *kap1 = reinterpret_cast<float *>(ws + L.off_kap1);
     if (y) {
-        _Float16 *cobs1 = reinterpret_cast<_Float16 *>(ws + L.off_cobs1), *xobs1 = reinterpret_cast<_Float16 *>(ws + L.off_xobs1),
-                 *dimg = reinterpret_cast<_Float16 *>(ws + L.off_dimg), *xm1 = reinterpret_cast<_Float16 *>(ws + L.off_xm1);
+        _Float16 *cobs1 = reinterpret_cast<_Float16 *>(ws + L.off_cobs1), *dimg = reinterpret_cast<_Float16 *>(ws + L.off_dimg),
+                 *xm1 = reinterpret_cast<_Float16 *>(ws + L.off_xm1);
         float *r2p = reinterpret_cast<float *>(ws + L.off_r2p), *u1 = reinterpret_cast<float *>(ws + L.off_u1);
         const int Mpad = 32 * L.MT;
-        {
-            const size_t lds = 256 + sizeof(_Float16) * 8 * 512 * pg_xp(NFB);
-            auto kern = pg_obs_images_kernel<KS>;
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return DPGP_ERR_LAUNCH;
-            DPGP_PRELAUNCH(); hipLaunchKernelGGL(kern, dim3(dpgp_ceil_div(N, 256), D), dim3(256), lds, st, N, Q, consts, mu, s, gamma, cobs1, xobs1,
-                               L.NT, flag, y, ldy);
-            DPGP_LAUNCH_CHECK();
+        // (training step: images, diagonal rows and the pass over the observations ran in part 1 and gave the forward its Psi1^T y)
+        if (!psi1_front_done) {
+            rc = launch_psi1_front<KS>(D, N, M, Q, consts, mu, s, gamma, alpha, ws, y, ldy, nullptr, st, wlo);
+            if (rc != DPGP_OK) return rc;
         }
-        DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_diag_image_kernel<KS>), dim3(dpgp_ceil_div(Mpad * KS * 2, 256)), dim3(256), 0, st, M, Mpad, pimg, dimg);
-        DPGP_LAUNCH_CHECK();
         DPGP_PRELAUNCH(); hipLaunchKernelGGL(pg_u1_kernel, dim3(D), dim3(64), 0, st, M, Mp, Mpad, alpha, Gv, u1, kap1);
         DPGP_LAUNCH_CHECK();
         DPGP_PRELAUNCH(); hipLaunchKernelGGL((pg_pair_images_kernel<KS>), dim3(dpgp_ceil_div(Mpad, 256), D), dim3(256), 0, st, Mpad, Q,
                            (const _Float16 *)dimg, (const float *)u1, (const float *)kap1, xm1);
         DPGP_LAUNCH_CHECK();
-        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+        PgPsi2Out po = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, 0};
         // rows: the inducing points (dimg, features xm1 of output dim d); columns: the observations of output dim d -> R1' [d][n][.]
         rc = wlo ? pg_launch_pass<KS, true>(D, dimg, 0, xm1, cobs1, 1, r1p, L.MT, L.NT, po, st)
                  : pg_launch_pass<KS, false>(D, dimg, 0, xm1, cobs1, 1, r1p, L.MT, L.NT, po, st);
-        if (rc != DPGP_OK) return rc;
-        // rows: the observations of output dim d (cobs1, y-weighted features xobs1); columns: the inducing points -> R2' [d][m][.]
-        po.col_major = 1;
-        rc = wlo ? pg_launch_pass<KS, true>(D, cobs1, 1, xobs1, dimg, 0, r2p, L.NT, L.MT, po, st)
-                 : pg_launch_pass<KS, false>(D, cobs1, 1, xobs1, dimg, 0, r2p, L.NT, L.MT, po, st);
         if (rc != DPGP_OK) return rc;
         DPGP_PRELAUNCH();
         PG_QP_SWITCH(Q, hipLaunchKernelGGL((pg_finish_m1_kernel<NF, QP_>), dim3(M), dim3(256), 0, st, M, Mpad, Q, D, z, consts, (const float *)u1,
@@ -1388,7 +1419,9 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
 int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
                       double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st, int which,
-                      float *psi2_part, const float *scale, const double *y, int ldy, const double *Gv, int fast) {
+                      float *psi2_part, const float *scale, const double *y, int ldy, const double *Gv, int fast, double *psi1v) {
+    // psi1v != nullptr: with which = 1 (and y) part 1 also runs the adjoint-free half of the Psi1 term and writes Psi1^T y there; with
+    // which = 2 it says that part 1 has done so (the pointer itself is not used)
     if (!psi2_pgrad_supported(M, Q)) return -4;
     (void)stage;
     int rc = DPGP_OK;
@@ -1396,9 +1429,11 @@ int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, c
 #define CASE(k)                                                                                                                  \
     case k:                                                                                                                      \
         if (which & 1) rc = launch_pgrad_part1<k>(D, N, M, Q, consts, mu, s, gamma, ws, psi2_part, scale, st, !fast);           \
+        if (rc == DPGP_OK && which == 1 && y && psi1v)                                                                           \
+            rc = launch_psi1_front<k>(D, N, M, Q, consts, mu, s, gamma, alpha, ws, y, ldy, psi1v, st, !fast);                    \
         if (rc == DPGP_OK && (which & 2))                                                                                        \
             rc = launch_pgrad_part2<k>(D, N, M, Q, consts, z, mu, s, gamma, alpha, GP, scale, (which & 1) ? nullptr : psi2_part, ws, dmu, ds, \
-                                       dz, dgamma, st, y, ldy, Gv, !fast);                                                       \
+                                       dz, dgamma, st, y, ldy, Gv, !fast, which == 2 && psi1v != nullptr);                       \
         return rc;
         CASE(2) CASE(4) CASE(6) CASE(8)
 #undef CASE
