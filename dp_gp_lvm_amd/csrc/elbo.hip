@@ -893,17 +893,25 @@ __global__ __launch_bounds__(256) void model_backward_kernel(
         aat[t] = softplus_d(aat_raw[t]);
         bat[t] = softplus_d(bat_raw[t]);
     }
-    if (t == 0) {                                       // c1_k = psi(g1)-psi(g1+g2); c2cum_k = sum_{k' < k} (psi(g2)-psi(g1+g2))
+    // c1_k = psi(g1)-psi(g1+g2); c2cum_k = sum_{k' < k} (psi(g2)-psi(g1+g2)): the digammas one stick per thread (each is a chain of ~10
+    // dependent fp64 divisions: one thread walking all 3 (T - 1) of them was 40 us of this kernel's 70), the prefix sum by thread 0
+    __shared__ double c2inc[PREP_MAX_T];
+    if (t < T) {
+        if (t < T - 1) {
+            const double g1 = softplus_d(g1_raw[t]), g2 = softplus_d(g2_raw[t]), p12 = digamma_d(g1 + g2);
+            c1[t] = digamma_d(g1) - p12;
+            c2inc[t] = digamma_d(g2) - p12;
+        } else {
+            c1[t] = 0.0;
+            c2inc[t] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
         double cum = 0.0;
         for (int k = 0; k < T; ++k) {
             c2cum[k] = cum;
-            if (k < T - 1) {
-                const double g1 = softplus_d(g1_raw[k]), g2 = softplus_d(g2_raw[k]), p12 = digamma_d(g1 + g2);
-                c1[k] = digamma_d(g1) - p12;
-                cum += digamma_d(g2) - p12;
-            } else {
-                c1[k] = 0.0;
-            }
+            cum += c2inc[k];
         }
         c2cum[T] = cum;
     }

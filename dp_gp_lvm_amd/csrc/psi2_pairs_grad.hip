@@ -202,17 +202,24 @@ __global__ __launch_bounds__(256) void pg_u_kernel(int M, int Q, int Mp, const d
 __global__ __launch_bounds__(1024) void pg_u_scale_kernel(int Ppad, int Mp, int Q, const unsigned *__restrict__ pmap,
                                                           const float *__restrict__ scale, const double *__restrict__ GP,
                                                           float *__restrict__ u, float *__restrict__ kap,
-                                                          const float *__restrict__ psi2, const double *__restrict__ z,
-                                                          double *__restrict__ dgamma) {
+                                                          const float *__restrict__ psi2, const double *z,
+                                                          double *__restrict__ dgamma, int zlds) {
     // psi2 != nullptr ([D][Mp][Mp], slab 0 of the forward's partial slabs = the column sums of pass 1 with their per-pair factors):
     // the derivative through beta_dp = -1/4 log2e sum_q gamma_dq delta_pq^2 needs only g_dp psi2_dp per pair,
     //     dgamma[d][q] += sum_p -1/4 delta_pq^2 g_dp psi2_dp        (what pg_dgamma_pairs_kernel forms from u_dp and R2's constant feature)
     // block = output dim, 1024 threads (a 256-thread block walked 33 dependent trips at M = 128), wave sums, one LDS hand-over
     __shared__ float red[16];
     __shared__ double redd[16][DPGP_MAX_Q];
+    extern __shared__ __align__(16) unsigned char u_smem[];    // z [M][Q] where it fits (zlds): the 2 Q gathered reads per pair come from
+    double *zs = reinterpret_cast<double *>(u_smem);           // LDS instead of 8-byte gathers through the texture path (39 us of them)
     const int d = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const double *Gd = GP + (size_t)d * Mp * Mp;
     const float *Pd = psi2 ? psi2 + (size_t)d * Mp * Mp : nullptr;
+    if (zlds && Pd) {
+        for (int i = t; i < zlds; i += 1024) zs[i] = z[i];
+        __syncthreads();
+        z = zs;
+    }
     float mx = 0.0f;
     double a[DPGP_MAX_Q];
 #pragma unroll
@@ -1329,8 +1336,11 @@ static int launch_pgrad_part2(int D, int N, int M, int Q, const unsigned char *c
     const _Float16 *pimg = reinterpret_cast<const _Float16 *>(consts + C.off_pairs);
     DPGP_PRELAUNCH();
     if (scale)
-        hipLaunchKernelGGL(pg_u_scale_kernel, dim3(D), dim3(1024), 0, st, L.Ppad, Mp, Q, reinterpret_cast<const unsigned *>(consts + C.off_pmap),
-                           scale, GP, u, kap, psi2, z, dgamma);
+    {
+        const int zl = (size_t)M * Q * sizeof(double) <= 32 * 1024 ? M * Q : 0;
+        hipLaunchKernelGGL(pg_u_scale_kernel, dim3(D), dim3(1024), sizeof(double) * (size_t)zl, st, L.Ppad, Mp, Q,
+                           reinterpret_cast<const unsigned *>(consts + C.off_pmap), scale, GP, u, kap, psi2, z, dgamma, zl);
+    }
     else
         hipLaunchKernelGGL(pg_u_kernel, dim3(D), dim3(256), 0, st, M, Q, Mp, z, gamma, alpha, GP, u, kap);
     DPGP_LAUNCH_CHECK();
