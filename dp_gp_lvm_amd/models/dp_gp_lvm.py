@@ -158,6 +158,11 @@ def dp_gp_lvm(y_train,
 
     # one training step through dpgp_elbo_step (mixed precision, M <= 128, Q <= 20: DESIGN.md section 7.1): the forward's psi2 dispatch is
     # replaced by the first pass of stage B (DPGP_FUSED_STEP=0: the three separate calls, e.g. for bench.py's per-stage breakdown)
+    # fp64 forward + 'mixed' stage B: pair-tile or patch form by the conditioning of K_uu (see _gradients; DPGP_ADAPTIVE_STAGE_B=0: always
+    # the patch form)
+    DPGP_GUARD_REL = 2.0e-3                                  # (include/dpgp.h)
+    adaptive_stage_b = (precision == 'f64' and backward_precision == 'mixed' and num_latent_dims <= 20 and
+                        os.environ.get('DPGP_ADAPTIVE_STAGE_B', '1') != '0')
     step_ok = (grad_precision == 'mixed' and stage_b_precision in ('mixed', 'mixed_fast') and psi_algo == 'auto' and
                num_latent_dims <= 20 and os.environ.get('DPGP_FUSED_STEP', '1') != '0')
     fused_step = step_ok and ops.elbo_step_supported(num_inducing_points, num_latent_dims)
@@ -267,8 +272,19 @@ def dp_gp_lvm(y_train,
             gp, wk, gv, dab, _ = ops.elbo_grad_chain(buf['alpha'], buf['beta'], gws, jitter=GP_DEFAULT_JITTER, z=x_u,
                                                      gamma=buf['gamma'])
             mark(1)
+            form = stage_b_precision
+            if adaptive_stage_b:
+                # the training configuration (fp64 forward, matrix-pipe stage B): the pair-tile form of the Psi2 term (4.6 ms at config 3)
+                # while K_uu is well conditioned, the patch form (7.5 ms) once it is not — the pair form accumulates the a'- and b-weighted
+                # exponentials separately and loses accuracy where they cancel (include/dpgp.h, DPGP_PREC_MIXED_PATCH: 7e-3 against 2e-3 of
+                # the largest gradient entry at the ill-conditioned fixture, whose guard bound is 80 x the threshold).  The measure is the
+                # conditioning-guard bound the forward evaluation computes in every precision (one host read per step: 10 ms of fp64
+                # forward pass are in front of it); the switch sits at a tenth of the threshold a mixed forward pass is flagged at.
+                bound = float(gws.guard.max())
+                form = 'mixed' if bound <= 0.1 * DPGP_GUARD_REL * num_samples else 'mixed_patch'
+                grad_state['stage_b_form'] = form
             dmu, ds, dz, dg = ops.elbo_grad_psi(y_local, x_u, x_mean, buf['s'], buf['gamma'], buf['alpha'], gp, wk, gv,
-                                                prec=stage_b_precision)
+                                                prec=form)
             mark(2)
         rows = r['logits'].shape[0]
         sizes = [num_samples * num_latent_dims, num_samples * num_latent_dims, num_inducing_points * num_latent_dims,
@@ -432,6 +448,12 @@ def dp_gp_lvm(y_train,
             """[D_local] bound on what the rounding of an fp32 Psi2 can move each output dim's f_hat terms by (last
             evaluation; computed in every precision mode; flagged in info when > DPGP_GUARD_REL * N in mixed / f32)."""
             return workspace.guard
+
+        @property
+        def last_stage_b_form(self):
+            """'mixed' (pair-tile form) or 'mixed_patch' (patch form): what the last gradients() of the training configuration
+            (precision='f64', backward_precision='mixed') chose for the Psi2 term by the conditioning-guard bound; None otherwise."""
+            return grad_state.get('stage_b_form')
 
         evaluate_ = staticmethod(evaluate)
         evaluate_graph = staticmethod(_evaluate_graph)

@@ -356,6 +356,36 @@ def test_fp64_forward_with_matrix_pipe_stage_b(dev, fixture):
         want = g['grad_' + ref_name]
         have = got[raw_name].cpu().numpy().reshape(want.shape)
         np.testing.assert_allclose(have, want, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(want).max()), err_msg=ref_name)
+    # the form of the Psi2 term follows the conditioning-guard bound of the forward evaluation (tests/test_gpu_illcond.py: the patch form
+    # at 80 x the threshold); whichever it is, the gradients above hold the mixed tolerance
+    bound = float(model.conditioning_guard.max())
+    assert model.last_stage_b_form == ('mixed' if bound <= 0.1 * 2.0e-3 * g['y'].shape[0] else 'mixed_patch')
+
+
+def test_training_configuration_switches_between_the_two_forms_of_stage_b(dev, monkeypatch):
+    """Well-conditioned K_uu (spread-out inducing inputs, short length scales): the pair-tile form; and the same model with
+    DPGP_ADAPTIVE_STAGE_B=0: the patch form — both within the mixed tolerance of the all-fp64 gradients."""
+    from dp_gp_lvm_amd.models.dp_gp_lvm import dp_gp_lvm
+    rng = np.random.default_rng(11)
+    n, d, m, q, t = 300, 12, 40, 4, 3
+    y = rng.standard_normal((n, d))
+    y = (y - y.mean(0)) / y.std(0)
+    iv = dict(x_mean=rng.standard_normal((n, q)), x_var=0.3 + 0.2 * rng.random((n, q)), x_u=3.0 * rng.standard_normal((m, q)),
+              phi_logits=rng.standard_normal((d, t)), gamma_atoms=1.0 + rng.random((t, q)), alpha_atoms=1.0 + rng.random((t, 1)),
+              beta_atoms=1.0 + rng.random((t, 1)), gamma_1=1.0 + rng.random(t - 1), gamma_2=1.0 + rng.random(t - 1), w_1=1.3, w_2=0.8)
+    kw = dict(num_latent_dims=q, num_inducing_points=m, truncation_level=t, device=dev, initial_values=iv)
+    ref = dp_gp_lvm(y, precision='f64', backward_precision='f64', **kw).gradients()
+    a = dp_gp_lvm(y, precision='f64', backward_precision='mixed', **kw)
+    ga = a.gradients()
+    assert a.last_stage_b_form == 'mixed', float(a.conditioning_guard.max())
+    monkeypatch.setenv('DPGP_ADAPTIVE_STAGE_B', '0')
+    b = dp_gp_lvm(y, precision='f64', backward_precision='mixed', **kw)
+    gb = b.gradients()
+    assert b.last_stage_b_form is None
+    for k, want in ref.items():
+        w = want.cpu().numpy()
+        for got in (ga[k], gb[k]):
+            np.testing.assert_allclose(got.cpu().numpy(), w, rtol=0, atol=5e-4 * max(np.abs(w).max(), 1e-300), err_msg=k)
 
 
 @pytest.mark.parametrize('shape', [(40, 6, 12, 3), (33, 5, 17, 5), (200, 6, 70, 4), (300, 16, 100, 10), (260, 3, 200, 7)])

@@ -39,6 +39,8 @@ def test_fp64_matches_the_reference_where_kuu_is_nearly_singular(dev, backward):
     # the bound is computed in every mode; with an fp64 Psi2 it is the oracle's number
     np.testing.assert_allclose(model.conditioning_guard.cpu().numpy(), g['guard'], rtol=1e-6)
     _check_gradients(model, g, 1e-5 if backward is None else 2e-3)
+    # the training configuration picks the form of the Psi2 term by this bound: here (80 x the threshold) the patch form
+    assert model.last_stage_b_form == (None if backward is None else 'mixed_patch')
 
 
 def test_mixed_precision_raises_its_flag_instead_of_diverging(dev):
