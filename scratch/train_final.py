@@ -9,8 +9,11 @@ init = dict(x_mean=p['mu'], x_var=p['s'], x_u=p['z'], phi_logits=np.log(p['phi']
 kw = dict(num_latent_dims=q, num_inducing_points=m, truncation_level=t, alpha_prior_params=np.array([p['s1'], p['s2']]), device='cuda:0', initial_values=init)
 model = dp_gp_lvm(p['y'], precision='f64', backward_precision='mixed', **kw)
 o0 = float(model.objective); torch.cuda.synchronize(); t0 = time.time()
-model.optimise(400, 0.01)
+forms = []
+model.optimise(400, 0.01, callback=lambda it: forms.append(model.last_stage_b_form))
 torch.cuda.synchronize(); dt = time.time() - t0
+sw = next((i for i, f in enumerate(forms) if f == 'mixed_patch'), None)
+print('stage B form: pair-tile for the first %s iterations, patch form afterwards (%d of 400)' % (sw if sw is not None else 400, sum(f == 'mixed_patch' for f in forms)))
 print('training configuration: 400 iterations, %.2f ms per iteration, objective %.1f -> %.1f' % (1e3 * dt / 400, o0, float(model.objective)), flush=True)
 model = dp_gp_lvm(p['y'], precision='mixed', **kw)
 done = [0]
