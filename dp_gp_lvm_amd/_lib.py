@@ -61,6 +61,8 @@ SIGNATURES = {
     'dpgp_model_backward_t': (_i, [_i] * 8 + [_vp] * 10 + [_d, _d, _i] + [_vp] * 16 + [_vp]),
     'dpgp_model_pack': (_i, [_i, _vp, _vp, _vp, _vp]),
     'dpgp_model_finalize': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'dpgp_elbo_grad_chain_big_workspace_bytes': (_sz, [_i, _i]),
+    'dpgp_elbo_grad_chain_big': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _i, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dpgp_trouble_flag': (_i, [_sz, _vp, _i, _vp, _vp, _vp]),
     'dpgp_trtri_lower_batched_f64': (_i, [_i, _i, _vp, _vp, _vp, _sz, _vp]),
     'dpgp_gemm_strided_f64': (_i, [_i, _i, _i, _i, _d, _vp, _ll, _ll, _ll, _vp, _ll, _ll, _ll, _d, _vp, _ll, _ll, _ll, _vp]),

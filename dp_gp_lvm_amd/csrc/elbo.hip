@@ -195,6 +195,46 @@ extern "C" int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *al
                                      beta, yy, jitter, la, g_psi2, w_kuu, g_v, d_alpha_beta, info, (hipStream_t)stream);
 }
 
+// Stage A for M > 128 (M a multiple of 128; other M: the host composes it from the batched operators) from the workspace of a finished
+// forward evaluation, as dpgp_elbo_grad_chain for M <= 128.  psi2_slabs: 0 = the forward's own slab count, 1 after dpgp_elbo_fhat_step.
+extern "C" size_t dpgp_elbo_grad_chain_big_workspace_bytes(int D, int M) {
+    return (D > 0 && M > 0) ? chain_grad_big_ws_bytes(D, M) : 0;
+}
+extern "C" int dpgp_elbo_grad_chain_big(int D, int N, int M, int Q, const double *z, const double *gamma, const double *alpha,
+                                        const double *beta, double jitter, int prec, void *fwd_ws, size_t fwd_ws_bytes, int psi2_slabs,
+                                        void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v, double *d_alpha_beta,
+                                        int *info, void *stream) {
+    if (D <= 0) return -1;
+    if (N <= 0) return -2;
+    if (M <= 0 || !chain_grad_big_supported(M)) return -3;
+    if (Q <= 0 || Q > DPGP_MAX_Q) return -4;
+    if (!z) return -5;
+    if (!gamma) return -6;
+    if (!alpha) return -7;
+    if (!beta) return -8;
+    if (!(jitter >= 0.0)) return -9;
+    if (prec != DPGP_PREC_MIXED && prec != DPGP_PREC_F64) return -10;
+    if (!fwd_ws) return -11;
+    const ElboLayout L = elbo_layout(D, N, M, Q, prec);
+    if (fwd_ws_bytes < L.total) return -12;
+    if (psi2_slabs < 0 || psi2_slabs > L.ns2) return -13;
+    if (!ws) return -14;
+    if (ws_bytes < chain_grad_big_ws_bytes(D, M)) return -15;
+    if (!g_psi2) return -16;
+    if (!w_kuu) return -17;
+    if (!g_v) return -18;
+    if (!d_alpha_beta) return -19;
+    if (!info) return -20;
+    const unsigned char *w = (const unsigned char *)fwd_ws;
+    const double *yy = reinterpret_cast<const double *>(w + L.off_yy), *vpart = reinterpret_cast<const double *>(w + L.off_v);
+    const int ns2 = psi2_slabs ? psi2_slabs : L.ns2;
+    if (prec == DPGP_PREC_MIXED)
+        return launch_chain_grad_big<float>(D, N, M, Q, z, gamma, alpha, beta, jitter, reinterpret_cast<const float *>(w + L.off_p2), ns2,
+                                            vpart, L.ns1, yy, (unsigned char *)ws, g_psi2, w_kuu, g_v, d_alpha_beta, info, (hipStream_t)stream);
+    return launch_chain_grad_big<double>(D, N, M, Q, z, gamma, alpha, beta, jitter, reinterpret_cast<const double *>(w + L.off_p2), ns2,
+                                         vpart, L.ns1, yy, (unsigned char *)ws, g_psi2, w_kuu, g_v, d_alpha_beta, info, (hipStream_t)stream);
+}
+
 // Stage B in mixed precision.  Workspace: [plain kernel's partials | psi2 constants | patch-form partials | Psi1 term | reduction
 // stage | pair-tile form].  fwd_consts / fwd_scale != nullptr (training step): the forward evaluation's constants and per-pair
 // factors are used as they are, and part 1 of the pair-tile form (images of the observations, pass 1) has already run on this

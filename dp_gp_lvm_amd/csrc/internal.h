@@ -146,6 +146,13 @@ bool psi2_pgrad_supported(int M, int Q);
 size_t psi2_pgrad_ws_bytes(int D, int N, int M, int Q);
 // which: 1 = the part that does not depend on the adjoints (observation images, pass 1; psi2_part / scale != nullptr: Psi2 as a
 // by-product into slab 0 of the forward's partial slabs), 2 = the rest (after part 1 on the same ws), 3 = both
+// stage A for M > 128 (M a multiple of 128) on [D][M][M] matrices in memory (chain_grad_big.hip); ws: chain_grad_big_ws_bytes
+bool chain_grad_big_supported(int M);
+size_t chain_grad_big_ws_bytes(int D, int M);
+template <typename TP>
+int launch_chain_grad_big(int D, int N, int M, int Q, const double *z, const double *gamma, const double *alpha, const double *beta,
+                          double jitter, const TP *psi2_part, int ns2, const double *v_part, int ns1, const double *yy_part,
+                          unsigned char *ws, double *GP, double *WK, double *Gv, double *dab, int *info, hipStream_t st);
 int launch_psi2_pgrad(int D, int N, int M, int Q, const unsigned char *consts, const double *z, const double *mu,
                       const double *s, const double *gamma, const double *alpha, const double *GP, unsigned char *ws,
                       double *stage, double *dmu, double *ds, double *dz, double *dgamma, hipStream_t st, int which = 3,

@@ -520,6 +520,30 @@ def elbo_grad_chain(alpha, beta, workspace, jitter=1e-8, z=None, gamma=None, psi
 
 
 def _elbo_grad_chain_large(alpha, beta, workspace, jitter, z, gamma, psi2_slabs=None):
+    """Stage A for M > 128.  M a multiple of 128: ONE library call, dpgp_elbo_grad_chain_big (csrc/chain_grad_big.hip: persistent Cholesky
+    and solve, five strided MFMA products, three streaming kernels); other M (or DPGP_STAGE_A_COMPOSED=1, the cross-check): composed here
+    from the batched operators (``_elbo_grad_chain_large_composed``)."""
+    import os
+    d, n, m, q = workspace.shape
+    if m % 128 != 0 or workspace.prec not in ('mixed', 'f64') or os.environ.get('DPGP_STAGE_A_COMPOSED', '0') == '1':
+        return _elbo_grad_chain_large_composed(alpha, beta, workspace, jitter, z, gamma, psi2_slabs)
+    f64 = torch.float64
+    dev = workspace.ws.device
+    l = _lib.lib()
+    z, gamma = _prep(z, f64, 'z'), _prep(gamma, f64, 'gamma')
+    wsb = int(l.dpgp_elbo_grad_chain_big_workspace_bytes(d, m))
+    ws = _ws(wsb, dev)
+    gp, wk = torch.empty((d, m, m), dtype=f64, device=dev), torch.empty((d, m, m), dtype=f64, device=dev)
+    gv, dab = torch.empty((d, m), dtype=f64, device=dev), torch.empty((d, 2), dtype=f64, device=dev)
+    info = torch.empty(d, dtype=torch.int32, device=dev)
+    _lib.check(l.dpgp_elbo_grad_chain_big(d, n, m, q, z.data_ptr(), gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(), float(jitter),
+                                          _lib.PREC[workspace.prec], workspace.ws.data_ptr(), workspace.nbytes,
+                                          0 if psi2_slabs is None else int(psi2_slabs), ws.data_ptr(), wsb, gp.data_ptr(), wk.data_ptr(),
+                                          gv.data_ptr(), dab.data_ptr(), info.data_ptr(), _stream()), 'dpgp_elbo_grad_chain_big')
+    return gp, wk, gv, dab, info
+
+
+def _elbo_grad_chain_large_composed(alpha, beta, workspace, jitter, z, gamma, psi2_slabs=None):
     """Stage A for M > 128 (first version): the same adjoints as chain_grad_kernel (grad.hip), with B^-1 and K^-1 formed
     explicitly from the library's Cholesky factors — L^-1 by dpgp_trsm_batched on the identity, the M x M products as plain
     fp64 GEMMs (the library's strided MFMA kernel, ``matmul`` above), element-wise work in torch.  Reads Psi2, Psi1^T y and y^T y from the

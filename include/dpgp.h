@@ -205,6 +205,17 @@ int dpgp_elbo_fhat_ex(int D, int N, int M, int Q, const double *y, int ldy, cons
 int dpgp_elbo_grad_chain(int D, int N, int M, int Q, const double *alpha, const double *beta, double jitter, int prec,
                          void *ws, size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v, double *d_alpha_beta,
                          int *info, void *stream);
+/* Stage A for M > 128, M a multiple of 128 (-3 otherwise: the host side composes it from dpgp_potrf_batched / dpgp_trsm_batched /
+ * dpgp_gemm_strided_f64 then): the same adjoints from the forward evaluation's workspace, on [D][M][M] fp64 matrices in memory — the
+ * persistent-workgroup Cholesky and solve (L^-1 with every block row stored), five strided MFMA products and three streaming kernels
+ * (csrc/chain_grad_big.hip).  K_uu is rebuilt from z, gamma, alpha (rbf_kernel.py:58-93).  psi2_slabs: 0 = the forward's own count of
+ * Psi2 slabs, 1 after dpgp_elbo_fhat_step.  ws: dpgp_elbo_grad_chain_big_workspace_bytes(D, M) (six [D][M][M] matrices).  Outputs as
+ * dpgp_elbo_grad_chain with Mp = M, both triangles written. */
+size_t dpgp_elbo_grad_chain_big_workspace_bytes(int D, int M);
+int dpgp_elbo_grad_chain_big(int D, int N, int M, int Q, const double *z, const double *gamma, const double *alpha,
+                             const double *beta, double jitter, int prec, void *fwd_ws, size_t fwd_ws_bytes, int psi2_slabs, void *ws,
+                             size_t ws_bytes, double *g_psi2, double *w_kuu, double *g_v, double *d_alpha_beta, int *info,
+                             void *stream);
 
 /* Backward pass, stage B: second streaming pass over the observations — the derivatives of
  * <g_psi2, Psi2> + <g_v, Psi1^T y> + <d f_hat / d K_uu, K_uu> (reference forward: src/kernels/rbf_kernel.py:58-199) with

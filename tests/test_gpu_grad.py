@@ -184,7 +184,7 @@ def test_sharding_arithmetic_on_one_gpu(dev, world):
 
 
 @pytest.mark.parametrize('shape', [(33, 5, 17, 5, 1, 1), (70, 9, 33, 9, 3, 3), (80, 8, 64, 6, 4, 2), (45, 14, 20, 13, 3, 1),
-                                   (160, 6, 140, 5, 3, 1), (300, 9, 200, 8, 2, 3)])
+                                   (160, 6, 140, 5, 3, 1), (300, 9, 200, 8, 2, 3), (300, 6, 256, 5, 2, 1)])
 @pytest.mark.parametrize('prec', ['f64', 'mixed'])
 def test_model_gradients_odd_shapes(dev, shape, prec):
     """Shapes off the tile sizes (M not a multiple of 16, Q not a multiple of 4, T = 1, mask_size > 1) against the pinned
@@ -223,6 +223,27 @@ def test_model_gradients_odd_shapes(dev, shape, prec):
         have = got[raw_name].cpu().numpy().reshape(-1)[:want.size].reshape(want.shape)
         np.testing.assert_allclose(have, want, rtol=tol, atol=tol * max(1.0, np.abs(want).max()), err_msg=ref_name)
     np.testing.assert_allclose(got['dp_w'].cpu().numpy(), [float(ref['w_1_raw']), float(ref['w_2_raw'])], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('prec', ['f64', 'mixed'])
+def test_stage_a_beyond_128_inducing_points_one_call_equals_the_composed_one(dev, prec, monkeypatch):
+    """M a multiple of 128: dpgp_elbo_grad_chain_big (one library call on [D][M][M] matrices) against the same adjoints composed on the
+    host from the batched operators (DPGP_STAGE_A_COMPOSED=1); both from the workspace of one forward evaluation."""
+    rng = np.random.default_rng(5)
+    n, d, m, q = 300, 5, 256, 4
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    y = rng.standard_normal((n, d))
+    z, mu, s = 4.0 * rng.standard_normal((m, q)), rng.standard_normal((n, q)), 0.3 + 0.3 * rng.random((n, q))
+    gamma, alpha, beta = 0.5 + rng.random((d, q)), 0.5 + rng.random(d), 0.5 + rng.random(d)
+    w = ops.ElboWorkspace(d, n, m, q, prec, dev)
+    args = [t(a) for a in (y, z, mu, s, gamma, alpha, beta)]
+    ops.elbo_fhat(*args, prec=prec, workspace=w)
+    one = ops.elbo_grad_chain(args[5], args[6], w, z=args[1], gamma=args[4])
+    monkeypatch.setenv('DPGP_STAGE_A_COMPOSED', '1')
+    ref = ops.elbo_grad_chain(args[5], args[6], w, z=args[1], gamma=args[4])
+    assert int(one[4].abs().max()) == 0 and int(ref[4].abs().max()) == 0
+    for name, a, b in zip(('g_psi2', 'w_kuu', 'g_v', 'd_alpha_beta'), one, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-9 * float(b.abs().max()), err_msg=name)
 
 
 def _stage_b_problem(dev, shape):
