@@ -1227,26 +1227,40 @@ static int pg_launch_pass_g(int D, const _Float16 *rimg, int row_per_d, const _F
     DPGP_LAUNCH_CHECK();
     return DPGP_OK;
 }
+static int pg_cu_count() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
+        else ncu = 256;
+    }
+    return ncu;
+}
 template <int KS, bool WLO>
 static int pg_launch_pass(int D, const _Float16 *rimg, int row_per_d, const _Float16 *ximg, const _Float16 *cimg, int col_per_d, float *out,
                           int n_row_tiles, int n_col_tiles, const PgPsi2Out &po, hipStream_t st) {
     constexpr int G0 = PgCfg<KS>::G, NW = PgCfg<KS>::NW;
+    // cost of a pass with G resident column tiles per wave: rounds of workgroups (one per compute unit) x G tile steps per row tile x the
+    // measured cost of a step (KS <= 4, config 3: G = 3 and 4 — the latter with one register set for the exponent operand — take 0.945 /
+    // 0.94 of a G = 2 step: a third / half the LDS-DMA pieces per step; KS = 8: G = 2 takes 0.92 of a G = 1 step).  The rounds count the
+    // surplus tile slots of the last group of a row AND an under-filled chip: at D = 64 the 63 observation tiles in two groups of 32 are
+    // 128 workgroups on 256 compute units (config 2: 380 us where four groups of 16 take 270)
+    const int ncu = pg_cu_count();
+    auto cost = [&](int G, int permille) {
+        const long long nwg = (long long)D * dpgp_ceil_div(n_col_tiles, NW * G);
+        return ((nwg + ncu - 1) / ncu) * G * permille;
+    };
     if constexpr (KS <= 4 && G0 == 2) {
-        // tile slots of the last group included, times the measured cost of a step (config 3: G = 3 and 4 — the latter with one register
-        // set for the exponent operand — take 0.945 / 0.94 of a G = 2 step: a third / half the LDS-DMA pieces per step)
-        const int s2 = dpgp_ceil_div(n_col_tiles, NW * 2) * 2 * 1000, s3 = dpgp_ceil_div(n_col_tiles, NW * 3) * 3 * 945,
-                  s4 = dpgp_ceil_div(n_col_tiles, NW * 4) * 4 * 940;
+        const long long c2 = cost(2, 1000), c3 = cost(3, 945), c4 = cost(4, 940);
         const char *e = getenv("DPGP_PG_G");                       // (experiments: 2, 3 or 4)
-        const int pick = e ? atoi(e) : (s4 < s3 && s4 < s2 ? 4 : (s3 < s2 ? 3 : 2));
+        const int pick = e ? atoi(e) : (c4 < c3 && c4 < c2 ? 4 : (c3 < c2 ? 3 : 2));
         if (pick == 4) return pg_launch_pass_g<KS, WLO, 4>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
         if (pick == 3) return pg_launch_pass_g<KS, WLO, 3>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
     }
     if constexpr (KS >= 8 && G0 == 1) {
         // two resident column tiles per wave (one register set for the exponent operand: 248 registers) halve the ring fills and the LDS
-        // reads per step — about 8 % per step — unless the coarser groups leave that many more surplus tile slots (config 5's 65 pair tiles:
-        // 80 slots instead of 72)
-        const int s1 = dpgp_ceil_div(n_col_tiles, NW), s2 = dpgp_ceil_div(n_col_tiles, NW * 2) * 2;
-        if (s2 * 92 <= s1 * 100 && !getenv("DPGP_PG_G1"))          // (DPGP_PG_G1: experiments)
+        // reads per step
+        if (cost(2, 920) <= cost(1, 1000) && !getenv("DPGP_PG_G1"))   // (DPGP_PG_G1: experiments)
             return pg_launch_pass_g<KS, WLO, 2>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
     }
     return pg_launch_pass_g<KS, WLO, G0>(D, rimg, row_per_d, ximg, cimg, col_per_d, out, n_row_tiles, n_col_tiles, po, st);
