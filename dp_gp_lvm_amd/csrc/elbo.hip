@@ -71,12 +71,19 @@ struct AuxJoin {
     }
 };
 
+// A launch that needs what the last kernel of elbo_run (chain_b) needs and nothing of chain_b itself — stage A of a training step: it
+// goes to the second stream beside chain_b where both fit on the chip at once (2 D workgroups on 2 x 256 slots).
+struct SideLaunch {
+    int (*fn)(void *ctx, hipStream_t st);
+    void *ctx;
+};
+
 template <typename TP, typename TL>
 static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const double *z, const double *mu,
                     const double *s, const double *gamma, const double *alpha, const double *beta, double jitter,
                     int algo, double *terms, double *sums, int *info, unsigned char *ws, const ElboLayout &L,
                     hipStream_t st, const dpgp_exec_t *ex, TL *lb_out = nullptr, unsigned char *pgws = nullptr,
-                    bool psi1_from_pass = false) {
+                    bool psi1_from_pass = false, const SideLaunch *side = nullptr, bool *side_done = nullptr) {
     double *yy = reinterpret_cast<double *>(ws + L.off_yy);
     double *ldk = reinterpret_cast<double *>(ws + L.off_ld);
     int *ik = reinterpret_cast<int *>(ws + L.off_ik);
@@ -97,6 +104,10 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     // Psi1^T y needs only the front launch and feeds only the chain: with a second stream in `exec` it runs beside the psi2
     // launch instead of in front of it (12 us of the per-GPU share at D = 64)
     hipStream_t aux = (ex && ex->stream_aux && ex->ev_fork && ex->ev_join) ? (hipStream_t)ex->stream_aux : nullptr;
+    // A fork / join pair costs tens of microseconds of cross-stream hand-over: in a training step the second stream is used only with few
+    // output dims (D <= 256: the K_uu branch and stage A are then launches that leave most of the chip idle — config 2: 1.142 -> 1.12 ms);
+    // at configs 3 / 5 it cost more than it hid (5.53 -> 5.58 / 3.71 -> 3.82 ms)
+    if (pgws != nullptr && psi1_from_pass && D > 256) aux = nullptr;
     AuxJoin aj;
     if (aux) {
         if (hipEventRecord((hipEvent_t)ex->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)ex->ev_fork, 0) != hipSuccess)
@@ -150,6 +161,21 @@ static int elbo_run(int D, int N, int M, int Q, const double *y, int ldy, const 
     // ... and, in the workgroup that finishes last, f_hat and KL; with the model-level pointers of exec also the packed pair /
     // the finished objective (round 2: a launch of its own, sum_terms_kernel)
     if (big && lb_out) return -30;
+    if (side && aux && !big && 2 * D <= 512) {
+        // fork again: the side launch on the second stream, chain_b on this one; this stream waits for the side launch behind chain_b
+        if (hipEventRecord((hipEvent_t)ex->ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, (hipEvent_t)ex->ev_fork, 0) != hipSuccess)
+            return DPGP_ERR_LAUNCH;
+        aj.arm(st, aux, (hipEvent_t)ex->ev_join);
+        if ((rc = side->fn(side->ctx, aux))) return rc;
+        if (hipEventRecord((hipEvent_t)ex->ev_join, aux) != hipSuccess) return DPGP_ERR_LAUNCH;
+        rc = launch_chain_b<TP, TL>(D, N, M, p2, step ? 1 : L.ns2, vpart, ns1, alpha, beta, yy, ldk, ik, terms, info,
+                                    reinterpret_cast<double *>(ws + L.off_guard), la, algo, st, klp, sums,
+                                    ex ? (const double *)ex->model_scal : nullptr, ex ? (double *)ex->model_pack : nullptr,
+                                    ex ? (double *)ex->model_out : nullptr, lb_out);
+        if (rc) return rc;
+        if (side_done) *side_done = true;
+        return aj.join();
+    }
     if constexpr (sizeof(TL) == 8) {
         if (big)
             return launch_chain_big_b<TP>(D, N, M, p2, step ? 1 : L.ns2, vpart, ns1, alpha, beta, yy, ik, terms, info,
@@ -457,15 +483,30 @@ extern "C" int dpgp_elbo_step(int D, int N, int M, int Q, const double *y, int l
     const GradPsiWs W = grad_psi_ws(D, N, M, Q, (unsigned char *)gws, false);
     // (DPGP_PSI1_PLAIN, an experiment switch of grad_psi_mixed, keeps the Psi1 term off the passes: then the forward's own Psi1^T y launch)
     const bool v_from_pass = !getenv("DPGP_PSI1_PLAIN") && !getenv("DPGP_GRAD_PATCH") && !getenv("DPGP_GRAD_PLAIN");
+    // stage A on the ONE slab pass 1 left (and the one slab of Psi1^T y): it needs what chain_b needs and nothing of chain_b, so with a
+    // second stream and few output dims (per-GPU shares of a sharded run: both launches fit on the chip at once) it runs beside chain_b
+    struct StageA {
+        int D, N, M, ns1;
+        const unsigned char *w;
+        const ElboLayout *L;
+        const double *alpha, *beta;
+        double jitter, *g_psi2, *w_kuu, *g_v, *dab;
+        int *info;
+    } sa = {D, N, M, v_from_pass ? 1 : L.ns1, w, &L, alpha, beta, jitter, g_psi2, w_kuu, g_v, d_alpha_beta, info_grad};
+    auto stage_a = [](void *c, hipStream_t s_) -> int {
+        const StageA &a = *static_cast<const StageA *>(c);
+        return launch_chain_grad<float>(a.D, a.N, a.M, reinterpret_cast<const float *>(a.w + a.L->off_p2), 1,
+                                        reinterpret_cast<const double *>(a.w + a.L->off_v), a.ns1, a.alpha, a.beta,
+                                        reinterpret_cast<const double *>(a.w + a.L->off_yy), a.jitter,
+                                        reinterpret_cast<double *>(const_cast<unsigned char *>(a.w) + a.L->off_la), a.g_psi2, a.w_kuu, a.g_v,
+                                        a.dab, a.info, s_);
+    };
+    const SideLaunch side = {stage_a, &sa};
+    bool side_done = false;
     int rc = elbo_run<float, double>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, beta, jitter, DPGP_ALGO_AUTO, terms, sums, info, w,
-                                     L, st, exec, nullptr, W.pgws, v_from_pass);
+                                     L, st, exec, nullptr, W.pgws, v_from_pass, &side, &side_done);
     if (rc != DPGP_OK) return rc;
-    // stage A on the ONE slab pass 1 left (and the one slab of Psi1^T y)
-    rc = launch_chain_grad<float>(D, N, M, reinterpret_cast<const float *>(w + L.off_p2), 1,
-                                  reinterpret_cast<const double *>(w + L.off_v), v_from_pass ? 1 : L.ns1, alpha, beta,
-                                  reinterpret_cast<const double *>(w + L.off_yy), jitter, reinterpret_cast<double *>(w + L.off_la),
-                                  g_psi2, w_kuu, g_v, d_alpha_beta, info_grad, st);
-    if (rc != DPGP_OK) return rc;
+    if (!side_done && (rc = stage_a(&sa, st)) != DPGP_OK) return rc;
     return grad_psi_mixed(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v, nullptr, false, (unsigned char *)gws, d_mu,
                           d_s, d_z, d_gamma, st, w + L.off_pc, reinterpret_cast<const float *>(w + L.off_sc),
                           reinterpret_cast<const float *>(w + L.off_p2), prec == DPGP_PREC_MIXED_FAST ? 1 : 0,

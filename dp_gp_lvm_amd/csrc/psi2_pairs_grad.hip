@@ -883,7 +883,7 @@ template <int NF>
 __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int D, int Ppad, int dchunk,
                                                               const double *__restrict__ gamma, const float *__restrict__ u,
                                                               const float *__restrict__ r2, double *__restrict__ tp) {
-    constexpr int QB = 4;
+    constexpr int QB = 4, KD = 2;                             // (KD output dims per trip: their 10 KD loads in flight together; 4: slower, 122 registers)
     __shared__ double gsh[32][QB];
     const int t = threadIdx.x, p = blockIdx.x * 256 + t, c = blockIdx.y, q0 = QB * blockIdx.z;
     const int P = (int)((long long)M * (M + 1) / 2);
@@ -901,10 +901,10 @@ __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int 
             gsh[dd][q] = q0 + q < Q ? gamma[(size_t)(d0 + dd) * Q + q0 + q] : 0.0;
         }
         __syncthreads();
-        for (int dd = 0; dd < nd; dd += 2) {
-            float ud[2], cc[2], ra[2][QB], rb[2][QB];
+        for (int dd = 0; dd < nd; dd += KD) {
+            float ud[KD], cc[KD], ra[KD][QB], rb[KD][QB];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < KD; ++k) {
                 const bool on = dd + k < nd;
                 const int d = d0 + (on ? dd + k : dd);
                 ud[k] = on ? u[(size_t)d * Ppad + pp] * (1.0f / 4096.0f) : 0.0f;          // (x 2^-PG_WSHIFT)
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void pg_finish_pairs_kernel(int M, int Q, int 
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < KD; ++k) {
                 const double udd = (double)ud[k], uc = udd * (double)cc[k];
                 const int dl = dd + k < nd ? dd + k : dd;
 #pragma unroll
@@ -1080,36 +1080,39 @@ __global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D,
             iksh[t - 64][1] = r1p ? 0.5 / ((double)kap1[d0 + t - 64] * 4096.0) : 0.0;
         }
         __syncthreads();
-        for (int dd = 0; dd < nd; ++dd) {
-            const int d = d0 + dd;
-            double dg[QB];
-#pragma unroll
-            for (int q = 0; q < QB; ++q) dg[q] = 0.0;
-            // (both sources' loads first)
-            float ra[2][QB], rb[2][QB], rcf[2] = {0.0f, 0.0f};
-            double yv = 0.0;
+        // rows of output dim dd + 1 are fetched while those of dd are worked on (two register sets, the loop unrolled by two)
+        struct Rows { float ra[2][QB], rb[2][QB], rcf[2]; double yv; };
+        auto fetch = [&](Rows &R, int dd) __attribute__((always_inline)) {
+            const int d = d0 + (dd < nd ? dd : nd - 1);
+            R.yv = 0.0; R.rcf[0] = 0.0f; R.rcf[1] = 0.0f;
 #pragma unroll
             for (int src = 0; src < 2; ++src) {
                 if (src && !r1p) break;
                 const float *row = (src ? r1p : r1) + pg_oix<NF>((size_t)d * NT * 32 + nn, 0);
-                rcf[src] = row[64 * Q];
+                R.rcf[src] = row[64 * Q];
 #pragma unroll
                 for (int q = 0; q < QB; ++q) {
                     const bool lq = q0 + q < Q;
-                    ra[src][q] = lq ? row[64 * (q0 + q)] : 0.0f;
-                    rb[src][q] = lq ? row[64 * (q0 + q) + 32] : 0.0f;
+                    R.ra[src][q] = lq ? row[64 * (q0 + q)] : 0.0f;
+                    R.rb[src][q] = lq ? row[64 * (q0 + q) + 32] : 0.0f;
                 }
-                if (src) yv = y[(size_t)nn * ldy + d];
+                if (src) R.yv = y[(size_t)nn * ldy + d];
             }
+        };
+        auto work = [&](const Rows &R, int dd) __attribute__((always_inline)) {
+            const int d = d0 + dd;
+            double dg[QB];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) dg[q] = 0.0;
 #pragma unroll
             for (int src = 0; src < 2; ++src) {
                 if (src && !r1p) break;
-                const double ik = src ? iksh[dd][1] * yv : iksh[dd][0];
-                const double rc = (double)rcf[src] * ik;
+                const double ik = src ? iksh[dd][1] * R.yv : iksh[dd][0];
+                const double rc = (double)R.rcf[src] * ik;
 #pragma unroll
                 for (int q = 0; q < QB; ++q)
                     if (q0 + q < Q)
-                        pg_obs_chain_q((double)ra[src][q] * ik, (double)rb[src][q] * ik, rc, gsh[dd][q], mc[q], sv[q], src, am[q], as_[q], dg[q]);
+                        pg_obs_chain_q((double)R.ra[src][q] * ik, (double)R.rb[src][q] * ik, rc, gsh[dd][q], mc[q], sv[q], src, am[q], as_[q], dg[q]);
             }
             if (!ok) {
 #pragma unroll
@@ -1118,6 +1121,16 @@ __global__ __launch_bounds__(256) void pg_finish_obs_kernel(int N, int Q, int D,
             const double tot = pg_wave_reduce4(dg, lane);
             const int qi = q0 + (lane >> 4);
             if ((lane & 15) == 0 && qi < Q) dgw[(size_t)d * Q + qi] = tot;
+        };
+        Rows Ra, Rb;
+        fetch(Ra, 0);
+        for (int dd = 0; dd < nd; dd += 2) {
+            if (dd + 1 < nd) fetch(Rb, dd + 1);
+            work(Ra, dd);
+            if (dd + 1 < nd) {
+                if (dd + 2 < nd) fetch(Ra, dd + 2);
+                work(Rb, dd + 1);
+            }
         }
     }
     if (ok) {
