@@ -918,7 +918,7 @@ def dp_gp_lvm_t(y_train,
     def _local_flat():
         """The same with the model-level ends in the HIP library: dpgp_model_prepare_t (softplus / softmax transforms, phi), f_hat and
         its derivatives with respect to (x_mean, S, x_u, atoms, phi) from the library's operators (_fhat_forward / _fhat_backward),
-        dpgp_model_backward_t (chain rule to the raw variables, KL, DP objective, hyper-prior): ~110 launches instead of ~540.
+        dpgp_model_backward_t (chain rule to the raw variables, KL, DP objective, hyper-prior): ~200 launches instead of ~540.
         Sharded: the replicated terms are added on rank 0 only (add_constants); the ranks' packed gradients sum to the gradient."""
         if os.environ.get('DPGP_T_AUTOGRAD', '0') == '1':
             return _local_flat_autograd()
