@@ -721,16 +721,15 @@ def dp_gp_lvm_t(y_train,
 
     def _fhat_forward(x_mean_, s_, x_u_, gat, aat, bat, phit, for_backward=True):
         """f_hat of dp_gp_lvm.py:617-667 from the library's operators; returns (f_hat, what the backward pass needs).
-        for_backward: K^-1 and B^-1 are formed once here (two triangular solves on the identity + two products) and serve the trace,
+        for_backward: K^-1 and B^-1 are formed once here (two inverses of the triangular factors + two products) and serve the trace,
         the solve against V and the whole backward pass — six latency-bound batched solves of T small matrices otherwise."""
         psi_1, psi_2, k_uu, l_k, l_b = _chain(x_u_, x_mean_, s_, gat, aat, bat)
         v = ops.matmul(psi_1.transpose(1, 2), y_dev)                       # [T x M x D]
         k_inv = b_inv = None
         if for_backward:
-            eyes = torch.eye(m_, dtype=TORCH_DTYPE, device=device).expand(gat.shape[0], m_, m_).contiguous()
-            li = ops.trsm_batched(l_k, eyes)
+            li = ops.tril_inverse_batched(l_k)                             # (M a multiple of 128: the persistent solve, one launch)
             k_inv = ops.matmul(li.transpose(1, 2), li)
-            li = ops.trsm_batched(l_b, eyes)
+            li = ops.tril_inverse_batched(l_b)
             b_inv = ops.matmul(li.transpose(1, 2), li)
             tr = torch.sum(k_inv * psi_2, dim=(1, 2))                        # tr(L^-1 Psi2 L^-T) = <K^-1, Psi2>
             c = ops.matmul(li, v)                                          # L_B^-1 V
