@@ -292,19 +292,18 @@ static int grad_psi_mixed(int D, int N, int M, int Q, const double *y, int ldy, 
     const bool big = dpgp_round_up(M, 16) > 128;             // the plain kernel holds one row of the M x M statistics per thread
     if (big && !fast) return -30;
     int rc = DPGP_OK;
-    if (!big) {
-        if (g_psi1 && !fast) return -15;
-        rc = launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v ? g_v : w_kuu, (double *)ws,
-                                    d_mu, d_s, d_z, d_gamma, fast ? 0 : 1, st);
-        if (rc != DPGP_OK || !fast) return rc;
+    if (!big && !fast) {                                     // everything by the plain kernel (Q > DPGP_MAX_Q-type shapes, experiments)
+        if (g_psi1) return -15;
+        return launch_psi_grad<float>(D, N, M, Q, y, ldy, z, mu, s, gamma, alpha, g_psi2, w_kuu, g_v ? g_v : w_kuu, (double *)ws,
+                                      d_mu, d_s, d_z, d_gamma, 1, st);
     }
     const GradPsiWs W = grad_psi_ws(D, N, M, Q, ws, patch_form);
     const unsigned char *consts = fwd_consts ? fwd_consts : W.consts;
     if (!fwd_consts && (rc = launch_psi2_consts<double>(z, M, Q, W.consts, st)) != DPGP_OK) return rc;
-    if (big) {                                               // K_uu term for any M (partials in the plain kernel's workspace)
-        rc = launch_kuu_grad(D, M, Q, consts, gamma, w_kuu, (double *)ws, W.stage, d_z, d_gamma, st);
-        if (rc != DPGP_OK) return rc;
-    }
+    // K_uu term, any M: kuu_grad_kernel, (64 rows, output dim) per workgroup (partials in the plain kernel's workspace).  For M <= 128 the
+    // plain kernel's K_uu-only mode did this with one workgroup per output dim: 51 us at config 3
+    rc = launch_kuu_grad(D, M, Q, consts, gamma, w_kuu, (double *)ws, W.stage, d_z, d_gamma, st);
+    if (rc != DPGP_OK) return rc;
     // the Psi2 term: pair-tile form (psi2_pairs_grad.hip) where it exists, else the per-observation patch form; the Psi1 term: the
     // pair-tile form's passes on the diagonal pairs (rank-1 adjoint), else the reduction-free kernels of grad.hip
     const bool pair_form = psi2_pgrad_supported(M, Q) && !patch_form && !getenv("DPGP_GRAD_PATCH");      // (DPGP_GRAD_PATCH: experiments)
