@@ -212,6 +212,32 @@ def test_trsm_many_right_hand_sides(dev, shape):
     close(x, x_ref, dict(rtol=1e-10, atol_rel=1e-12), 'trsm')
 
 
+@pytest.mark.parametrize('n', [7, 5000, 300001])
+def test_trouble_flag(dev, n):
+    """dpgp_trouble_flag: 1.0 iff any info != 0 or any non-finite value among flat[0..n) (the value optimise() branches on where the
+    reference's tf.cholesky raises); the flag word itself lies behind the scanned range."""
+    from dp_gp_lvm_amd import _lib
+    l = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(n)
+    flat = torch.as_tensor(np.append(rng.standard_normal(n), 123.0), dtype=torch.float64, device=dev)
+    info = torch.zeros(37, dtype=torch.int32, device=dev)
+
+    def flag():
+        _lib.check(l.dpgp_trouble_flag(n, flat.data_ptr(), info.numel(), info.data_ptr(), flat[-1:].data_ptr(), st), 'dpgp_trouble_flag')
+        return float(flat[-1])
+    assert flag() == 0.0
+    for bad in (float('nan'), float('inf'), -float('inf')):
+        pos = int(rng.integers(0, n))
+        keep = float(flat[pos])
+        flat[pos] = bad
+        assert flag() == 1.0
+        flat[pos] = keep
+        assert flag() == 0.0
+    info[int(rng.integers(0, 37))] = -2
+    assert flag() == 1.0
+
+
 @pytest.mark.parametrize('m', [128, 256, 512, 200])
 def test_inverse_of_a_lower_triangular_factor(dev, m):
     """tf.matrix_triangular_solve(l, eye): the persistent-workgroup solve with every block row stored (M a multiple of 128), the
