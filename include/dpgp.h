@@ -248,7 +248,10 @@ int dpgp_elbo_grad_psi_ex(int D, int N, int M, int Q, const double *y, int ldy, 
  * Mixed precision (prec = DPGP_PREC_MIXED, as of the three calls it replaces: dpgp_elbo_fhat_ex + dpgp_elbo_grad_chain +
  * dpgp_elbo_grad_psi; or DPGP_PREC_MIXED_FAST for stage B), M <= 128 (-3), Q <= 20 (-4).  Same results as the three calls within the mixed-precision tolerance; the
  * Psi2 statistic comes out of the first pass of stage B (same exponentials, constant feature), so its exponentials are
- * evaluated twice per step instead of three times.
+ * evaluated twice per step instead of three times — the minimum: Psi2 is needed before the adjoints exist, the observation-side sums
+ * after; Psi1^T y likewise comes out of the Psi1 term's adjoint-free pass (its y-weighted constant feature).  exec (may be NULL): with
+ * stream_aux / ev_fork / ev_join set and D <= 256 the K_uu branch and stage A run on the second stream beside the image build and
+ * chain_b (few output dims leave most of the chip idle); the streams are joined again on every way out.
  *   terms / sums / info / ws: as dpgp_elbo_fhat (ws: dpgp_elbo_workspace_bytes(D,N,M,Q,DPGP_PREC_MIXED));
  *   g_psi2 / w_kuu / g_v / d_alpha_beta / info_grad: as dpgp_elbo_grad_chain (outputs, caller-allocated);
  *   gws: dpgp_elbo_grad_psi_workspace_bytes_ex(D,N,M,Q,DPGP_PREC_MIXED);  d_mu / d_s / d_z / d_gamma: as dpgp_elbo_grad_psi.   */
